@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py — Mreads/s of exact deduplication on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one batch of synthetic 150-bp reads already
+resident in HBM: empty the set, encode + insert every read, produce keep flags.
+  N = 1 : BASELINE.json configs[1] — 100 M single-end 150 bp reads, ~20 % duplicates.
+  N > 1 : weak scaling, the same per-GPU batch on every rank; reads are sharded by hash
+          prefix with an all-to-all over RCCL (fastq-dupaway_amd/sharded.py).
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under
+python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0        # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads (pairs) per GPU per step")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--paired", action="store_true", help="configs[2]: 2x150 bp pair-hash")
+    ap.add_argument("--dup-permille", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="reads timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(bases, n_sample, L, paired, bases2):
+    """The oracle (CPU restatement of the reference's --fast loop: base-5 17-mer keys,
+    std::unordered_set, find-then-insert) timed single-threaded on a prefix of the SAME
+    workload.  Reported beside the GPU number; never the thing measured."""
+    import numpy as np
+    from oracle import binding
+    oracle = binding.load_oracle()
+    host = bases[: n_sample * L].cpu().numpy()
+    offs = np.arange(n_sample, dtype=np.uint64) * np.uint64(L)
+    lens = np.full(n_sample, L, np.uint32)
+    t0 = time.perf_counter()
+    if paired:
+        host2 = bases2[: n_sample * L].cpu().numpy()
+        keep = oracle.dedup_paired(host, offs, lens, host2, offs, lens)
+    else:
+        keep = oracle.dedup_single(host, offs, lens)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_sample / dt / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_sample} reads of the same synthetic workload, in-memory arrays "
+                      f"(no file parsing or output), {dt:.1f} s; host has {os.cpu_count()} cores, the reference "
+                      f"path is single-threaded"}, keep
+
+
+def main():
+    a = parse()
+    import torch
+    import fastq_dupaway_amd as fqd
+    from fastq_dupaway_amd import Engine, Reads
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    n, L, S = a.reads, a.read_len, (2 if a.paired else 1)
+    dev = torch.device("cuda", local)
+    bases = [torch.empty(n * L + 16, dtype=torch.uint8, device=dev) for _ in range(S)]
+    expect = torch.empty(n, dtype=torch.uint8, device=dev)
+    keep = torch.empty(n, dtype=torch.uint8, device=dev)
+
+    eng = Engine(segments=S, device=local, capacity_reads=n, capacity_bases=S * n * L, profile=True)
+    first = rank * n
+    for m in range(S):
+        eng.synth_reads(a.seed, first, n, L, a.dup_permille, m, bases[m], expect if m == S - 1 else None)
+    eng.sync()
+    segs = [Reads(bases[m], uniform_len=L, uniform_stride=L) for m in range(S)]
+
+    if world > 1:
+        from fastq_dupaway_amd.sharded import ShardedDedup
+        sharded = ShardedDedup(eng, dist, dev, n_max=n, len0=L, len1=(L if S == 2 else 0))
+
+        def step():
+            eng.reset()
+            sharded.dedup(segs, n, keep)
+            eng.sync()
+    else:
+        def step():
+            eng.reset()
+            eng.submit(segs, n, keep=keep)
+            eng.sync()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    parity = "skipped"
+    if not a.no_verify:
+        # world == 1: closed-form flags of the generator.  world > 1: copies may point at other
+        # ranks' reads, the closed form still holds globally (first occurrence = the non-copy).
+        ok = bool(torch.equal(keep, expect)) if a.warmup > 0 else None
+        if ok is False:
+            sys.exit(f"rank {rank}: keep flags differ from the generator's closed form — result invalid")
+        parity = "keep flags == closed-form flags of the generator on every rank" if ok else "skipped (no warmup step)"
+    eng.reset_profile()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = eng.profile()
+
+    if rank == 0:
+        ms_step = dt / a.steps * 1e3
+        value = world * n * a.steps / dt / 1e6
+        bytes_per_unit = S * L                       # sequence bytes read once from HBM
+        kernels = {}
+        for k in ("encode", "insert"):
+            if prof[f"{k}_launches"]:
+                avg_ms = prof[f"{k}_ms"] / prof[f"{k}_launches"]
+                per_launch = prof[f"{k}_reads"] / prof[f"{k}_launches"]
+                kernels[k] = {"avg_ms": round(avg_ms, 4), "launches": prof[f"{k}_launches"],
+                              "GBps": round(per_launch * bytes_per_unit / (avg_ms * 1e-3) / 1e9, 1)}
+        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+        roofline = {"bound": "hbm", "kernel": f"fqd::{dom}_kernel", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_unit": bytes_per_unit, "kernels": kernels,
+                    "whole_step_frac": round(value * 1e6 / world * bytes_per_unit / 1e9 / HBM_PEAK_GBS, 4)}
+        out = {"metric": "Mreads/s dedup, 150 bp %s FASTQ" % ("PE" if a.paired else "SE"),
+               "value": round(value, 2), "unit": "Mreads/s" if not a.paired else "Mpairs/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+               "data": "synthetic",
+               "config": {"workload": ("100M paired-end 2x150 bp, --fast pair-hash" if a.paired and n == 100_000_000 else
+                                       "100M single-end 150 bp FASTQ (~20% dups), --fast" if n == 100_000_000 else
+                                       f"{n} {'pairs' if a.paired else 'reads'} x {L} bp per GPU"),
+                          "reads_per_gpu": n, "read_len": L, "dup_fraction": a.dup_permille / 1000.0,
+                          "sharding": "none" if world == 1 else f"hash-prefix all-to-all over {world} GPUs"},
+               "parity": parity, "roofline": roofline}
+        if world == 1 and a.cpu_sample > 0:
+            m = min(a.cpu_sample, n)
+            cb, cpu_keep = cpu_baseline(bases[0], m, L, a.paired, bases[1] if S == 2 else None)
+            import numpy as np
+            if not np.array_equal(cpu_keep, keep[:m].cpu().numpy()):
+                sys.exit("GPU keep flags differ from the CPU oracle on the baseline sample — result invalid")
+            out["cpu_baseline"] = cb
+            out["parity"] += f"; == CPU oracle on the first {m}"
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""Locates, builds and loads lib/libfqdupaway.so and declares the C ABI to ctypes."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_ROOT = PKG_DIR.parent
+LIB_PATH = PKG_DIR / "lib" / "libfqdupaway.so"
+CLI_PATH = PKG_DIR / "bin" / "fastq-dupaway"
+HEADER = REPO_ROOT / "include" / "fqdupaway.h"
+
+OK, ERR_ARG, ERR_HIP, ERR_BAD_BASE, ERR_CAPACITY, ERR_NO_DEVICE = range(6)
+MEM_HOST, MEM_DEVICE = 0, 1
+FLAG_PROFILE, FLAG_NO_STAGE = 1, 2
+
+
+class FqdError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"fqdupaway error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("segments", C.c_int32), ("capacity_reads", C.c_uint64),
+                ("capacity_bases", C.c_uint64), ("stream", C.c_void_p), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class ReadsDesc(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("offsets", C.c_void_p), ("lengths", C.c_void_p),
+                ("uniform_len", C.c_uint32), ("uniform_stride", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("records", C.c_uint64), ("duplicates", C.c_uint64), ("table_slots", C.c_uint64), ("key_bytes", C.c_uint64)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("encode_ms", C.c_double), ("encode_launches", C.c_uint64), ("encode_reads", C.c_uint64),
+                ("insert_ms", C.c_double), ("insert_launches", C.c_uint64), ("insert_reads", C.c_uint64),
+                ("other_ms", C.c_double), ("other_launches", C.c_uint64)]
+
+
+def build_native(target: str = "all") -> None:
+    """hipcc --offload-arch=gfx950 build of the library (and CLI); cross-compiles without a GPU."""
+    subprocess.run(["make", "-s", "-C", str(PKG_DIR), target], check=True)
+
+
+def declared_symbols():
+    """Every function name include/fqdupaway.h declares."""
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(fqd_[a-z_0-9]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load_library():
+    """Loads the HIP library or raises: there is deliberately no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise FqdError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: run __graft_entry__.build() "
+                                      f"(make -C {PKG_DIR}); this engine has no CPU path")
+    L = C.CDLL(str(LIB_PATH))
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    L.fqd_abi_version.restype = i32
+    L.fqd_device_count.argtypes = [C.POINTER(i32)]
+    L.fqd_engine_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.fqd_engine_destroy.argtypes = [vp]
+    L.fqd_engine_reset.argtypes = [vp]
+    L.fqd_submit.argtypes = [vp, C.POINTER(ReadsDesc), u64, i32, vp]
+    L.fqd_engine_sync.argtypes = [vp]
+    L.fqd_bad_base.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint8)]
+    L.fqd_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.fqd_get_profile.argtypes = [vp, C.POINTER(Profile)]
+    L.fqd_reset_profile.argtypes = [vp]
+    L.fqd_last_error.argtypes = [vp]
+    L.fqd_last_error.restype = C.c_char_p
+    L.fqd_key_words.argtypes = [u32, u32]
+    L.fqd_key_words.restype = u32
+    L.fqd_encode_uniform.argtypes = [vp, C.POINTER(ReadsDesc), u64, vp]
+    L.fqd_partition_records.argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
+    L.fqd_insert_records.argtypes = [vp, vp, u64, u32, u32, vp]
+    L.fqd_synth_reads.argtypes = [vp, u64, u64, u64, u32, u32, i32, vp, vp]
+    for name in declared_symbols():
+        fn = getattr(L, name)          # AttributeError here = header and library disagree
+        if name not in ("fqd_last_error", "fqd_key_words"):
+            fn.restype = i32
+    _lib = L
+    return L

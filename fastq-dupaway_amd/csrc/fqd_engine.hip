@@ -1,0 +1,640 @@
+// fqd_engine.hip — the C-ABI library (include/fqdupaway.h) over the gfx950 kernels.
+//
+// One engine = one HBM-resident exact set of sequence keys on one MI355X:
+//   table  : open addressing, 8-byte slots (tag:32 | first record index:32), <= 50 % load
+//   keys   : packed key words of EVERY record submitted so far (64 B per 150-bp read),
+//            so a tag match can always be verified word-for-word
+// It stands where the reference keeps `std::unordered_set<setRecord>` plus its
+// find/insert loop (hash_dup_remover.hpp:70-71,113-144,206-248).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fqdupaway.h"
+#include "fqd_kernels.hpp"
+
+using namespace fqd;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+enum Kind { K_ENCODE = 0, K_INSERT = 1, K_OTHER = 2 };
+
+struct Timed { hipEvent_t a, b; int kind; uint64_t reads; };
+
+} // namespace
+
+struct fqd_engine {
+    int          device = 0;
+    int          S = 1;
+    uint32_t     flags = 0;
+    hipStream_t  stream = nullptr;
+    bool         own_stream = false;
+    int          n_cu = 256;
+
+    DevBuf   table;    uint64_t slots = 0;
+    DevBuf   keys;     uint64_t keys_used = 0;       // words
+    DevBuf   koff;                                   // ragged only: word offset per record
+    bool     ragged = false, have_shape = false;
+    uint32_t L0 = 0, L1 = 0, W0 = 0;
+    uint64_t n_records = 0;
+    uint64_t cap_hint_reads = 0, cap_hint_bases = 0;
+
+    DevBuf   hashes;                                 // per-batch placement hashes
+    DevBuf   scan_scratch;
+    DevBuf   part_scratch;
+    DevBuf   st_bases[2], st_off[2], st_len[2], st_keep;   // staging for host-space submits
+    uint64_t* d_state = nullptr;                     // [0] error word, [1] dups, [2] table-full
+    uint64_t* h_state = nullptr;                     // pinned mirror
+
+    std::string last_error;
+    bool     has_bad = false;
+    uint64_t bad_record = 0; uint32_t bad_seg = 0, bad_pos = 0; uint8_t bad_byte = 0;
+
+    std::vector<Timed>      pending;
+    std::vector<hipEvent_t> free_events;
+    fqd_profile prof{};
+
+    int fail(int code, const std::string& msg) { last_error = msg; return code; }
+    int fail_hip(const char* what, hipError_t err)
+    {
+        last_error = std::string(what) + ": " + hipGetErrorString(err);
+        return FQD_ERR_HIP;
+    }
+};
+
+#define HIP_TRY(e, expr)                                                       \
+    do { hipError_t _err = (expr); if (_err != hipSuccess) return (e)->fail_hip(#expr, _err); } while (0)
+
+namespace {
+
+inline uint64_t pow2_at_least(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
+inline uint32_t grid_for(const fqd_engine* e, uint64_t n, uint32_t per_block = kBlock)
+{
+    const uint64_t want = (n + per_block - 1) / per_block;
+    const uint64_t cap = uint64_t(e->n_cu) * 8u;
+    return uint32_t(std::max<uint64_t>(1, std::min(want, cap)));
+}
+
+// Grows a buffer to `bytes`; when `used` > 0 the first `used` bytes are carried over.
+int reserve(fqd_engine* e, DevBuf& b, size_t bytes, size_t used = 0)
+{
+    if (bytes <= b.cap) return FQD_OK;
+    size_t want = std::max(bytes, b.cap + b.cap / 2);
+    want = (want + 255) & ~size_t(255);
+    void* np = nullptr;
+    HIP_TRY(e, hipMalloc(&np, want));
+    if (used && b.p) {
+        hipError_t err = hipMemcpyAsync(np, b.p, used, hipMemcpyDeviceToDevice, e->stream);
+        if (err != hipSuccess) { (void)hipFree(np); return e->fail_hip("hipMemcpyAsync(grow)", err); }
+    }
+    if (b.p) {
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        HIP_TRY(e, hipFree(b.p));
+    }
+    b.p = np; b.cap = want;
+    return FQD_OK;
+}
+
+void release(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+// ---- profiling brackets ---------------------------------------------------------
+hipEvent_t take_event(fqd_engine* e)
+{
+    if (!e->free_events.empty()) { hipEvent_t ev = e->free_events.back(); e->free_events.pop_back(); return ev; }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+}
+struct Bracket {
+    fqd_engine* e; Timed t; bool on;
+    Bracket(fqd_engine* eng, int kind, uint64_t reads) : e(eng), on((eng->flags & FQD_FLAG_PROFILE) != 0)
+    {
+        if (!on) return;
+        t.a = take_event(e); t.b = take_event(e); t.kind = kind; t.reads = reads;
+        (void)hipEventRecord(t.a, e->stream);
+    }
+    ~Bracket() { if (on) { (void)hipEventRecord(t.b, e->stream); e->pending.push_back(t); } }
+};
+void drain_profile(fqd_engine* e)
+{
+    for (const Timed& t : e->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            if (t.kind == K_ENCODE)      { e->prof.encode_ms += ms; e->prof.encode_launches++; e->prof.encode_reads += t.reads; }
+            else if (t.kind == K_INSERT) { e->prof.insert_ms += ms; e->prof.insert_launches++; e->prof.insert_reads += t.reads; }
+            else                         { e->prof.other_ms += ms;  e->prof.other_launches++; }
+        }
+        e->free_events.push_back(t.a); e->free_events.push_back(t.b);
+    }
+    e->pending.clear();
+}
+
+// ---- exclusive scan of uint64 (in place), returns device pointer to the grand total ----
+int scan_exclusive(fqd_engine* e, uint64_t* data, uint64_t n, uint64_t add, const uint64_t** total_out)
+{
+    // level sizes
+    std::vector<uint64_t> sizes; sizes.push_back(n);
+    while (sizes.back() > 1) sizes.push_back((sizes.back() + kScanTile - 1) / kScanTile);
+    if (sizes.size() == 1) sizes.push_back(1);        // n == 1: still one tile
+    uint64_t scratch_words = 0;
+    for (size_t l = 1; l < sizes.size(); ++l) scratch_words += sizes[l];
+    scratch_words += 1;
+    int rc = reserve(e, e->scan_scratch, scratch_words * sizeof(uint64_t));
+    if (rc) return rc;
+    std::vector<uint64_t*> lvl(sizes.size());
+    lvl[0] = data;
+    uint64_t* s = e->scan_scratch.as<uint64_t>();
+    for (size_t l = 1; l < sizes.size(); ++l) { lvl[l] = s; s += sizes[l]; }
+    uint64_t* top_total = s;
+    // upsweep: scan tiles of each level, totals become the next level
+    for (size_t l = 0; l + 1 < sizes.size(); ++l) {
+        const uint32_t tiles = uint32_t((sizes[l] + kScanTile - 1) / kScanTile);
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(kBlock), 0, e->stream, lvl[l], sizes[l], lvl[l + 1]);
+    }
+    // the last level has one element = grand total; keep a copy, then make it an exclusive prefix (0)
+    HIP_TRY(e, hipMemcpyAsync(top_total, lvl[sizes.size() - 1], sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(e, hipMemsetAsync(lvl[sizes.size() - 1], 0, sizeof(uint64_t), e->stream));
+    // downsweep
+    for (size_t l = sizes.size() - 1; l-- > 0;) {
+        const uint64_t a = (l == 0) ? add : 0;
+        hipLaunchKernelGGL(scan_add_kernel, dim3(grid_for(e, sizes[l])), dim3(kBlock), 0, e->stream,
+                           lvl[l], sizes[l], static_cast<const uint64_t*>(lvl[l + 1]), a);
+    }
+    HIP_TRY(e, hipGetLastError());
+    if (total_out) *total_out = top_total;
+    return FQD_OK;
+}
+
+// Keeps the table at <= 50 % load.  `exact`: size for a known total (capacity hint);
+// otherwise grow geometrically so rehashes stay rare.
+int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
+{
+    if (e->slots >= 2 * records_after && e->slots) return FQD_OK;
+    const uint64_t want = std::max<uint64_t>(pow2_at_least((exact ? 2 : 4) * records_after), 1ull << 16);
+    void* nt = nullptr;
+    HIP_TRY(e, hipMalloc(&nt, want * sizeof(uint64_t)));
+    HIP_TRY(e, hipMemsetAsync(nt, 0xFF, want * sizeof(uint64_t), e->stream));
+    if (e->slots && e->n_records) {
+        Bracket br(e, K_OTHER, 0);
+        KeyStore ks{e->keys.as<uint64_t>(), e->ragged ? e->koff.as<uint64_t>() : nullptr, e->W0, e->W0, 0};
+        hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(e, e->slots)), dim3(kBlock), 0, e->stream,
+                           e->table.as<uint64_t>(), e->slots, static_cast<uint64_t*>(nt), want - 1, ks, e->L0, e->L1);
+    }
+    if (e->table.p) {
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+        HIP_TRY(e, hipFree(e->table.p));
+    }
+    e->table.p = nt; e->table.cap = want * sizeof(uint64_t); e->slots = want;
+    return FQD_OK;
+}
+
+// Switches a uniform engine to the ragged layout (headers + per-record offsets).
+int convert_to_ragged(fqd_engine* e, uint64_t records_after)
+{
+    const uint64_t cap = std::max<uint64_t>(records_after, e->cap_hint_reads);
+    if (e->n_records == 0 || !e->have_shape) {
+        int rc = reserve(e, e->koff, cap * sizeof(uint64_t));
+        if (rc) return rc;
+        e->ragged = true; e->have_shape = true; e->keys_used = 0;
+        return FQD_OK;
+    }
+    DevBuf nk, no;
+    const uint64_t words = e->n_records * uint64_t(e->W0 + 1);
+    int rc = reserve(e, nk, std::max<uint64_t>(words * 2, 1024) * sizeof(uint64_t));
+    if (rc) return rc;
+    rc = reserve(e, no, cap * sizeof(uint64_t));
+    if (rc) { release(nk); return rc; }
+    {
+        Bracket br(e, K_OTHER, 0);
+        const uint64_t header = uint64_t(e->L0) | (uint64_t(e->L1) << 32);
+        hipLaunchKernelGGL(relayout_ragged_kernel, dim3(grid_for(e, words)), dim3(kBlock), 0, e->stream,
+                           e->keys.as<uint64_t>(), nk.as<uint64_t>(), no.as<uint64_t>(), e->n_records, e->W0, header);
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    release(e->keys); release(e->koff);
+    e->keys = nk; e->koff = no; e->keys_used = words; e->ragged = true;
+    return FQD_OK;
+}
+
+struct StagedChoice { bool staged; uint32_t R; uint32_t tile0, tile1; };
+
+StagedChoice choose_staged(const fqd_engine* e, const fqd_reads* seg, bool uniform)
+{
+    StagedChoice c{false, 0, 0, 0};
+    if (!uniform || (e->flags & FQD_FLAG_NO_STAGE)) return c;
+    for (uint32_t R = 256; R >= 64; R -= 64) {
+        uint64_t t0 = (uint64_t(R) * seg[0].uniform_stride + 32 + 15) & ~15ull;
+        uint64_t t1 = (e->S == 2) ? ((uint64_t(R) * seg[1].uniform_stride + 32 + 15) & ~15ull) : 0;
+        if (t0 + t1 <= 64 * 1024) { c = {true, R, uint32_t(t0), uint32_t(t1)}; return c; }
+    }
+    return c;
+}
+
+int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_reads* seg, uint64_t n,
+                  uint64_t first_idx, const KeyStore& ks, uint64_t* hash_out)
+{
+    Bracket br(e, K_ENCODE, n);
+    const StagedChoice c = choose_staged(e, seg, uniform);
+    uint64_t* err = e->d_state;
+    if (c.staged) {
+        const uint32_t grid = uint32_t(std::min<uint64_t>((n + c.R - 1) / c.R, uint64_t(e->n_cu) * 8u));
+        const size_t lds = size_t(c.tile0) + c.tile1;
+        if (e->S == 1)
+            hipLaunchKernelGGL(encode_staged_kernel<1>, dim3(grid), dim3(c.R), lds, e->stream,
+                               sv[0], sv[1], n, first_idx, ks, hash_out, err, c.tile0, c.tile1);
+        else
+            hipLaunchKernelGGL(encode_staged_kernel<2>, dim3(grid), dim3(c.R), lds, e->stream,
+                               sv[0], sv[1], n, first_idx, ks, hash_out, err, c.tile0, c.tile1);
+    } else {
+        if (e->S == 1)
+            hipLaunchKernelGGL(encode_general_kernel<1>, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
+                               sv[0], sv[1], n, first_idx, ks, hash_out, err);
+        else
+            hipLaunchKernelGGL(encode_general_kernel<2>, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
+                               sv[0], sv[1], n, first_idx, ks, hash_out, err);
+    }
+    HIP_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+int launch_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes, uint32_t hash_stride,
+                  uint64_t n, uint64_t first_idx, uint8_t* keep)
+{
+    {
+        Bracket br(e, K_OTHER, 0);
+        HIP_TRY(e, hipMemsetAsync(keep, 1, n, e->stream));
+    }
+    Bracket br(e, K_INSERT, n);
+    hipLaunchKernelGGL(insert_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
+                       e->table.as<uint64_t>(), e->slots - 1, ks, hashes, hash_stride, n, uint32_t(first_idx), keep,
+                       reinterpret_cast<unsigned long long*>(e->d_state + 1));
+    HIP_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+// Reads back the state words after the stream is idle and turns them into a status.
+int check_state(fqd_engine* e)
+{
+    HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->flags & FQD_FLAG_PROFILE) drain_profile(e);
+    if (e->h_state[2] != 0)
+        return e->fail(FQD_ERR_HIP, "internal: hash set overflowed its table");
+    if (e->h_state[0] != kNoError) {
+        const uint64_t w = e->h_state[0];
+        e->has_bad = true;
+        e->bad_record = w >> 32; e->bad_seg = uint32_t((w >> 31) & 1u);
+        e->bad_pos = uint32_t((w >> 8) & 0x7FFFFFu); e->bad_byte = uint8_t(w & 0xFFu);
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "unknown character in DNA sequence: byte 0x%02x at record %llu, mate %u, position %u",
+                      unsigned(e->bad_byte), static_cast<unsigned long long>(e->bad_record), e->bad_seg + 1, e->bad_pos);
+        return e->fail(FQD_ERR_BAD_BASE, buf);
+    }
+    return FQD_OK;
+}
+
+bool seg_is_uniform(const fqd_reads& r) { return r.offsets == nullptr && r.lengths == nullptr; }
+
+} // namespace
+
+// =============================== C ABI ==========================================
+extern "C" {
+
+int fqd_abi_version(void) { return FQD_ABI_VERSION; }
+
+int fqd_device_count(int* count)
+{
+    if (!count) return FQD_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return FQD_ERR_NO_DEVICE; }
+    *count = n;
+    return FQD_OK;
+}
+
+uint32_t fqd_key_words(uint32_t len0, uint32_t len1) { return seg_words(len0) + seg_words(len1); }
+
+const char* fqd_last_error(const fqd_engine* e) { return e ? e->last_error.c_str() : g_create_error.c_str(); }
+
+int fqd_engine_create(const fqd_config* cfg, fqd_engine** out)
+{
+    if (!cfg || !out || (cfg->segments != 1 && cfg->segments != 2)) { g_create_error = "bad fqd_config"; return FQD_ERR_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+        g_create_error = "no HIP device available for the dedup engine (this library has no CPU path)";
+        return FQD_ERR_NO_DEVICE;
+    }
+    fqd_engine* e = new fqd_engine();
+    e->device = cfg->device; e->S = cfg->segments; e->flags = cfg->flags;
+    e->cap_hint_reads = cfg->capacity_reads; e->cap_hint_bases = cfg->capacity_bases;
+    auto bail = [&](const char* what, hipError_t err) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        delete e; return FQD_ERR_HIP;
+    };
+    hipError_t err;
+    if ((err = hipSetDevice(e->device)) != hipSuccess) return bail("hipSetDevice", err);
+    hipDeviceProp_t prop;
+    if ((err = hipGetDeviceProperties(&prop, e->device)) != hipSuccess) return bail("hipGetDeviceProperties", err);
+    e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (cfg->stream) { e->stream = static_cast<hipStream_t>(cfg->stream); }
+    else {
+        if ((err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", err);
+        e->own_stream = true;
+    }
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->d_state), 4 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc(state)", err);
+    if ((err = hipHostMalloc(reinterpret_cast<void**>(&e->h_state), 4 * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess)
+        return bail("hipHostMalloc(state)", err);
+    int rc = fqd_engine_reset(e);
+    if (rc == FQD_OK && cfg->capacity_reads) rc = ensure_table(e, cfg->capacity_reads, true);
+    if (rc == FQD_OK && cfg->capacity_bases) {
+        // 2 bits + 1 mask bit per base, rounded up per read: bases*3/8 bytes plus slack
+        const uint64_t words = cfg->capacity_bases * 3 / 64 + 2 * cfg->capacity_reads + 1024;
+        rc = reserve(e, e->keys, words * sizeof(uint64_t));
+    }
+    if (rc != FQD_OK) { g_create_error = e->last_error; fqd_engine_destroy(e); return rc; }
+    *out = e;
+    return FQD_OK;
+}
+
+int fqd_engine_destroy(fqd_engine* e)
+{
+    if (!e) return FQD_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    drain_profile(e);
+    for (hipEvent_t ev : e->free_events) (void)hipEventDestroy(ev);
+    release(e->table); release(e->keys); release(e->koff); release(e->hashes);
+    release(e->scan_scratch); release(e->part_scratch); release(e->st_keep);
+    for (int s = 0; s < 2; ++s) { release(e->st_bases[s]); release(e->st_off[s]); release(e->st_len[s]); }
+    if (e->d_state) (void)hipFree(e->d_state);
+    if (e->h_state) (void)hipHostFree(e->h_state);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return FQD_OK;
+}
+
+int fqd_engine_reset(fqd_engine* e)
+{
+    if (!e) return FQD_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (e->table.p) {
+        Bracket br(e, K_OTHER, 0);
+        HIP_TRY(e, hipMemsetAsync(e->table.p, 0xFF, e->slots * sizeof(uint64_t), e->stream));
+    }
+    e->h_state[0] = kNoError; e->h_state[1] = 0; e->h_state[2] = 0; e->h_state[3] = 0;
+    HIP_TRY(e, hipMemcpyAsync(e->d_state, e->h_state, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->n_records = 0; e->keys_used = 0; e->ragged = false; e->have_shape = false;
+    e->L0 = e->L1 = e->W0 = 0; e->has_bad = false; e->last_error.clear();
+    return FQD_OK;
+}
+
+int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!seg || (n && !keep) || (memory != FQD_MEM_HOST && memory != FQD_MEM_DEVICE))
+        return e->fail(FQD_ERR_ARG, "fqd_submit: bad arguments");
+    if (n == 0) return FQD_OK;
+    if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
+    HIP_TRY(e, hipSetDevice(e->device));
+    int rc;
+
+    bool uniform = true;
+    for (int s = 0; s < e->S; ++s) {
+        if (!seg[s].bases && !(seg_is_uniform(seg[s]) && seg[s].uniform_len == 0))
+            return e->fail(FQD_ERR_ARG, "fqd_submit: null bases");
+        if (!seg_is_uniform(seg[s])) {
+            if (!seg[s].offsets || !seg[s].lengths) return e->fail(FQD_ERR_ARG, "fqd_submit: offsets and lengths go together");
+            uniform = false;
+        }
+    }
+
+    // ---- host-space input: stage into device buffers ------------------------------
+    SegView sv[2] = {{nullptr, nullptr, nullptr, 0, 0}, {nullptr, nullptr, nullptr, 0, 0}};
+    uint64_t host_ragged_words = 0;                      // exact key words when lengths are on the host
+    uint8_t* d_keep = keep;
+    for (int s = 0; s < e->S; ++s) {
+        const fqd_reads& r = seg[s];
+        sv[s].ulen = r.uniform_len; sv[s].ustride = r.uniform_stride;
+        if (memory == FQD_MEM_DEVICE) { sv[s].bases = r.bases; sv[s].offsets = r.offsets; sv[s].lengths = r.lengths; continue; }
+        uint64_t extent = 0;
+        if (seg_is_uniform(r)) extent = (n - 1) * uint64_t(r.uniform_stride) + r.uniform_len;
+        else for (uint64_t i = 0; i < n; ++i) extent = std::max<uint64_t>(extent, r.offsets[i] + r.lengths[i]);
+        if ((rc = reserve(e, e->st_bases[s], extent + 16))) return rc;
+        if (extent) HIP_TRY(e, hipMemcpyAsync(e->st_bases[s].p, r.bases, extent, hipMemcpyHostToDevice, e->stream));
+        sv[s].bases = e->st_bases[s].as<uint8_t>();
+        if (!seg_is_uniform(r)) {
+            if ((rc = reserve(e, e->st_off[s], n * sizeof(uint64_t)))) return rc;
+            if ((rc = reserve(e, e->st_len[s], n * sizeof(uint32_t)))) return rc;
+            HIP_TRY(e, hipMemcpyAsync(e->st_off[s].p, r.offsets, n * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(e, hipMemcpyAsync(e->st_len[s].p, r.lengths, n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+            sv[s].offsets = e->st_off[s].as<uint64_t>(); sv[s].lengths = e->st_len[s].as<uint32_t>();
+        }
+    }
+    if (memory == FQD_MEM_HOST) {
+        if ((rc = reserve(e, e->st_keep, n))) return rc;
+        d_keep = e->st_keep.as<uint8_t>();
+        if (!uniform)
+            for (uint64_t i = 0; i < n; ++i) {
+                host_ragged_words += 1;
+                for (int s = 0; s < e->S; ++s)
+                    host_ragged_words += seg_words(seg[s].lengths ? seg[s].lengths[i] : seg[s].uniform_len);
+            }
+    }
+
+    // ---- shape: stay uniform while every record has the same mate lengths ----------
+    const uint32_t bl0 = seg[0].uniform_len, bl1 = (e->S == 2) ? seg[1].uniform_len : 0u;
+    if (!e->have_shape && uniform) {
+        e->have_shape = true; e->ragged = false; e->L0 = bl0; e->L1 = bl1; e->W0 = seg_words(bl0) + seg_words(bl1);
+    } else if (!e->ragged && (!uniform || bl0 != e->L0 || bl1 != e->L1)) {
+        if ((rc = convert_to_ragged(e, e->n_records + n))) return rc;
+    }
+
+    const uint64_t first = e->n_records;
+    if ((rc = ensure_table(e, first + n))) return rc;
+    if ((rc = reserve(e, e->hashes, n * sizeof(uint64_t)))) return rc;
+
+    uint64_t new_words = 0;
+    if (!e->ragged) {
+        new_words = n * uint64_t(e->W0);
+        if ((rc = reserve(e, e->keys, std::max<uint64_t>((e->keys_used + new_words), 64) * sizeof(uint64_t),
+                          e->keys_used * sizeof(uint64_t)))) return rc;
+    } else {
+        if ((rc = reserve(e, e->koff, (first + n) * sizeof(uint64_t), first * sizeof(uint64_t)))) return rc;
+        uint64_t* need = e->koff.as<uint64_t>() + first;
+        {
+            Bracket br(e, K_OTHER, 0);
+            if (e->S == 1) hipLaunchKernelGGL(slot_words_kernel<1>, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream, sv[0], sv[1], n, need);
+            else           hipLaunchKernelGGL(slot_words_kernel<2>, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream, sv[0], sv[1], n, need);
+            const uint64_t* total_dev = nullptr;
+            if ((rc = scan_exclusive(e, need, n, e->keys_used, &total_dev))) return rc;
+            if (uniform)                         new_words = n * uint64_t(1 + seg_words(bl0) + seg_words(bl1));
+            else if (memory == FQD_MEM_HOST)     new_words = host_ragged_words;
+            else {
+                HIP_TRY(e, hipMemcpyAsync(&e->h_state[3], total_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+                HIP_TRY(e, hipStreamSynchronize(e->stream));
+                new_words = e->h_state[3];
+            }
+        }
+        if ((rc = reserve(e, e->keys, std::max<uint64_t>((e->keys_used + new_words), 64) * sizeof(uint64_t),
+                          e->keys_used * sizeof(uint64_t)))) return rc;
+    }
+
+    KeyStore ks{e->keys.as<uint64_t>(), e->ragged ? e->koff.as<uint64_t>() : nullptr, e->W0, e->W0, 0};
+    if ((rc = launch_encode(e, sv, uniform, seg, n, first, ks, e->hashes.as<uint64_t>()))) return rc;
+    if ((rc = launch_insert(e, ks, e->hashes.as<uint64_t>(), 1, n, first, d_keep))) return rc;
+    e->n_records += n;
+    e->keys_used += new_words;
+
+    if (memory == FQD_MEM_HOST) {
+        HIP_TRY(e, hipMemcpyAsync(keep, d_keep, n, hipMemcpyDeviceToHost, e->stream));
+        return check_state(e);
+    }
+    return FQD_OK;
+}
+
+int fqd_engine_sync(fqd_engine* e)
+{
+    if (!e) return FQD_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    return check_state(e);
+}
+
+int fqd_bad_base(const fqd_engine* e, uint64_t* record, uint32_t* segment, uint32_t* position, uint8_t* byte)
+{
+    if (!e || !e->has_bad) return FQD_ERR_ARG;
+    if (record) *record = e->bad_record;
+    if (segment) *segment = e->bad_seg;
+    if (position) *position = e->bad_pos;
+    if (byte) *byte = e->bad_byte;
+    return FQD_OK;
+}
+
+int fqd_get_stats(fqd_engine* e, fqd_stats* out)
+{
+    if (!e || !out) return FQD_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    out->records = e->n_records; out->duplicates = e->h_state[1];
+    out->table_slots = e->slots; out->key_bytes = e->keys_used * sizeof(uint64_t);
+    return FQD_OK;
+}
+
+int fqd_get_profile(fqd_engine* e, fqd_profile* out)
+{
+    if (!e || !out) return FQD_ERR_ARG;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    drain_profile(e);
+    *out = e->prof;
+    return FQD_OK;
+}
+
+int fqd_reset_profile(fqd_engine* e)
+{
+    if (!e) return FQD_ERR_ARG;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    drain_profile(e);
+    e->prof = fqd_profile{};
+    return FQD_OK;
+}
+
+// ---- multi-GPU halves -------------------------------------------------------------
+
+int fqd_encode_uniform(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint64_t* records)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!seg || (n && !records)) return e->fail(FQD_ERR_ARG, "fqd_encode_uniform: bad arguments");
+    for (int s = 0; s < e->S; ++s)
+        if (!seg_is_uniform(seg[s])) return e->fail(FQD_ERR_ARG, "fqd_encode_uniform: uniform batches only");
+    if (n == 0) return FQD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    SegView sv[2] = {{nullptr, nullptr, nullptr, 0, 0}, {nullptr, nullptr, nullptr, 0, 0}};
+    for (int s = 0; s < e->S; ++s) { sv[s].bases = seg[s].bases; sv[s].ulen = seg[s].uniform_len; sv[s].ustride = seg[s].uniform_stride; }
+    const uint32_t W = seg_words(seg[0].uniform_len) + (e->S == 2 ? seg_words(seg[1].uniform_len) : 0u);
+    KeyStore ks{records, nullptr, W, W + 1, 1};
+    return launch_encode(e, sv, true, seg, n, 0, ks, nullptr);
+}
+
+int fqd_partition_records(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
+                          uint32_t n_parts, uint64_t* out, uint64_t* counts, uint32_t* origin)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!n_parts || n_parts > 1024 || !counts || (n && (!records || !out || !origin)) || n > 0xFFFFFFFFull)
+        return e->fail(FQD_ERR_ARG, "fqd_partition_records: bad arguments");
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (n == 0) { HIP_TRY(e, hipMemsetAsync(counts, 0, n_parts * sizeof(uint64_t), e->stream)); return FQD_OK; }
+    const uint32_t n_blocks = uint32_t((n + kBlock - 1) / kBlock);
+    const uint32_t rec_words = key_words + 1;
+    const uint64_t cells = uint64_t(n_parts) * n_blocks;
+    int rc = reserve(e, e->part_scratch, cells * sizeof(uint64_t));
+    if (rc) return rc;
+    uint64_t* c2 = e->part_scratch.as<uint64_t>();
+    Bracket br(e, K_OTHER, 0);
+    hipLaunchKernelGGL(part_count_kernel, dim3(n_blocks), dim3(kBlock), n_parts * sizeof(uint32_t), e->stream,
+                       records, n, rec_words, n_parts, c2, n_blocks);
+    if ((rc = scan_exclusive(e, c2, cells, 0, nullptr))) return rc;
+    hipLaunchKernelGGL(part_scatter_kernel, dim3(n_blocks), dim3(kBlock), n_parts * 4 * sizeof(uint32_t), e->stream,
+                       records, n, rec_words, n_parts, static_cast<const uint64_t*>(c2), n_blocks, out, origin);
+    hipLaunchKernelGGL(part_totals_kernel, dim3((n_parts + 63) / 64), dim3(64), 0, e->stream,
+                       static_cast<const uint64_t*>(c2), n_parts, n_blocks, n, counts);
+    HIP_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+int fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (n && (!records || !keep)) return e->fail(FQD_ERR_ARG, "fqd_insert_records: bad arguments");
+    if (e->S == 1 && len1 != 0) return e->fail(FQD_ERR_ARG, "fqd_insert_records: single-end engine given a mate-2 length");
+    if (n == 0) return FQD_OK;
+    if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (!e->have_shape) { e->have_shape = true; e->ragged = false; e->L0 = len0; e->L1 = len1; e->W0 = seg_words(len0) + seg_words(len1); }
+    else if (e->ragged || e->L0 != len0 || e->L1 != len1)
+        return e->fail(FQD_ERR_ARG, "fqd_insert_records: engine holds keys of another shape");
+    int rc;
+    const uint64_t first = e->n_records;
+    if ((rc = ensure_table(e, first + n))) return rc;
+    const uint64_t new_words = n * uint64_t(e->W0);
+    if ((rc = reserve(e, e->keys, std::max<uint64_t>(e->keys_used + new_words, 64) * sizeof(uint64_t),
+                      e->keys_used * sizeof(uint64_t)))) return rc;
+    if (e->W0) {
+        Bracket br(e, K_OTHER, 0);
+        hipLaunchKernelGGL(unpack_records_kernel, dim3(grid_for(e, new_words)), dim3(kBlock), 0, e->stream,
+                           records, n, e->W0, e->keys.as<uint64_t>() + first * uint64_t(e->W0));
+    }
+    KeyStore ks{e->keys.as<uint64_t>(), nullptr, e->W0, e->W0, 0};
+    if ((rc = launch_insert(e, ks, records, e->W0 + 1, n, first, keep))) return rc;
+    e->n_records += n; e->keys_used += new_words;
+    return FQD_OK;
+}
+
+int fqd_synth_reads(fqd_engine* e, uint64_t seed, uint64_t first, uint64_t n, uint32_t len,
+                    uint32_t dup_permille, int mate, uint8_t* bases, uint8_t* expect_keep)
+{
+    if (!e) return FQD_ERR_ARG;
+    if ((n && len && !bases) || dup_permille > 1000 || (mate != 0 && mate != 1))
+        return e->fail(FQD_ERR_ARG, "fqd_synth_reads: bad arguments");
+    if (n == 0) return FQD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipLaunchKernelGGL(synth_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
+                       seed, first, n, len, dup_permille, mate, bases, expect_keep);
+    HIP_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+} // extern "C"

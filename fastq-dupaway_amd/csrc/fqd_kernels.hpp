@@ -1,0 +1,426 @@
+// fqd_kernels.hpp — gfx950 kernels of the dedup engine (included by fqd_engine.hip).
+//
+//   encode_*   : ASCII bases -> validated, packed key words + 64-bit placement hash
+//                (replaces SeqUtils::seq2hash / pattern2number / _char2number,
+//                 seq_utils.cpp:3-49, and the key constructors, hash_dup_remover.cpp:4-24)
+//   insert     : probe / insert into the HBM-resident open-addressing set with exact
+//                key verification and first-occurrence-wins
+//                (replaces records.find + records.insert, hash_dup_remover.hpp:133-138,
+//                 237-244, and operator==, hash_dup_remover.cpp:10-14,26-33)
+//   rehash, scans, re-layout, partition: housekeeping around those two.
+#pragma once
+#include "fqd_device.hpp"
+
+namespace fqd {
+
+constexpr int kBlock = 256;
+
+// One mate's input as the kernels see it.
+struct SegView {
+    const uint8_t*  bases;
+    const uint64_t* offsets;   // nullptr: uniform
+    const uint32_t* lengths;   // nullptr: uniform
+    uint32_t        ulen;
+    uint32_t        ustride;
+    __device__ __forceinline__ const uint8_t* ptr(uint64_t i) const
+    { return bases + (offsets ? offsets[i] : i * uint64_t(ustride)); }
+    __device__ __forceinline__ uint32_t len(uint64_t i) const { return lengths ? lengths[i] : ulen; }
+};
+
+// Where keys live.  Uniform engines: key j = keys + j*stride + lead, all with
+// W0 words (lens implied).  Ragged engines: key j = keys + koff[j] = [len0 | len1<<32][words...].
+struct KeyStore {
+    uint64_t*       keys;
+    const uint64_t* koff;      // nullptr: uniform
+    uint32_t        W0;
+    uint32_t        stride;    // words between consecutive uniform keys
+    uint32_t        lead;      // words to skip at the start of a uniform slot (records: 1 for the hash)
+    __device__ __forceinline__ uint64_t* slot(uint64_t j) const
+    { return keys + (koff ? koff[j] : j * uint64_t(stride) + lead); }
+};
+
+// ---------------------------------------------------------------------------
+// Per-lane packing of one mate from a dword-aligned window: the sequence starts
+// `sh` bytes (0..3) into q[0].  Aligned dword loads + v_alignbyte; never reads a
+// dword that holds no byte of the sequence.  q may point to HBM or to LDS (the
+// caller keeps the pointer's provenance visible so LDS reads stay ds_read_b32).
+template <class Sink>
+__device__ __forceinline__ void pack_dwords(const uint32_t* __restrict__ q, uint32_t sh, uint32_t len,
+                                            Packer& pk, Sink&& sink)
+{
+    const uint32_t n_src = (sh + len + 3u) >> 2;      // aligned dwords that hold sequence bytes
+    const uint32_t n_quad = (len + 3u) >> 2;
+    uint32_t cur = n_src ? q[0] : 0u;
+    for (uint32_t k = 0; k < n_quad; ++k) {
+        const uint32_t nxt = (k + 1u < n_src) ? q[k + 1u] : 0u;
+        const uint32_t w = shifted_dword(cur, nxt, sh);
+        const uint32_t left = len - 4u * k;
+        pk.push(w, left < 4u ? left : 4u, sink);
+        cur = nxt;
+    }
+    pk.finish(sink);
+}
+
+template <class Sink>
+__device__ __forceinline__ void pack_from_memory(const uint8_t* p, uint32_t len, Packer& pk, Sink&& sink)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t sh = uint32_t(a & 3u);
+    pack_dwords(reinterpret_cast<const uint32_t*>(a - sh), sh, len, pk, sink);
+}
+
+// ---------------------------------------------------------------------------
+// encode_general: one record (all its mates) per lane, loads straight from HBM.
+// Handles ragged and uniform input, any length, any alignment.
+//   hash_out != nullptr : hash of record i -> hash_out[i]
+//   hash_out == nullptr : hash -> word 0 of the record's slot (records layout, lead == 1)
+template <int S>
+__global__ __launch_bounds__(kBlock)
+void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx,
+                           KeyStore ks, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err)
+{
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
+        const uint32_t l0 = s0.len(i);
+        const uint32_t l1 = (S == 2) ? s1.len(i) : 0u;
+        uint64_t* out = ks.slot(first_idx + i);
+        uint64_t h = hash_begin(l0, l1);
+        if (ks.koff) *out++ = uint64_t(l0) | (uint64_t(l1) << 32);
+        auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
+        Packer p0;
+        pack_from_memory(s0.ptr(i), l0, p0, sink);
+        uint64_t e = kNoError;
+        if (p0.bad_pos != 0xFFFFFFFFu) e = make_error(first_idx + i, 0, p0.bad_pos, p0.bad_byte);
+        if (S == 2) {
+            Packer p1;
+            pack_from_memory(s1.ptr(i), l1, p1, sink);
+            if (e == kNoError && p1.bad_pos != 0xFFFFFFFFu) e = make_error(first_idx + i, 1, p1.bad_pos, p1.bad_byte);
+        }
+        h = hash_end(h);
+        if (hash_out) hash_out[i] = h;
+        else          ks.slot(first_idx + i)[-1] = h;
+        if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// encode_staged: uniform-length, uniform-stride input (the BASELINE layout: 150 B
+// per read, back to back).  A workgroup pulls a tile of R reads (R*stride bytes,
+// 16-B aligned chunks) into LDS with fully coalesced 16-byte loads, then each
+// lane packs one read out of LDS.  HBM sees only whole-line streaming reads.
+//   tile_reads R = blockDim.x; LDS = round16(R*stride + 32)
+template <int S>
+__global__ __launch_bounds__(kBlock)
+void encode_staged_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx,
+                          KeyStore ks, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err,
+                          uint32_t tile_bytes0, uint32_t /*tile_bytes1*/)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t R = blockDim.x;
+    const uint64_t n_tiles = (n + R - 1) / R;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t r0 = tile * R;
+        const uint32_t nr = uint32_t(n - r0 < R ? n - r0 : R);
+        uint32_t lds_off[2] = {0u, 0u};
+        uint32_t head[2] = {0u, 0u};
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const SegView& sv = s ? s1 : s0;
+            const uint8_t* g0 = sv.bases + r0 * uint64_t(sv.ustride);
+            const uint32_t bytes = (nr - 1u) * sv.ustride + sv.ulen;
+            const uintptr_t ga = reinterpret_cast<uintptr_t>(g0);
+            head[s] = uint32_t(ga & 15u);                           // bytes before g0 in its 16-B chunk
+            const uint4* src = reinterpret_cast<const uint4*>(ga - head[s]);
+            const uint32_t n16 = (head[s] + bytes + 15u) >> 4;
+            lds_off[s] = s ? tile_bytes0 : 0u;
+            uint4* dst = reinterpret_cast<uint4*>(lds + (lds_off[s] >> 2));
+            for (uint32_t c = threadIdx.x; c < n16; c += R) dst[c] = src[c];
+        }
+        __syncthreads();
+        const uint32_t t = threadIdx.x;
+        if (t < nr) {
+            const uint64_t i = r0 + t;
+            const uint32_t l0 = s0.ulen, l1 = (S == 2) ? s1.ulen : 0u;
+            uint64_t* out = ks.slot(first_idx + i);
+            uint64_t h = hash_begin(l0, l1);
+            if (ks.koff) *out++ = uint64_t(l0) | (uint64_t(l1) << 32);
+            auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
+            Packer p0;
+            const uint32_t b0 = lds_off[0] + head[0] + t * s0.ustride;
+            pack_dwords(lds + (b0 >> 2), b0 & 3u, l0, p0, sink);
+            uint64_t e = kNoError;
+            if (p0.bad_pos != 0xFFFFFFFFu) e = make_error(first_idx + i, 0, p0.bad_pos, p0.bad_byte);
+            if (S == 2) {
+                Packer p1;
+                const uint32_t b1 = lds_off[1] + head[1] + t * s1.ustride;
+                pack_dwords(lds + (b1 >> 2), b1 & 3u, l1, p1, sink);
+                if (e == kNoError && p1.bad_pos != 0xFFFFFFFFu) e = make_error(first_idx + i, 1, p1.bad_pos, p1.bad_byte);
+            }
+            h = hash_end(h);
+            if (hash_out) hash_out[i] = h;
+            else          ks.slot(first_idx + i)[-1] = h;
+            if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Exact key comparison (setRecord::operator== / setRecordPair::operator==).
+__device__ __forceinline__ bool keys_equal(const KeyStore& ks, uint32_t a, uint32_t b)
+{
+    const uint64_t* p = ks.slot(a);
+    const uint64_t* q = ks.slot(b);
+    uint32_t W = ks.W0;
+    if (ks.koff) {
+        const uint64_t ha = p[0];
+        if (ha != q[0]) return false;                 // mate lengths differ
+        W = seg_words(uint32_t(ha)) + seg_words(uint32_t(ha >> 32));
+        ++p; ++q;
+    }
+    for (uint32_t k = 0; k < W; ++k)
+        if (p[k] != q[k]) return false;
+    return true;
+}
+
+// insert: one record per lane.  Slot = (tag:32 | record index:32), EMPTY = all ones.
+//   * atomicCAS(EMPTY -> mine) claims a free slot: the record is (so far) the first of its key.
+//   * a slot whose tag matches is verified word-for-word against the owner's stored key;
+//     only then atomicMin(slot, mine) decides who is first: the loser's keep flag is cleared
+//     (mine if the owner is older, the displaced owner's if I am older).
+//   * keep[] was preset to 1; flags are only ever cleared, so concurrent order does not matter.
+// Records of earlier batches have smaller indices and can never be displaced, so a batch's
+// flags are final when its launch retires.
+__global__ __launch_bounds__(kBlock)
+void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, KeyStore ks,
+                   const uint64_t* __restrict__ hashes, uint32_t hash_stride,
+                   uint64_t n, uint32_t first_idx, uint8_t* __restrict__ keep,
+                   unsigned long long* __restrict__ counters /* [0]=dups [1]=table-full */)
+{
+    unsigned long long* tab = reinterpret_cast<unsigned long long*>(table);
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
+        const uint64_t h = hashes[i * uint64_t(hash_stride)];
+        const uint32_t idx = first_idx + uint32_t(i);
+        const uint64_t tag = h >> 32;
+        const unsigned long long mine = (tag << 32) | idx;
+        uint64_t pos = h & slot_mask;
+        bool placed = false;
+        for (uint64_t probe = 0; probe <= slot_mask; ++probe) {
+            const unsigned long long old = atomicCAS(&tab[pos], kEmptySlot, mine);
+            if (old == kEmptySlot) { placed = true; break; }
+            if ((old >> 32) == tag && keys_equal(ks, idx, uint32_t(old))) {
+                const unsigned long long prev = atomicMin(&tab[pos], mine);
+                const uint32_t owner = uint32_t(prev);
+                if (owner < idx) keep[i] = 0;                       // an earlier record holds this key
+                else             keep[owner - first_idx] = 0;       // I am earlier: the displaced one loses
+                atomicAdd(&counters[0], 1ull);
+                placed = true;
+                break;
+            }
+            pos = (pos + 1) & slot_mask;
+        }
+        if (!placed) atomicAdd(&counters[1], 1ull);
+    }
+}
+
+// rehash: move every owner into a larger table (keys are distinct: no verification).
+__global__ __launch_bounds__(kBlock)
+void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
+                   uint64_t* __restrict__ new_table, uint64_t new_mask, KeyStore ks, uint32_t len0, uint32_t len1)
+{
+    unsigned long long* tab = reinterpret_cast<unsigned long long*>(new_table);
+    for (uint64_t s = blockIdx.x * uint64_t(kBlock) + threadIdx.x; s < old_slots; s += uint64_t(gridDim.x) * kBlock) {
+        const uint64_t e = old_table[s];
+        if (e == kEmptySlot) continue;
+        const uint32_t idx = uint32_t(e);
+        const uint64_t* p = ks.slot(idx);
+        uint32_t l0 = len0, l1 = len1, W = ks.W0;
+        if (ks.koff) { l0 = uint32_t(p[0]); l1 = uint32_t(p[0] >> 32); W = seg_words(l0) + seg_words(l1); ++p; }
+        uint64_t h = hash_begin(l0, l1);
+        for (uint32_t k = 0; k < W; ++k) h = hash_word(h, p[k]);
+        h = hash_end(h);
+        const unsigned long long mine = ((h >> 32) << 32) | idx;
+        uint64_t pos = h & new_mask;
+        while (atomicCAS(&tab[pos], kEmptySlot, mine) != kEmptySlot) pos = (pos + 1) & new_mask;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Ragged bookkeeping: words per record, exclusive scan, uniform -> ragged re-layout.
+
+// need[i] = 1 (header) + key words of record i
+template <int S>
+__global__ __launch_bounds__(kBlock)
+void slot_words_kernel(SegView s0, SegView s1, uint64_t n, uint64_t* __restrict__ need)
+{
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock)
+        need[i] = 1u + seg_words(s0.len(i)) + ((S == 2) ? seg_words(s1.len(i)) : 0u);
+}
+
+constexpr int kScanItems = 4;                       // per thread
+constexpr int kScanTile = kBlock * kScanItems;      // 1024 per block
+
+// In-place exclusive scan of each 1024-item tile; tile totals go to sums[block].
+__global__ __launch_bounds__(kBlock)
+void scan_tiles_kernel(uint64_t* __restrict__ data, uint64_t n, uint64_t* __restrict__ sums)
+{
+    __shared__ uint64_t wave_tot[kBlock / 64];
+    const uint64_t base = blockIdx.x * uint64_t(kScanTile) + threadIdx.x * uint64_t(kScanItems);
+    uint64_t v[kScanItems], run = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) { v[k] = (base + k < n) ? data[base + k] : 0; run += v[k]; }
+    // inclusive scan of `run` across the wave
+    uint64_t inc = run;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t up = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += up;
+    }
+    const int wave = threadIdx.x >> 6;
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint64_t before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_tot[w];
+    uint64_t ex = before + inc - run;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) { if (base + k < n) data[base + k] = ex; ex += v[k]; }
+    if (threadIdx.x == kBlock - 1) sums[blockIdx.x] = before + inc;
+}
+
+// data[i] += tile_prefix[i / 1024] + add
+__global__ __launch_bounds__(kBlock)
+void scan_add_kernel(uint64_t* __restrict__ data, uint64_t n, const uint64_t* __restrict__ tile_prefix, uint64_t add)
+{
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock)
+        data[i] += (tile_prefix ? tile_prefix[i / kScanTile] : 0) + add;
+}
+
+// Uniform -> ragged: key j moves from src + j*W0 to dst + j*(W0+1) + 1 behind a header, koff[j] = j*(W0+1).
+__global__ __launch_bounds__(kBlock)
+void relayout_ragged_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, uint64_t* __restrict__ koff,
+                            uint64_t n, uint32_t W0, uint64_t header)
+{
+    const uint64_t total = n * uint64_t(W0 + 1u);
+    for (uint64_t x = blockIdx.x * uint64_t(kBlock) + threadIdx.x; x < total; x += uint64_t(gridDim.x) * kBlock) {
+        const uint64_t j = x / (W0 + 1u);
+        const uint32_t k = uint32_t(x - j * (W0 + 1u));
+        dst[x] = k ? src[j * W0 + (k - 1u)] : header;
+        if (k == 0) koff[j] = x;
+    }
+}
+
+// Records [hash, words...] -> uniform arena slots (multi-GPU insert path).
+__global__ __launch_bounds__(kBlock)
+void unpack_records_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t W0, uint64_t* __restrict__ arena_at_first)
+{
+    const uint64_t total = n * uint64_t(W0);
+    for (uint64_t x = blockIdx.x * uint64_t(kBlock) + threadIdx.x; x < total; x += uint64_t(gridDim.x) * kBlock) {
+        const uint64_t j = x / W0;
+        const uint32_t k = uint32_t(x - j * W0);
+        arena_at_first[x] = rec[j * (W0 + 1u) + 1u + k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Stable partition of records by owner = (hash >> 40) % n_parts  (SURVEY §8e step 2).
+// counts2d is part-major: counts2d[p * n_blocks + b]; an exclusive scan of it is
+// the destination of the first record of part p in block b.
+__device__ __forceinline__ uint32_t owner_of(uint64_t hash, uint32_t n_parts) { return uint32_t((hash >> 40) % n_parts); }
+
+__global__ __launch_bounds__(kBlock)
+void part_count_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t rec_words, uint32_t n_parts,
+                       uint64_t* __restrict__ counts2d, uint32_t n_blocks)
+{
+    extern __shared__ uint32_t hist[];                 // n_parts
+    for (uint32_t p = threadIdx.x; p < n_parts; p += kBlock) hist[p] = 0;
+    __syncthreads();
+    const uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x;
+    if (i < n) atomicAdd(&hist[owner_of(rec[i * uint64_t(rec_words)], n_parts)], 1u);
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < n_parts; p += kBlock) counts2d[uint64_t(p) * n_blocks + blockIdx.x] = hist[p];
+}
+
+__global__ __launch_bounds__(kBlock)
+void part_scatter_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t rec_words, uint32_t n_parts,
+                         const uint64_t* __restrict__ starts2d, uint32_t n_blocks,
+                         uint64_t* __restrict__ out, uint32_t* __restrict__ origin)
+{
+    extern __shared__ uint32_t wave_cnt[];             // [n_parts][4 waves]
+    const uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x;
+    const bool live = i < n;
+    const uint32_t mine = live ? owner_of(rec[i * uint64_t(rec_words)], n_parts) : 0xFFFFFFFFu;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t rank_in_wave = 0;
+    for (uint32_t p = 0; p < n_parts; ++p) {
+        const unsigned long long m = __ballot(mine == p);
+        if (mine == p) rank_in_wave = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[p * 4 + wave] = __popcll(m);
+    }
+    __syncthreads();
+    if (live) {
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += wave_cnt[mine * 4 + w];
+        const uint64_t dst = starts2d[uint64_t(mine) * n_blocks + blockIdx.x] + before + rank_in_wave;
+        const uint64_t* s = rec + i * uint64_t(rec_words);
+        uint64_t* d = out + dst * uint64_t(rec_words);
+        for (uint32_t k = 0; k < rec_words; ++k) d[k] = s[k];
+        origin[dst] = uint32_t(i);
+    }
+}
+
+// counts[p] = number of records of part p, read off the scanned 2-D starts.
+__global__ void part_totals_kernel(const uint64_t* __restrict__ starts2d, uint32_t n_parts, uint32_t n_blocks,
+                                   uint64_t n, uint64_t* __restrict__ counts)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_parts) return;
+    const uint64_t lo = starts2d[uint64_t(p) * n_blocks];
+    const uint64_t hi = (p + 1 < n_parts) ? starts2d[uint64_t(p + 1) * n_blocks] : n;
+    counts[p] = hi - lo;
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic workload.  Counter-based: every value is a pure function of
+// (seed, global index), so ranks generate their slices independently and the expected
+// keep flags are known in closed form.
+__host__ __device__ inline uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline bool syn_is_copy(uint64_t seed, uint64_t g, uint32_t permille)
+{ return g > 0 && (mix64(seed ^ (g * 4u + 1u)) % 1000u) < permille; }
+__host__ __device__ inline uint64_t syn_parent(uint64_t seed, uint64_t g) { return mix64(seed ^ (g * 4u + 2u)) % g; }
+__host__ __device__ inline bool syn_same_mate2(uint64_t seed, uint64_t g) { return (mix64(seed ^ (g * 4u + 3u)) & 1u) != 0; }
+
+__global__ __launch_bounds__(kBlock)
+void synth_kernel(uint64_t seed, uint64_t first, uint64_t n, uint32_t len, uint32_t permille, int mate,
+                  uint8_t* __restrict__ bases, uint8_t* __restrict__ expect_keep)
+{
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
+        const uint64_t g = first + i;
+        uint64_t r = g;
+        if (mate == 0) { while (syn_is_copy(seed, r, permille)) r = syn_parent(seed, r); }
+        else           { while (syn_is_copy(seed, r, permille) && syn_same_mate2(seed, r)) r = syn_parent(seed, r); }
+        if (expect_keep) {
+            const bool dup = syn_is_copy(seed, g, permille) && (mate == 0 || syn_same_mate2(seed, g));
+            expect_keep[i] = dup ? 0 : 1;
+        }
+        const uint64_t stream = mix64(seed ^ mix64(r * 2u + uint64_t(mate)));
+        uint8_t* out = bases + i * uint64_t(len);
+        const uint64_t nv = mix64(stream ^ 0x5bd1e995u);
+        const uint32_t n_at = ((nv & 7u) == 0u && len) ? uint32_t((nv >> 8) % len) : 0xFFFFFFFFu;
+        for (uint32_t b = 0; b < len; b += 32) {
+            uint64_t bits = mix64(stream + (b >> 5) * 0x9E3779B97F4A7C15ull);
+            const uint32_t m = (len - b < 32u) ? len - b : 32u;
+            for (uint32_t k = 0; k < m; ++k) {
+                out[b + k] = (b + k == n_at) ? uint8_t('N') : uint8_t("ACGT"[bits & 3u]);
+                bits >>= 2;
+            }
+        }
+    }
+}
+
+} // namespace fqd

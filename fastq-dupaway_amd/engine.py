@@ -1,0 +1,152 @@
+"""ctypes wrapper over the C ABI (include/fqdupaway.h).  Plumbing only: all work
+happens in lib/libfqdupaway.so on the GPU; nothing here computes a result."""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import FqdError, load_library
+
+
+@dataclass
+class Reads:
+    """One mate's sequences for a batch (mirrors struct fqd_reads).
+
+    bases/offsets/lengths are numpy arrays (host space), torch CUDA tensors or raw
+    device pointers as int (device space).  Leave offsets and lengths None for a
+    uniform batch: read i = uniform_len bytes at bases + i*uniform_stride."""
+    bases: Any
+    offsets: Any = None
+    lengths: Any = None
+    uniform_len: int = 0
+    uniform_stride: int = 0
+
+
+def _is_host(x) -> bool:
+    return isinstance(x, np.ndarray)
+
+
+def _addr(x) -> Optional[int]:
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()          # torch tensor
+
+
+def _desc_array(segs: Sequence[Reads]):
+    arr = (_lib.ReadsDesc * 2)()
+    for k, s in enumerate(segs):
+        arr[k].bases = _addr(s.bases)
+        arr[k].offsets = _addr(s.offsets)
+        arr[k].lengths = _addr(s.lengths)
+        arr[k].uniform_len = s.uniform_len
+        arr[k].uniform_stride = s.uniform_stride
+    return arr
+
+
+class Engine:
+    """One HBM-resident exact sequence set on one MI355X (struct fqd_engine)."""
+
+    def __init__(self, segments: int = 1, device: int = 0, capacity_reads: int = 0, capacity_bases: int = 0,
+                 stream: Optional[int] = None, profile: bool = False, no_stage: bool = False):
+        self._L = load_library()
+        cfg = _lib.Config(device=device, segments=segments, capacity_reads=capacity_reads,
+                          capacity_bases=capacity_bases, stream=stream,
+                          flags=(_lib.FLAG_PROFILE if profile else 0) | (_lib.FLAG_NO_STAGE if no_stage else 0))
+        h = C.c_void_p()
+        rc = self._L.fqd_engine_create(C.byref(cfg), C.byref(h))
+        if rc != _lib.OK:
+            raise FqdError(rc, (self._L.fqd_last_error(None) or b"").decode())
+        self._h = h
+        self.segments = segments
+
+    # -- lifecycle ----------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fqd_engine_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != _lib.OK:
+            raise FqdError(rc, (self._L.fqd_last_error(self._h) or b"").decode())
+
+    def reset(self):
+        self._check(self._L.fqd_engine_reset(self._h))
+
+    def sync(self):
+        self._check(self._L.fqd_engine_sync(self._h))
+
+    # -- the hot path ---------------------------------------------------------------
+    def submit(self, segs: Sequence[Reads], n: int, keep=None):
+        """Dedups n more records; returns their keep flags (numpy for host input,
+        the given device buffer otherwise)."""
+        if len(segs) != self.segments:
+            raise ValueError(f"engine has {self.segments} mate(s) per record, got {len(segs)}")
+        host = _is_host(segs[0].bases)
+        for s in segs:
+            if _is_host(s.bases) != host:
+                raise ValueError("all mates must live in the same memory space")
+            if _is_host(s.bases):
+                for a, dt in ((s.bases, np.uint8), (s.offsets, np.uint64), (s.lengths, np.uint32)):
+                    if a is not None and (a.dtype != dt or not a.flags["C_CONTIGUOUS"]):
+                        raise ValueError(f"host arrays must be C-contiguous {dt}")
+        if host:
+            keep = np.empty(n, dtype=np.uint8) if keep is None else keep
+        elif keep is None:
+            raise ValueError("device submits need a device keep buffer")
+        rc = self._L.fqd_submit(self._h, _desc_array(segs), n, _lib.MEM_HOST if host else _lib.MEM_DEVICE, _addr(keep))
+        self._check(rc)
+        return keep
+
+    def bad_base(self):
+        rec, seg, pos, byte = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint8()
+        self._check(self._L.fqd_bad_base(self._h, C.byref(rec), C.byref(seg), C.byref(pos), C.byref(byte)))
+        return rec.value, seg.value, pos.value, byte.value
+
+    def stats(self):
+        st = _lib.Stats()
+        self._check(self._L.fqd_get_stats(self._h, C.byref(st)))
+        return {"records": st.records, "duplicates": st.duplicates, "table_slots": st.table_slots, "key_bytes": st.key_bytes}
+
+    def profile(self):
+        p = _lib.Profile()
+        self._check(self._L.fqd_get_profile(self._h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in _lib.Profile._fields_}
+
+    def reset_profile(self):
+        self._check(self._L.fqd_reset_profile(self._h))
+
+    # -- sharding halves ---------------------------------------------------------------
+    def key_words(self, len0: int, len1: int = 0) -> int:
+        return int(self._L.fqd_key_words(len0, len1))
+
+    def encode_uniform(self, segs: Sequence[Reads], n: int, records):
+        self._check(self._L.fqd_encode_uniform(self._h, _desc_array(segs), n, _addr(records)))
+
+    def partition_records(self, records, n: int, key_words: int, n_parts: int, out, counts, origin):
+        self._check(self._L.fqd_partition_records(self._h, _addr(records), n, key_words, n_parts,
+                                                  _addr(out), _addr(counts), _addr(origin)))
+
+    def insert_records(self, records, n: int, len0: int, len1: int, keep):
+        self._check(self._L.fqd_insert_records(self._h, _addr(records), n, len0, len1, _addr(keep)))
+
+    def synth_reads(self, seed: int, first: int, n: int, length: int, dup_permille: int, mate: int, bases, expect_keep=None):
+        self._check(self._L.fqd_synth_reads(self._h, seed, first, n, length, dup_permille, mate,
+                                            _addr(bases), _addr(expect_keep)))

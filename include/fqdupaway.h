@@ -1,0 +1,166 @@
+/* fqdupaway.h — C ABI of the MI355X-native `--fast` deduplication engine.
+ *
+ * The reference (fastq-dupaway V1.5.0) has no FFI: its seam for this path is the
+ * C++ class template HashDupRemover<T> (src/hash_dup_remover.hpp:73-94), which
+ * builds one key per record (setRecord / setRecordPair, hpp:19-41 via
+ * SeqUtils::seq2hash, src/seq_utils.cpp:35-49) and runs find-then-insert on a
+ * std::unordered_set (hpp:70-71,126-144,228-248).  This header is what a
+ * binding for that loop would call instead: the host side keeps parsing
+ * records and writing survivors (fastq-dupaway_amd/host mirrors
+ * HashDupRemover's constructor, filterSE and filterPE), and hands batches of
+ * sequences to the device, which answers with one keep flag per record.
+ *
+ * Conventions: plain pointers and sizes only; every function returns an int
+ * status (FQD_OK = 0) and never throws; the text of the last failure of an
+ * engine is available from fqd_last_error().  `device` pointers are HIP
+ * device pointers, `stream` is a hipStream_t passed as void*.
+ *
+ * Contract: record i of an engine's input
+ * order is KEPT iff no record j < i has the identical sequence (for paired
+ * engines: identical mate-1 AND mate-2 sequences, lengths included) over the
+ * alphabet {A,C,G,T,N}.  Selection is exact — hashes only place keys — and
+ * the first occurrence always wins.  Any other byte is an error that carries
+ * the offending byte, as SeqUtils::_char2number does (seq_utils.cpp:3-21).
+ */
+#ifndef FQDUPAWAY_H
+#define FQDUPAWAY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FQD_ABI_VERSION 1
+
+/* status codes */
+#define FQD_OK              0
+#define FQD_ERR_ARG         1   /* bad argument / misuse                              */
+#define FQD_ERR_HIP         2   /* a HIP runtime call failed (see fqd_last_error)     */
+#define FQD_ERR_BAD_BASE    3   /* a byte outside {A,C,G,T,N}: see fqd_bad_base()     */
+#define FQD_ERR_CAPACITY    4   /* more than 2^32-2 records in one engine             */
+#define FQD_ERR_NO_DEVICE   5   /* no usable MI355X / HIP device                      */
+
+/* where the caller's buffers live */
+#define FQD_MEM_HOST        0
+#define FQD_MEM_DEVICE      1
+
+/* fqd_config.flags */
+#define FQD_FLAG_PROFILE    1u  /* bracket every kernel with HIP events (fqd_profile) */
+#define FQD_FLAG_NO_STAGE   2u  /* testing: force the per-lane global-load encoder    */
+
+typedef struct fqd_engine fqd_engine;
+
+/* Replaces: HashDupRemover<T>::HashDupRemover(memlimit, tempdir, verbose)
+ * (hash_dup_remover.hpp:77-78) + the `hashed_set records; records.reserve(ONE_MIL)`
+ * of each driver (hpp:113-114,206-207,269-270). */
+typedef struct fqd_config {
+    int32_t  device;          /* HIP device ordinal                                       */
+    int32_t  segments;        /* 1: setRecord keys (SE); 2: setRecordPair keys (PE)       */
+    uint64_t capacity_reads;  /* hint: records expected over the engine's life (0 = grow) */
+    uint64_t capacity_bases;  /* hint: total bases expected (0 = grow)                    */
+    void*    stream;          /* hipStream_t to run on; NULL = the engine creates one     */
+    uint32_t flags;           /* FQD_FLAG_*                                               */
+    uint32_t reserved;
+} fqd_config;
+
+/* One mate's sequences for a batch: ASCII, one byte per base, no newlines
+ * needed between reads.  Either ragged (offsets + lengths arrays, in the same
+ * memory space as `bases`) or uniform (offsets == lengths == NULL: read i is
+ * the uniform_len bytes at bases + i * uniform_stride).
+ * Replaces the (obj.seq(), obj.seq_len()-1) pairs handed to the key
+ * constructors at hash_dup_remover.hpp:124,131,223-224,234-235,293-294. */
+typedef struct fqd_reads {
+    const uint8_t*  bases;
+    const uint64_t* offsets;
+    const uint32_t* lengths;
+    uint32_t        uniform_len;
+    uint32_t        uniform_stride;
+} fqd_reads;
+
+typedef struct fqd_stats {
+    uint64_t records;         /* records submitted so far (tot_reads, hpp:116)         */
+    uint64_t duplicates;      /* keep flags cleared so far (dup_reads, hpp:116)        */
+    uint64_t table_slots;     /* current capacity of the hash set                      */
+    uint64_t key_bytes;       /* bytes of packed keys resident in HBM                  */
+} fqd_stats;
+
+/* Average device time per launch, measured with HIP events on the engine's
+ * stream when FQD_FLAG_PROFILE is set (bench.py's roofline uses these). */
+typedef struct fqd_profile {
+    double   encode_ms;   uint64_t encode_launches;   uint64_t encode_reads;
+    double   insert_ms;   uint64_t insert_launches;   uint64_t insert_reads;
+    double   other_ms;    uint64_t other_launches;    /* clears, scans, rehash */
+} fqd_profile;
+
+int  fqd_abi_version(void);
+int  fqd_device_count(int* count);
+
+int  fqd_engine_create(const fqd_config* cfg, fqd_engine** out);
+int  fqd_engine_destroy(fqd_engine* e);
+/* Empties the set and the key store, keeping the allocations. */
+int  fqd_engine_reset(fqd_engine* e);
+
+/* Replaces one pass of the hot loop (hpp:126-144 SE, 228-248 PE) over `n`
+ * records: builds their keys, probes/inserts them, and writes keep[i] = 1 if
+ * record i (input order continues across calls) is the first with its key,
+ * else 0.  `seg` points at cfg.segments descriptors.  `memory` says where
+ * bases/offsets/lengths/keep live.  Device-space calls are asynchronous on
+ * the engine's stream and keep must stay valid until fqd_engine_sync();
+ * host-space calls return with keep filled.  Flags of a batch are final when
+ * it completes: later batches cannot change them. */
+int  fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep);
+
+/* Waits for the stream and surfaces deferred errors (FQD_ERR_BAD_BASE). */
+int  fqd_engine_sync(fqd_engine* e);
+
+/* After FQD_ERR_BAD_BASE: the first offending byte in input order — record
+ * index, segment (0/1), position in that sequence, and the byte itself — so a
+ * caller can print the reference's two lines (seq_utils.cpp:18-19).  Keep flags
+ * of records before `record` are valid. */
+int  fqd_bad_base(const fqd_engine* e, uint64_t* record, uint32_t* segment, uint32_t* position, uint8_t* byte);
+
+int  fqd_get_stats(fqd_engine* e, fqd_stats* out);
+int  fqd_get_profile(fqd_engine* e, fqd_profile* out);
+int  fqd_reset_profile(fqd_engine* e);
+const char* fqd_last_error(const fqd_engine* e);   /* NULL engine: last create() failure */
+
+/* ---- the two halves of fqd_submit, exposed for multi-GPU sharding ----------
+ * (encode where the reads are, exchange fixed-size key records by
+ * hash prefix with an all-to-all, insert at the owner.)  Uniform-length
+ * batches only: every key of the engine has the same word count. */
+
+/* Words (8 bytes each) of the packed key of a record with these mate lengths. */
+uint32_t fqd_key_words(uint32_t len0, uint32_t len1);
+
+/* Encodes n uniform reads into n*(key_words+1) uint64 at `records` (device):
+ * record i = [hash, key words...].  Does not touch the set. */
+int  fqd_encode_uniform(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint64_t* records);
+
+/* Stable partition of n records by owner = (hash >> 40) % n_parts:
+ * `out` gets the records grouped by owner in input order, `counts`
+ * (device, n_parts uint64) the group sizes, `origin` (device, n uint32) the
+ * input position of each output record.  `out` may not alias `records`. */
+int  fqd_partition_records(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
+                           uint32_t n_parts, uint64_t* out, uint64_t* counts, uint32_t* origin);
+
+/* Inserts n pre-encoded records (as produced by fqd_encode_uniform, in
+ * global input order) for mate lengths (len0,len1) and writes their keep flags. */
+int  fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n,
+                        uint32_t len0, uint32_t len1, uint8_t* keep);
+
+/* ---- synthetic workload (bench.py, tests): SURVEY §8(d) ---------------------
+ * Fills `bases` (device) with n reads of `len` bases at stride `len`, global
+ * indices [first, first+n): read g>0 is with probability dup_permille/1000 a
+ * copy of a uniformly chosen earlier read (chains allowed), else fresh uniform
+ * ACGT (one N in about 1 read of 8).  mate = 0/1 selects the mate stream of a
+ * pair; for mate 1 a copied pair keeps its parent's mate-2 with probability 1/2.
+ * expect_keep (device, may be NULL) receives the analytically known flags. */
+int  fqd_synth_reads(fqd_engine* e, uint64_t seed, uint64_t first, uint64_t n, uint32_t len,
+                     uint32_t dup_permille, int mate, uint8_t* bases, uint8_t* expect_keep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FQDUPAWAY_H */

@@ -1,0 +1,303 @@
+"""GPU parity: the HIP engine, called through the C ABI, against the CPU oracle on the
+same inputs — bit-exact keep flags (integer/byte work: no tolerance).
+
+Covers the edge cases the reference's semantics name: empty and
+ragged reads, N, chunk/word edges, equal-prefix different-length reads, first
+occurrence wins across batches, PE keys where only mate 2 differs, unknown bytes.
+Full-size runs (BASELINE.json configs[1], configs[2]) are checked through
+size-independent properties: the closed-form keep flags of the synthetic generator,
+idempotence, and agreement of the two encoder kernels.
+"""
+import numpy as np
+import pytest
+
+import fastq_dupaway_amd as fqd
+from fastq_dupaway_amd import Engine, Reads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+def make_pool_reads(rng, n, pool_size, len_lo, len_hi, alphabet=b"ACGTN"):
+    pool = [bytes(rng.choice(list(alphabet), size=int(rng.integers(len_lo, len_hi + 1))).astype(np.uint8))
+            for _ in range(pool_size)]
+    return [pool[int(rng.integers(0, pool_size))] for _ in range(n)]
+
+
+def ragged_arrays(reads, gap=0):
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    offs = np.zeros(len(reads), dtype=np.uint64)
+    pos = 0
+    chunks = []
+    for i, r in enumerate(reads):
+        offs[i] = pos
+        chunks.append(r + b"\n" * gap)
+        pos += len(r) + gap
+    data = np.frombuffer(b"".join(chunks) + b"\0" * 8, dtype=np.uint8).copy()
+    return data, offs, lens
+
+
+def oracle_keep(oracle, reads):
+    d, o, l = ragged_arrays(reads)
+    return oracle.dedup_single(d, o, l)
+
+
+# ---- single-end, ragged, host-space submits ----------------------------------------
+
+@pytest.mark.parametrize("gap", [0, 1, 3])
+def test_se_ragged_matches_oracle(oracle, gap):
+    rng = np.random.default_rng(10 + gap)
+    reads = make_pool_reads(rng, 20000, 3000, 0, 200)
+    d, o, l = ragged_arrays(reads, gap)
+    with Engine(segments=1) as e:
+        keep = e.submit([Reads(d, o, l)], len(reads))
+        st = e.stats()
+    exp = oracle_keep(oracle, reads)
+    assert np.array_equal(keep, exp)
+    assert st["records"] == len(reads) and st["duplicates"] == int((exp == 0).sum())
+
+
+def test_se_streaming_batches_first_occurrence_wins(oracle):
+    rng = np.random.default_rng(21)
+    reads = make_pool_reads(rng, 60000, 8000, 1, 160)
+    exp = oracle_keep(oracle, reads)
+    got = []
+    with Engine(segments=1) as e:          # no capacity hint: the table must grow and rehash
+        for a in range(0, len(reads), 7000):
+            d, o, l = ragged_arrays(reads[a:a + 7000])
+            got.append(e.submit([Reads(d, o, l)], len(o)))
+        st = e.stats()
+    assert np.array_equal(np.concatenate(got), exp)
+    assert st["table_slots"] >= 2 * len(reads)
+
+
+def test_se_chunk_and_word_edges(oracle):
+    base = b"ACGTTGCAAGCTTAGGCTAACGTTAGCATCGATCGGATCCGATTACAGCTAGCTAGGATCGATCGTACGATCGATCGGCTAGCTAGCATCGATGCATGCATGCATCGATCGATCGATGCATGCTAGCTAGCATGCTAGCATCGATGCTAGCTAGCTAG"
+    reads = [b"", b"", b"A", b"A", b"N", b"G", b"ACG", b"ACGA", b"AACG", b"ACGN", b"ACGN", b"ACGG"]
+    for L in (16, 17, 18, 31, 32, 33, 34, 63, 64, 65, 127, 128, 129, 150, 151):
+        s = base[:L]
+        reads += [s, s, s[:-1] + (b"A" if s[-1:] != b"A" else b"C"), s[:L // 2] + b"N" + s[L // 2 + 1:], s + b"A"]
+    d, o, l = ragged_arrays(reads)
+    with Engine(segments=1) as e:
+        keep = e.submit([Reads(d, o, l)], len(reads))
+    assert np.array_equal(keep, oracle_keep(oracle, reads))
+
+
+# ---- uniform batches: staged (LDS) encoder vs per-lane encoder vs oracle ---------------
+
+@pytest.mark.parametrize("L,stride", [(150, 150), (150, 151), (151, 151), (100, 100), (1, 1), (33, 40), (64, 64),
+                                      (250, 250), (301, 304), (17, 17)])
+def test_se_uniform_both_encoders_match_oracle(oracle, L, stride):
+    rng = np.random.default_rng(L * 1000 + stride)
+    n = 30011
+    pool = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=(n // 3, L), p=[.245, .245, .245, .245, .02])
+    pick = rng.integers(0, len(pool), size=n)
+    buf = np.full((n, stride), ord("\n"), dtype=np.uint8)
+    buf[:, :L] = pool[pick]
+    flat = np.concatenate([buf.reshape(-1), np.zeros(16, dtype=np.uint8)])
+    offs = (np.arange(n, dtype=np.uint64) * np.uint64(stride))
+    lens = np.full(n, L, dtype=np.uint32)
+    exp = oracle.dedup_single(flat, offs, lens)
+    for no_stage in (False, True):
+        with Engine(segments=1, no_stage=no_stage) as e:
+            keep = e.submit([Reads(flat, uniform_len=L, uniform_stride=stride)], n)
+        assert np.array_equal(keep, exp), f"no_stage={no_stage}"
+
+
+def test_uniform_then_other_length_switches_to_ragged_layout(oracle):
+    rng = np.random.default_rng(5)
+    a = make_pool_reads(rng, 5000, 900, 50, 50)
+    b = make_pool_reads(rng, 5000, 900, 40, 60)
+    c = a[:2500]                                     # repeats of batch 1 must still be found
+    exp = oracle_keep(oracle, a + b + c)
+    with Engine(segments=1) as e:
+        da = np.frombuffer(b"".join(a) + b"\0" * 16, dtype=np.uint8).copy()
+        k1 = e.submit([Reads(da, uniform_len=50, uniform_stride=50)], len(a))
+        d, o, l = ragged_arrays(b)
+        k2 = e.submit([Reads(d, o, l)], len(b))
+        dc = np.frombuffer(b"".join(c) + b"\0" * 16, dtype=np.uint8).copy()
+        k3 = e.submit([Reads(dc, uniform_len=50, uniform_stride=50)], len(c))
+    assert np.array_equal(np.concatenate([k1, k2, k3]), exp)
+
+
+# ---- paired-end -----------------------------------------------------------------------
+
+def test_pe_matches_oracle_ragged_and_uniform(oracle):
+    rng = np.random.default_rng(77)
+    n = 25000
+    r1 = make_pool_reads(rng, n, 1500, 0, 120)
+    r2 = make_pool_reads(rng, n, 40, 0, 120)          # few mate-2 variants: many R1-equal, R2-different pairs
+    d1, o1, l1 = ragged_arrays(r1)
+    d2, o2, l2 = ragged_arrays(r2, gap=2)
+    exp = oracle.dedup_paired(d1, o1, l1, d2, o2, l2)
+    assert 0 < int((exp == 0).sum()) < n
+    with Engine(segments=2) as e:
+        keep = e.submit([Reads(d1, o1, l1), Reads(d2, o2, l2)], n)
+    assert np.array_equal(keep, exp)
+    # uniform 2x150
+    L = 150
+    p1 = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(2000, L))
+    p2 = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=(50, L))
+    a = p1[rng.integers(0, 2000, size=n)].reshape(-1)
+    b = p2[rng.integers(0, 50, size=n)].reshape(-1)
+    a = np.concatenate([a, np.zeros(16, np.uint8)]); b = np.concatenate([b, np.zeros(16, np.uint8)])
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(L); lens = np.full(n, L, np.uint32)
+    exp = oracle.dedup_paired(a, offs, lens, b, offs, lens)
+    for no_stage in (False, True):
+        with Engine(segments=2, no_stage=no_stage) as e:
+            keep = e.submit([Reads(a, uniform_len=L, uniform_stride=L), Reads(b, uniform_len=L, uniform_stride=L)], n)
+        assert np.array_equal(keep, exp)
+
+
+def test_pe_only_mate2_differs_survives():
+    # reference fixture logic (test/test_fast.py paired: 0004 survives because only R2 differs)
+    a = np.frombuffer(b"ACGTACGT" * 3 + b"\0" * 16, dtype=np.uint8).copy()
+    b = np.frombuffer(b"TTTTAAAA" + b"TTTTAAAC" + b"TTTTAAAA" + b"\0" * 16, dtype=np.uint8).copy()
+    with Engine(segments=2) as e:
+        keep = e.submit([Reads(a, uniform_len=8, uniform_stride=8), Reads(b, uniform_len=8, uniform_stride=8)], 3)
+    assert keep.tolist() == [1, 1, 0]
+
+
+# ---- unknown bytes ------------------------------------------------------------------------
+
+@pytest.mark.parametrize("no_stage", [False, True])
+def test_unknown_base_is_reported_first_in_input_order(no_stage):
+    L, n = 150, 5000
+    rng = np.random.default_rng(3)
+    buf = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(n, L))
+    buf[4000, 17] = ord("x"); buf[1234, 149] = ord("\r"); buf[1234, 60] = ord("n"); buf[3000, 0] = ord("a")
+    flat = np.concatenate([buf.reshape(-1), np.zeros(16, np.uint8)])
+    with Engine(segments=1, no_stage=no_stage) as e:
+        with pytest.raises(fqd.FqdError) as ei:
+            e.submit([Reads(flat, uniform_len=L, uniform_stride=L)], n)
+        assert ei.value.code == 3
+        assert e.bad_base() == (1234, 0, 60, ord("n"))
+
+
+def test_unknown_base_in_mate2_and_flags_before_it_are_valid(oracle):
+    reads1 = [b"ACGT", b"ACGT", b"GGGG", b"ACGT", b"TTTT"]
+    reads2 = [b"AAAA", b"AAAA", b"CCCC", b"AAgA", b"CCCC"]
+    d1, o1, l1 = ragged_arrays(reads1); d2, o2, l2 = ragged_arrays(reads2)
+    keep = np.full(5, 9, dtype=np.uint8)
+    with Engine(segments=2) as e:
+        with pytest.raises(fqd.FqdError):
+            e.submit([Reads(d1, o1, l1), Reads(d2, o2, l2)], 5, keep=keep)
+        assert e.bad_base() == (3, 1, 2, ord("g"))
+    assert keep[:3].tolist() == [1, 0, 1]
+
+
+# ---- the reference's own fixtures through the engine ------------------------------------------
+
+def _fasta_records(path):
+    lines = path.read_bytes().split(b"\n")
+    return [(lines[i], lines[i + 1]) for i in range(0, len(lines) - 1, 2)]
+
+
+def test_reference_fixture_single_fast(golden_dir):
+    fx = golden_dir / "reference_fixtures"
+    recs = _fasta_records(fx / "inputs" / "single_fast.fa")
+    d, o, l = ragged_arrays([s for _, s in recs])
+    with Engine(segments=1) as e:
+        keep = e.submit([Reads(d, o, l)], len(recs))
+    out = b"".join(i + b"\n" + s + b"\n" for (i, s), k in zip(recs, keep) if k)
+    assert out == (fx / "expected" / "single_fast.fa").read_bytes()
+
+
+def test_reference_fixture_paired_fast(golden_dir):
+    fx = golden_dir / "reference_fixtures"
+    r1 = _fasta_records(fx / "inputs" / "paired_fast_r1.fa"); r2 = _fasta_records(fx / "inputs" / "paired_fast_r2.fa")
+    d1, o1, l1 = ragged_arrays([s for _, s in r1]); d2, o2, l2 = ragged_arrays([s for _, s in r2])
+    with Engine(segments=2) as e:
+        keep = e.submit([Reads(d1, o1, l1), Reads(d2, o2, l2)], len(r1))
+    for recs, name in ((r1, "paired_fast_r1.fa"), (r2, "paired_fast_r2.fa")):
+        out = b"".join(i + b"\n" + s + b"\n" for (i, s), k in zip(recs, keep) if k)
+        assert out == (fx / "expected" / name).read_bytes()
+
+
+# ---- device-space submits, synthetic workload, full-size properties -------------------------------
+
+def test_synthetic_1m_matches_oracle_and_closed_form(oracle, torch_cuda):
+    torch = torch_cuda
+    n, L = 1_000_000, 150
+    bases = torch.empty(n * L + 16, dtype=torch.uint8, device="cuda")
+    expect = torch.empty(n, dtype=torch.uint8, device="cuda")
+    keep = torch.empty(n, dtype=torch.uint8, device="cuda")
+    with Engine(segments=1, capacity_reads=n, capacity_bases=n * L) as e:
+        e.synth_reads(1234, 0, n, L, 200, 0, bases, expect)
+        e.submit([Reads(bases, uniform_len=L, uniform_stride=L)], n, keep=keep)
+        e.sync()
+        st = e.stats()
+    assert torch.equal(keep, expect)
+    host = bases.cpu().numpy()
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(L)
+    exp = oracle.dedup_single(host, offs, np.full(n, L, np.uint32))
+    assert np.array_equal(keep.cpu().numpy(), exp)
+    dups = int((exp == 0).sum())
+    assert st["duplicates"] == dups and 0.19 * n < dups < 0.21 * n       # ~20 % duplicates (BASELINE configs[0])
+    assert (host[: n * L] == ord("N")).sum() > 0                            # the N path is exercised
+
+
+def test_synthetic_pairs_match_oracle(oracle, torch_cuda):
+    torch = torch_cuda
+    n, L = 400_000, 150
+    b1 = torch.empty(n * L + 16, dtype=torch.uint8, device="cuda"); b2 = torch.empty_like(b1)
+    expect = torch.empty(n, dtype=torch.uint8, device="cuda"); keep = torch.empty_like(expect)
+    with Engine(segments=2, capacity_reads=n) as e:
+        e.synth_reads(99, 0, n, L, 200, 0, b1, None)
+        e.synth_reads(99, 0, n, L, 200, 1, b2, expect)
+        e.submit([Reads(b1, uniform_len=L, uniform_stride=L), Reads(b2, uniform_len=L, uniform_stride=L)], n, keep=keep)
+        e.sync()
+    assert torch.equal(keep, expect)
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(L); lens = np.full(n, L, np.uint32)
+    exp = oracle.dedup_paired(b1.cpu().numpy(), offs, lens, b2.cpu().numpy(), offs, lens)
+    assert np.array_equal(keep.cpu().numpy(), exp)
+    # about half of the mate-1 duplicates differ in mate 2, so pair-dups ~ 10 %
+    assert 0.08 * n < int((exp == 0).sum()) < 0.12 * n
+
+
+def test_full_size_100m_se_properties(torch_cuda):
+    """BASELINE.json configs[1]: 100 M x 150 bp, ~20 % duplicates, one MI355X."""
+    torch = torch_cuda
+    n, L = 100_000_000, 150
+    bases = torch.empty(n * L + 16, dtype=torch.uint8, device="cuda")
+    expect = torch.empty(n, dtype=torch.uint8, device="cuda")
+    keep = torch.empty(n, dtype=torch.uint8, device="cuda")
+    with Engine(segments=1, capacity_reads=n, capacity_bases=n * L) as e:
+        e.synth_reads(2026, 0, n, L, 200, 0, bases, expect)
+        e.submit([Reads(bases, uniform_len=L, uniform_stride=L)], n, keep=keep)
+        e.sync()
+        assert torch.equal(keep, expect)                          # closed-form flags of the generator
+        assert e.stats()["duplicates"] == int((expect == 0).sum().item())
+        # idempotence: feeding the same reads again finds every one of them
+        keep2 = torch.empty_like(keep)
+        e.submit([Reads(bases, uniform_len=L, uniform_stride=L)], 10_000_000, keep=keep2[:10_000_000])
+        e.sync()
+        assert int(keep2[:10_000_000].sum().item()) == 0
+    # streamed in 8 batches gives the same flags as one batch
+    with Engine(segments=1) as e:
+        keep3 = torch.empty_like(keep)
+        step = n // 8
+        for a in range(0, n, step):
+            e.submit([Reads(bases[a * L:], uniform_len=L, uniform_stride=L)], step, keep=keep3[a:a + step])
+        e.sync()
+        assert torch.equal(keep3, expect)
+
+
+def test_full_size_100m_pe_properties(torch_cuda):
+    """BASELINE.json configs[2]: 100 M pairs 2 x 150 bp."""
+    torch = torch_cuda
+    n, L = 100_000_000, 150
+    b1 = torch.empty(n * L + 16, dtype=torch.uint8, device="cuda"); b2 = torch.empty_like(b1)
+    expect = torch.empty(n, dtype=torch.uint8, device="cuda"); keep = torch.empty_like(expect)
+    with Engine(segments=2, capacity_reads=n, capacity_bases=2 * n * L) as e:
+        e.synth_reads(7, 0, n, L, 200, 0, b1, None)
+        e.synth_reads(7, 0, n, L, 200, 1, b2, expect)
+        e.submit([Reads(b1, uniform_len=L, uniform_stride=L), Reads(b2, uniform_len=L, uniform_stride=L)], n, keep=keep)
+        e.sync()
+        assert torch.equal(keep, expect)

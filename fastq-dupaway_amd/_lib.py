@@ -64,6 +64,13 @@ def load_library():
     if not LIB_PATH.exists():
         raise FqdError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: run __graft_entry__.build() "
                                       f"(make -C {PKG_DIR}); this engine has no CPU path")
+    # torch bundles its own libamdhip64 (same soname as /opt/rocm's).  One process must hold ONE
+    # HIP runtime, so when torch is installed it is imported first and this library binds to the
+    # runtime torch already loaded; otherwise torch would find ours and see no devices.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(str(LIB_PATH))
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     L.fqd_abi_version.restype = i32

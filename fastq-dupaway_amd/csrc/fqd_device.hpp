@@ -3,9 +3,16 @@
 // Key format (replaces the reference's base-5 17-mer words, seq_utils.cpp:23-49,
 // with an equally lossless but denser, shift-only packing):
 //   per mate, per block of 64 bases:  [codes(bases 0..31)] [codes(bases 32..63), if any] [N-mask(64 bits)]
-//   codes: 2 bits per base, base k of the group at bits 2k..2k+1, A=0 C=1 T=2 G=3, N=3 (+ its mask bit)
 //   words(L) = ceil(L/32) + ceil(L/64);  L = 150 -> 8 words = 64 B (one HBM line)
-// Unused high bits are zero, so for equal lengths  key words equal <=> sequences equal.
+//   2-bit code: A=0 C=1 T=2 G=3, N=3 plus its mask bit.
+// Bit positions follow what four-bases-per-dword SWAR produces without any
+// transposition (any fixed bijection serves equality):  a 32-base group is 8 dwords
+// d0..d7 of 4 ASCII bytes; base 4k+j (dword k, byte j) of the group goes to
+//   codes word: half = k/4 (low / high 32 bits), bits 8j + 2(k%4) .. +1
+//   mask  word: 32 bits per group (low: first group of the block, high: second),
+//               bit 8j + k
+// Bases past the end count as 'A' (zeros), so for equal lengths
+//   key words equal <=> sequences equal.
 // Lengths are compared separately (uniform engines: implied; ragged: header word).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -87,76 +94,104 @@ __host__ __device__ __forceinline__ uint32_t first_set_bit(uint32_t x)   // x !=
 #endif
 }
 
-// ---- 4 bases at a time -----------------------------------------------------------
+// ---- 32 bases at a time -----------------------------------------------------------
 // ASCII      A=0x41 C=0x43 G=0x47 T=0x54 N=0x4E
 // (c>>1)&7   A=0    C=1    G=3    T=2    N=7      -> low 2 bits = code, bit 2 = "is N"
 // A v_perm_b32 lookup of that 3-bit value rebuilds the byte the code stands for;
 // any input byte that does not round-trip is outside {A,C,G,T,N}.
-struct Quad {
-    uint32_t codes;   // 8 bits: base k at bits 2k..2k+1
-    uint32_t nmask;   // 4 bits
-    uint32_t diff;    // nonzero byte k <=> byte k invalid
+struct Group {
+    uint64_t codes;
+    uint32_t nmask;
+    uint32_t diff;     // nonzero <=> some byte of the group is invalid
 };
 
-__host__ __device__ __forceinline__ Quad pack_quad(uint32_t w)
+// w[0..7]: the group's dwords, bytes past the sequence end already replaced by 'A'.
+__host__ __device__ __forceinline__ Group pack_group(const uint32_t (&w)[8])
 {
-    const uint32_t c3 = (w >> 1) & 0x07070707u;
-    const uint32_t back = perm_bytes(0x4E000000u, 0x47544341u, c3);
-    Quad q;
-    q.diff = back ^ w;
-    const uint32_t c2 = c3 & 0x03030303u;
-    const uint32_t t = c2 | (c2 >> 6);
-    q.codes = (t | (t >> 12)) & 0xFFu;
-    const uint32_t m = (c3 >> 2) & 0x01010101u;
-    const uint32_t u = m | (m >> 7);
-    q.nmask = (u | (u >> 14)) & 0xFu;
-    return q;
+    uint32_t c[8], diff = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        c[k] = (w[k] >> 1) & 0x07070707u;
+        diff |= perm_bytes(0x4E000000u, 0x47544341u, c[k]) ^ w[k];
+    }
+    const uint32_t M = 0x03030303u, N = 0x04040404u;
+    const uint32_t lo = (c[0] & M) | ((c[1] & M) << 2) | ((c[2] & M) << 4) | ((c[3] & M) << 6);
+    const uint32_t hi = (c[4] & M) | ((c[5] & M) << 2) | ((c[6] & M) << 4) | ((c[7] & M) << 6);
+    const uint32_t y0 = ((c[0] & N) >> 2) | ((c[1] & N) >> 1) | (c[2] & N) | ((c[3] & N) << 1);
+    const uint32_t y1 = ((c[4] & N) << 2) | ((c[5] & N) << 3) | ((c[6] & N) << 4) | ((c[7] & N) << 5);
+    Group g;
+    g.codes = uint64_t(lo) | (uint64_t(hi) << 32);
+    g.nmask = y0 | y1;
+    g.diff = diff;
+    return g;
 }
 
-// Replaces bytes at index >= n (n in 1..3) of w by 'A' so they pack to zeros.
+// Replaces bytes at index >= n (n in 0..4) of w by 'A' so they pack to zeros.
 __host__ __device__ __forceinline__ uint32_t pad_tail(uint32_t w, uint32_t n)
 {
-    const uint32_t keep = (1u << (8u * n)) - 1u;
+    const uint32_t keep = n >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n)) - 1u);
     return (w & keep) | (0x41414141u & ~keep);
 }
 
-// ---- streaming packer ----------------------------------------------------------
-// Feeds consecutive dwords of one mate's sequence; emits key words in layout
-// order through `sink(word)` and reports the first invalid byte.
-struct Packer {
-    uint64_t codes = 0;     // current 32-base group
-    uint64_t mask = 0;      // current 64-base block
-    uint32_t bases = 0;     // bases consumed so far
-    uint32_t bad_pos = 0xFFFFFFFFu;
-    uint32_t bad_byte = 0;
+// First byte of [p, p+len) outside {A,C,G,T,N}: the slow path behind a nonzero diff.
+__host__ __device__ inline uint32_t first_bad_base(const uint8_t* p, uint32_t len, uint32_t* byte)
+{
+    for (uint32_t k = 0; k < len; ++k) {
+        const uint8_t c = p[k];
+        if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') { *byte = c; return k; }
+    }
+    *byte = 0;
+    return 0xFFFFFFFFu;
+}
 
-    template <class Sink>
-    __host__ __device__ __forceinline__ void push(uint32_t w, uint32_t nvalid /*1..4*/, Sink&& sink)
-    {
-        if (nvalid < 4u) w = pad_tail(w, nvalid);
-        const Quad q = pack_quad(w);
-        if (q.diff != 0u && bad_pos == 0xFFFFFFFFu) {
-            const uint32_t k = first_set_bit(q.diff) >> 3;
-            bad_pos = bases + k;
-            bad_byte = (w >> (8u * k)) & 0xFFu;
-        }
-        const uint32_t in_group = bases & 31u;
-        const uint32_t in_block = bases & 63u;
-        codes |= uint64_t(q.codes) << (2u * in_group);
-        mask  |= uint64_t(q.nmask) << in_block;
-        bases += nvalid;
-        if ((bases & 31u) == 0u && nvalid == 4u) {          // a group filled exactly
-            sink(codes); codes = 0;
-            if ((bases & 63u) == 0u) { sink(mask); mask = 0; }
-        }
+// ---- one mate, group by group -------------------------------------------------------
+// q: dword-aligned window, the sequence starts `sh` bytes (0..3) into q[0].  Emits key
+// words in layout order through sink(word); returns the OR of the groups' diffs.
+// Never reads a dword that holds no byte of the sequence.
+template <class Sink>
+__host__ __device__ __forceinline__ uint32_t pack_mate(const uint32_t* __restrict__ q, uint32_t sh, uint32_t len, Sink&& sink)
+{
+    const uint32_t n_src = (sh + len + 3u) >> 2;          // aligned dwords that hold sequence bytes
+    const uint32_t n_full = len >> 5;                     // groups of exactly 32 bases
+    uint32_t diff = 0;
+    uint32_t mask_lo = 0;
+    uint32_t carry = n_src ? q[0] : 0u;
+    uint32_t g = 0;
+    for (; g < n_full; ++g) {                             // every dword of these groups is in range
+        uint32_t d[9], w[8];
+        d[0] = carry;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) d[k] = q[8u * g + k];
+        d[8] = (8u * g + 8u < n_src) ? q[8u * g + 8u] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = shifted_dword(d[k], d[k + 1], sh);
+        carry = d[8];
+        const Group r = pack_group(w);
+        diff |= r.diff;
+        sink(r.codes);
+        if (g & 1u) { sink(uint64_t(mask_lo) | (uint64_t(r.nmask) << 32)); mask_lo = 0; }
+        else        mask_lo = r.nmask;
     }
-    // Flushes the partial group/block after the last push.
-    template <class Sink>
-    __host__ __device__ __forceinline__ void finish(Sink&& sink)
-    {
-        if ((bases & 31u) != 0u) { sink(codes); codes = 0; }
-        if ((bases & 63u) != 0u) { sink(mask); mask = 0; }
+    const uint32_t rem = len & 31u;
+    if (rem) {                                            // last, partial group
+        uint32_t d[9], w[8];
+        d[0] = carry;
+#pragma unroll
+        for (int k = 1; k < 9; ++k) d[k] = (8u * g + k < n_src) ? q[8u * g + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t have = rem > 4u * k ? rem - 4u * k : 0u;
+            w[k] = pad_tail(shifted_dword(d[k], d[k + 1], sh), have);
+        }
+        const Group r = pack_group(w);
+        diff |= r.diff;
+        sink(r.codes);
+        if (g & 1u) { sink(uint64_t(mask_lo) | (uint64_t(r.nmask) << 32)); mask_lo = 0; g = 0; }
+        else        { sink(uint64_t(r.nmask)); g = 0; }
+    } else if (n_full & 1u) {
+        sink(uint64_t(mask_lo));                          // odd number of full groups: flush the half block
     }
-};
+    return diff;
+}
 
 } // namespace fqd

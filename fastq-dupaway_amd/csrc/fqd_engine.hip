@@ -228,16 +228,23 @@ int convert_to_ragged(fqd_engine* e, uint64_t records_after)
     return FQD_OK;
 }
 
-struct StagedChoice { bool staged; uint32_t R; uint32_t tile0, tile1; };
+struct StagedChoice { bool staged; uint32_t R; uint32_t tile0, tile1; uint32_t lds_out; };
 
-StagedChoice choose_staged(const fqd_engine* e, const fqd_reads* seg, bool uniform)
+StagedChoice choose_staged(const fqd_engine* e, const fqd_reads* seg, bool uniform, const KeyStore& ks)
 {
-    StagedChoice c{false, 0, 0, 0};
+    StagedChoice c{false, 0, 0, 0, 0};
     if (!uniform || (e->flags & FQD_FLAG_NO_STAGE)) return c;
     for (uint32_t R = 256; R >= 64; R -= 64) {
         uint64_t t0 = (uint64_t(R) * seg[0].uniform_stride + 32 + 15) & ~15ull;
         uint64_t t1 = (e->S == 2) ? ((uint64_t(R) * seg[1].uniform_stride + 32 + 15) & ~15ull) : 0;
-        if (t0 + t1 <= 64 * 1024) { c = {true, R, uint32_t(t0), uint32_t(t1)}; return c; }
+        if (t0 + t1 <= 64 * 1024) {
+            // keys parked in LDS and streamed out as whole lines: see encode_staged_kernel
+            const uint32_t row_words = ks.W0 + ks.lead;
+            const uint32_t lds_out = (!ks.koff && ks.stride == row_words && row_words > 1 &&
+                                      seg[0].uniform_stride >= 8u * row_words + 15u) ? 1u : 0u;
+            c = {true, R, uint32_t(t0), uint32_t(t1), lds_out};
+            return c;
+        }
     }
     return c;
 }
@@ -246,17 +253,19 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
                   uint64_t first_idx, const KeyStore& ks, uint64_t* hash_out)
 {
     Bracket br(e, K_ENCODE, n);
-    const StagedChoice c = choose_staged(e, seg, uniform);
+    const StagedChoice c = choose_staged(e, seg, uniform, ks);
     uint64_t* err = e->d_state;
     if (c.staged) {
         const uint32_t grid = uint32_t(std::min<uint64_t>((n + c.R - 1) / c.R, uint64_t(e->n_cu) * 8u));
         const size_t lds = size_t(c.tile0) + c.tile1;
-        if (e->S == 1)
-            hipLaunchKernelGGL(encode_staged_kernel<1>, dim3(grid), dim3(c.R), lds, e->stream,
-                               sv[0], sv[1], n, first_idx, ks, hash_out, err, c.tile0, c.tile1);
-        else
-            hipLaunchKernelGGL(encode_staged_kernel<2>, dim3(grid), dim3(c.R), lds, e->stream,
-                               sv[0], sv[1], n, first_idx, ks, hash_out, err, c.tile0, c.tile1);
+        const uint32_t rw = ks.W0 + ks.lead;
+        const uint32_t magic = rw > 1 ? uint32_t(((1ull << 32) + rw - 1) / rw) : 0xFFFFFFFFu;   // x/rw for x < 2^16
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, e->stream,
+                               sv[0], sv[1], n, first_idx, ks, hash_out, err, c.tile0, magic);
+        };
+        if (e->S == 1) { if (c.lds_out) launch(encode_staged_kernel<1, true>); else launch(encode_staged_kernel<1, false>); }
+        else           { if (c.lds_out) launch(encode_staged_kernel<2, true>); else launch(encode_staged_kernel<2, false>); }
     } else {
         if (e->S == 1)
             hipLaunchKernelGGL(encode_general_kernel<1>, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,

@@ -40,33 +40,20 @@ struct KeyStore {
 };
 
 // ---------------------------------------------------------------------------
-// Per-lane packing of one mate from a dword-aligned window: the sequence starts
-// `sh` bytes (0..3) into q[0].  Aligned dword loads + v_alignbyte; never reads a
-// dword that holds no byte of the sequence.  q may point to HBM or to LDS (the
-// caller keeps the pointer's provenance visible so LDS reads stay ds_read_b32).
-template <class Sink>
-__device__ __forceinline__ void pack_dwords(const uint32_t* __restrict__ q, uint32_t sh, uint32_t len,
-                                            Packer& pk, Sink&& sink)
+// Shared tail of both encoders: error word for a record whose packing saw a bad byte.
+// Rare path: rescans the mate(s) byte by byte in global memory for the FIRST offender,
+// which is what the reference would have reported (seq_utils.cpp:17-19).
+__device__ __noinline__ uint64_t locate_bad_base(const uint8_t* p0, uint32_t l0, const uint8_t* p1, uint32_t l1,
+                                                 uint64_t record)
 {
-    const uint32_t n_src = (sh + len + 3u) >> 2;      // aligned dwords that hold sequence bytes
-    const uint32_t n_quad = (len + 3u) >> 2;
-    uint32_t cur = n_src ? q[0] : 0u;
-    for (uint32_t k = 0; k < n_quad; ++k) {
-        const uint32_t nxt = (k + 1u < n_src) ? q[k + 1u] : 0u;
-        const uint32_t w = shifted_dword(cur, nxt, sh);
-        const uint32_t left = len - 4u * k;
-        pk.push(w, left < 4u ? left : 4u, sink);
-        cur = nxt;
+    uint32_t byte = 0;
+    uint32_t pos = first_bad_base(p0, l0, &byte);
+    if (pos != 0xFFFFFFFFu) return make_error(record, 0, pos, byte);
+    if (p1) {
+        pos = first_bad_base(p1, l1, &byte);
+        if (pos != 0xFFFFFFFFu) return make_error(record, 1, pos, byte);
     }
-    pk.finish(sink);
-}
-
-template <class Sink>
-__device__ __forceinline__ void pack_from_memory(const uint8_t* p, uint32_t len, Packer& pk, Sink&& sink)
-{
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t sh = uint32_t(a & 3u);
-    pack_dwords(reinterpret_cast<const uint32_t*>(a - sh), sh, len, pk, sink);
+    return kNoError;
 }
 
 // ---------------------------------------------------------------------------
@@ -86,19 +73,21 @@ void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_id
         uint64_t h = hash_begin(l0, l1);
         if (ks.koff) *out++ = uint64_t(l0) | (uint64_t(l1) << 32);
         auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
-        Packer p0;
-        pack_from_memory(s0.ptr(i), l0, p0, sink);
-        uint64_t e = kNoError;
-        if (p0.bad_pos != 0xFFFFFFFFu) e = make_error(first_idx + i, 0, p0.bad_pos, p0.bad_byte);
+        const uint8_t* p0 = s0.ptr(i);
+        const uint8_t* p1 = (S == 2) ? s1.ptr(i) : nullptr;
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(p0);
+        uint32_t diff = pack_mate(reinterpret_cast<const uint32_t*>(a0 & ~uintptr_t(3)), uint32_t(a0 & 3u), l0, sink);
         if (S == 2) {
-            Packer p1;
-            pack_from_memory(s1.ptr(i), l1, p1, sink);
-            if (e == kNoError && p1.bad_pos != 0xFFFFFFFFu) e = make_error(first_idx + i, 1, p1.bad_pos, p1.bad_byte);
+            const uintptr_t a1 = reinterpret_cast<uintptr_t>(p1);
+            diff |= pack_mate(reinterpret_cast<const uint32_t*>(a1 & ~uintptr_t(3)), uint32_t(a1 & 3u), l1, sink);
         }
         h = hash_end(h);
         if (hash_out) hash_out[i] = h;
         else          ks.slot(first_idx + i)[-1] = h;
-        if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
+        if (diff) {
+            const uint64_t e = locate_bad_base(p0, l0, p1, l1, first_idx + i);
+            if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
+        }
     }
 }
 
@@ -107,15 +96,26 @@ void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_id
 // per read, back to back).  A workgroup pulls a tile of R reads (R*stride bytes,
 // 16-B aligned chunks) into LDS with fully coalesced 16-byte loads, then each
 // lane packs one read out of LDS.  HBM sees only whole-line streaming reads.
-//   tile_reads R = blockDim.x; LDS = round16(R*stride + 32)
-template <int S>
+//
+// LDS_OUT: instead of 64 scattered 8-byte stores per instruction, a lane writes its
+// key words over the bytes of ITS OWN read that it has already consumed (row start =
+// first 8-aligned byte >= 4 bytes into the read, so the boundary dword shared with
+// the previous read is never touched; key word k ends at most 27+12k bytes in, always
+// behind the read pointer, which is past 32k+32 when that word is produced).  Each
+// wave then streams its 64 rows out as one contiguous run.  The host picks LDS_OUT
+// only when  stride0 >= 8*row_words + 15  (row_words = W0 + lead) and the batch's key
+// slots are contiguous (no koff).  rw_magic = ceil(2^32 / row_words).
+//   tile_reads R = blockDim.x (multiple of 64); LDS = round16(R*stride + 32) per mate
+template <int S, bool LDS_OUT>
 __global__ __launch_bounds__(kBlock)
 void encode_staged_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx,
                           KeyStore ks, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err,
-                          uint32_t tile_bytes0, uint32_t /*tile_bytes1*/)
+                          uint32_t tile_bytes0, uint32_t rw_magic)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint64_t* lds64 = reinterpret_cast<uint64_t*>(lds);
     const uint32_t R = blockDim.x;
+    const uint32_t row_words = ks.W0 + ks.lead;
     const uint64_t n_tiles = (n + R - 1) / R;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t r0 = tile * R;
@@ -137,28 +137,52 @@ void encode_staged_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx
         }
         __syncthreads();
         const uint32_t t = threadIdx.x;
+        const uint64_t i = r0 + t;
+        const uint32_t l0 = s0.ulen, l1 = (S == 2) ? s1.ulen : 0u;
+        const uint32_t in0 = lds_off[0] + head[0];                  // byte offset of the tile's first read
         if (t < nr) {
-            const uint64_t i = r0 + t;
-            const uint32_t l0 = s0.ulen, l1 = (S == 2) ? s1.ulen : 0u;
-            uint64_t* out = ks.slot(first_idx + i);
             uint64_t h = hash_begin(l0, l1);
-            if (ks.koff) *out++ = uint64_t(l0) | (uint64_t(l1) << 32);
-            auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
-            Packer p0;
-            const uint32_t b0 = lds_off[0] + head[0] + t * s0.ustride;
-            pack_dwords(lds + (b0 >> 2), b0 & 3u, l0, p0, sink);
-            uint64_t e = kNoError;
-            if (p0.bad_pos != 0xFFFFFFFFu) e = make_error(first_idx + i, 0, p0.bad_pos, p0.bad_byte);
-            if (S == 2) {
-                Packer p1;
-                const uint32_t b1 = lds_off[1] + head[1] + t * s1.ustride;
-                pack_dwords(lds + (b1 >> 2), b1 & 3u, l1, p1, sink);
-                if (e == kNoError && p1.bad_pos != 0xFFFFFFFFu) e = make_error(first_idx + i, 1, p1.bad_pos, p1.bad_byte);
+            const uint32_t b0 = in0 + t * s0.ustride;
+            uint32_t diff;
+            if (LDS_OUT) {
+                uint64_t* row = lds64 + ((b0 + 4u + 7u) >> 3) + ks.lead;
+                uint64_t* out = row;
+                auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
+                diff = pack_mate(lds + (b0 >> 2), b0 & 3u, l0, sink);
+                if (S == 2) {
+                    const uint32_t b1 = lds_off[1] + head[1] + t * s1.ustride;
+                    diff |= pack_mate(lds + (b1 >> 2), b1 & 3u, l1, sink);
+                }
+                h = hash_end(h);
+                if (hash_out) hash_out[i] = h; else row[-1] = h;
+            } else {
+                uint64_t* out = ks.slot(first_idx + i);
+                if (ks.koff) *out++ = uint64_t(l0) | (uint64_t(l1) << 32);
+                auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
+                diff = pack_mate(lds + (b0 >> 2), b0 & 3u, l0, sink);
+                if (S == 2) {
+                    const uint32_t b1 = lds_off[1] + head[1] + t * s1.ustride;
+                    diff |= pack_mate(lds + (b1 >> 2), b1 & 3u, l1, sink);
+                }
+                h = hash_end(h);
+                if (hash_out) hash_out[i] = h; else ks.slot(first_idx + i)[-1] = h;
             }
-            h = hash_end(h);
-            if (hash_out) hash_out[i] = h;
-            else          ks.slot(first_idx + i)[-1] = h;
-            if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
+            if (diff) {
+                const uint64_t e = locate_bad_base(s0.bases + i * uint64_t(s0.ustride), l0,
+                                                   (S == 2) ? s1.bases + i * uint64_t(s1.ustride) : nullptr, l1, first_idx + i);
+                if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
+            }
+        }
+        if (LDS_OUT) {
+            // the wave's 64 rows -> one contiguous run of key slots
+            const uint32_t wave = t >> 6, lane = t & 63u;
+            const uint32_t wave_reads = (nr > wave * 64u) ? ((nr - wave * 64u < 64u) ? nr - wave * 64u : 64u) : 0u;
+            uint64_t* __restrict__ gout = ks.keys + (first_idx + r0 + wave * 64u) * uint64_t(ks.stride);
+            const uint32_t total = wave_reads * row_words;
+            for (uint32_t x = lane; x < total; x += 64u) {
+                const uint32_t rr = __umulhi(x, rw_magic), kk = x - rr * row_words;
+                gout[x] = lds64[((in0 + (wave * 64u + rr) * s0.ustride + 4u + 7u) >> 3) + kk];
+            }
         }
         __syncthreads();
     }
@@ -166,10 +190,12 @@ void encode_staged_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx
 
 // ---------------------------------------------------------------------------
 // Exact key comparison (setRecord::operator== / setRecordPair::operator==).
+// All loads of a 4-word chunk are issued before any compare so a tag match costs one
+// memory round trip per chunk, not one per word.
 __device__ __forceinline__ bool keys_equal(const KeyStore& ks, uint32_t a, uint32_t b)
 {
-    const uint64_t* p = ks.slot(a);
-    const uint64_t* q = ks.slot(b);
+    const uint64_t* __restrict__ p = ks.slot(a);
+    const uint64_t* __restrict__ q = ks.slot(b);
     uint32_t W = ks.W0;
     if (ks.koff) {
         const uint64_t ha = p[0];
@@ -177,9 +203,19 @@ __device__ __forceinline__ bool keys_equal(const KeyStore& ks, uint32_t a, uint3
         W = seg_words(uint32_t(ha)) + seg_words(uint32_t(ha >> 32));
         ++p; ++q;
     }
-    for (uint32_t k = 0; k < W; ++k)
-        if (p[k] != q[k]) return false;
-    return true;
+    uint32_t k = 0;
+    for (; k + 8u <= W; k += 8u) {
+        uint64_t x[8], y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x[j] = p[k + j]; y[j] = q[k + j]; }
+        uint64_t d = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d |= x[j] ^ y[j];
+        if (d) return false;
+    }
+    uint64_t d = 0;
+    for (; k < W; ++k) d |= p[k] ^ q[k];
+    return d == 0;
 }
 
 // insert: one record per lane.  Slot = (tag:32 | record index:32), EMPTY = all ones.
@@ -197,6 +233,7 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, KeyStore ks
                    unsigned long long* __restrict__ counters /* [0]=dups [1]=table-full */)
 {
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(table);
+    uint32_t dups = 0, lost = 0;
     for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
         const uint64_t h = hashes[i * uint64_t(hash_stride)];
         const uint32_t idx = first_idx + uint32_t(i);
@@ -208,17 +245,26 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, KeyStore ks
             const unsigned long long old = atomicCAS(&tab[pos], kEmptySlot, mine);
             if (old == kEmptySlot) { placed = true; break; }
             if ((old >> 32) == tag && keys_equal(ks, idx, uint32_t(old))) {
-                const unsigned long long prev = atomicMin(&tab[pos], mine);
-                const uint32_t owner = uint32_t(prev);
+                // The slot now belongs to my key for good.  If its owner is older I lose and the
+                // table needs no update; only an owner younger than me has to be displaced.
+                uint32_t owner = uint32_t(old);
+                if (owner > idx) owner = uint32_t(atomicMin(&tab[pos], mine));
                 if (owner < idx) keep[i] = 0;                       // an earlier record holds this key
                 else             keep[owner - first_idx] = 0;       // I am earlier: the displaced one loses
-                atomicAdd(&counters[0], 1ull);
+                ++dups;
                 placed = true;
                 break;
             }
             pos = (pos + 1) & slot_mask;
         }
-        if (!placed) atomicAdd(&counters[1], 1ull);
+        if (!placed) ++lost;
+    }
+    // one counter update per wave, not per duplicate (a single hot address serialises)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { dups += __shfl_down(dups, d, 64); lost += __shfl_down(lost, d, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (dups) atomicAdd(&counters[0], static_cast<unsigned long long>(dups));
+        if (lost) atomicAdd(&counters[1], static_cast<unsigned long long>(lost));
     }
 }
 

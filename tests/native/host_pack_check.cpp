@@ -25,18 +25,11 @@ int main()
         std::vector<uint64_t> words;
         uint64_t h = fqd::hash_begin(len, 0);
         auto sink = [&](uint64_t w) { words.push_back(w); h = fqd::hash_word(h, w); };
-        fqd::Packer pk;
-        const uint32_t n_src = (shift + len + 3u) >> 2, n_quad = (len + 3u) >> 2;
-        uint32_t cur = n_src ? buf[0] : 0u;
-        for (uint32_t k = 0; k < n_quad; ++k) {
-            const uint32_t nxt = (k + 1u < n_src) ? buf[k + 1u] : 0u;
-            const uint32_t left = len - 4u * k;
-            pk.push(fqd::shifted_dword(cur, nxt, shift), left < 4u ? left : 4u, sink);
-            cur = nxt;
-        }
-        pk.finish(sink);
+        const uint32_t diff = fqd::pack_mate(buf.data(), shift, len, sink);
+        uint32_t bad_byte = 0, bad_pos = 0xFFFFFFFFu;
+        if (diff) bad_pos = fqd::first_bad_base(reinterpret_cast<const uint8_t*>(raw.data()), len, &bad_byte);
         h = fqd::hash_end(h);
-        std::printf("%zu %llu %u %u", words.size(), (unsigned long long)h, pk.bad_pos, pk.bad_byte);
+        std::printf("%zu %llu %u %u", words.size(), (unsigned long long)h, bad_pos, bad_byte);
         for (uint64_t w : words) std::printf(" %llu", (unsigned long long)w);
         std::printf("\n");
     }

@@ -41,17 +41,19 @@ def packer():
 
 def expected_words(seq: bytes):
     """Independent statement of the layout in fqd_device.hpp: per 64-base block
-    [codes 0..31][codes 32..63 if any][N mask]."""
+    [codes group 0][codes group 1 if any][N mask]; inside a 32-base group, base
+    4k+j (dword k, byte j) -> codes bits 32*(k//4) + 8j + 2(k%4), mask bit 8j + k."""
     words = []
     for blk in range(0, len(seq), 64):
         part = seq[blk:blk + 64]
         mask = 0
-        for g in range(0, len(part), 32):
+        for gi, g in enumerate(range(0, len(part), 32)):
             w = 0
-            for k, c in enumerate(part[g:g + 32]):
-                w |= CODE[c] << (2 * k)
+            for b, c in enumerate(part[g:g + 32]):
+                k, j = divmod(b, 4)
+                w |= CODE[c] << (32 * (k // 4) + 8 * j + 2 * (k % 4))
                 if c == ord("N"):
-                    mask |= 1 << (g + k)
+                    mask |= 1 << (32 * gi + 8 * j + k)
             words.append(w)
         words.append(mask)
     return words

@@ -1,0 +1,426 @@
+#include "hash_dup_remover.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <filesystem>
+#include <hip/hip_runtime_api.h>
+#include <iostream>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <thread>
+
+#include "fqdupaway.h"
+#include "id_join.hpp"
+
+namespace fqdhost {
+
+// ---------------------------------------------------------------------------
+// TemporaryDirectory (file_utils.cpp:26-40,116-130), created on first use.
+const char* TemporaryDirectory::name()
+{
+    if (name_.empty()) {
+        static const char charset[] = "0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz";
+        std::mt19937 rng(std::random_device{}());
+        std::uniform_int_distribution<size_t> pick(0, sizeof(charset) - 2);
+        for (int tries = 0; tries < 10; ++tries) {
+            std::string cand(10, '0');                       // constants.hpp:9 DIRNAME_LEN
+            for (char& c : cand) c = charset[pick(rng)];
+            if (std::filesystem::create_directory(cand)) { name_ = cand; break; }
+        }
+        if (name_.empty()) throw std::runtime_error("Number of tries exhausted.");
+    }
+    return name_.c_str();
+}
+
+TemporaryDirectory::~TemporaryDirectory()
+{
+    if (!name_.empty()) { std::error_code ec; std::filesystem::remove_all(name_, ec); }
+}
+
+namespace {
+
+#define HIP_OK(expr)                                                                        \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess)                                      \
+        throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+// RAII over the C ABI
+struct EngineHandle {
+    fqd_engine* e = nullptr;
+    EngineHandle(int segments, int device, hipStream_t stream)
+    {
+        fqd_config cfg{};
+        cfg.device = device; cfg.segments = segments; cfg.stream = stream;
+        const int rc = fqd_engine_create(&cfg, &e);
+        if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(nullptr));
+    }
+    ~EngineHandle() { fqd_engine_destroy(e); }
+};
+
+// The reference's two lines for a byte outside {A,C,G,T,N} (seq_utils.cpp:17-19).
+[[noreturn]] void throw_unknown_base(uint8_t byte)
+{
+    std::cerr << "Error: unknown character in DNA sequence: " << static_cast<char>(byte) << '\n';
+    throw std::runtime_error("Supported sequence character set: {A, N, C, G, T}!");
+}
+
+template <class T>
+struct Pinned {
+    T* p = nullptr; size_t cap = 0;
+    ~Pinned() { if (p) (void)hipHostFree(p); }
+    void reserve(size_t n)
+    {
+        if (n <= cap) return;
+        if (p) (void)hipHostFree(p);
+        void* np = nullptr;
+        HIP_OK(hipHostMalloc(&np, std::max<size_t>(n, 1024) * sizeof(T), hipHostMallocDefault));
+        p = static_cast<T*>(np); cap = std::max<size_t>(n, 1024);
+    }
+};
+
+template <class T>
+struct Device {
+    T* p = nullptr; size_t cap = 0;
+    ~Device() { if (p) (void)hipFree(p); }
+    void reserve(size_t n)
+    {
+        if (n <= cap) return;
+        if (p) (void)hipFree(p);
+        void* np = nullptr;
+        HIP_OK(hipMalloc(&np, std::max<size_t>(n, 1024) * sizeof(T)));
+        p = static_cast<T*>(np); cap = std::max<size_t>(n, 1024);
+    }
+};
+
+// Thread-safe pool / queue of raw pointers.
+template <class T>
+class Channel {
+public:
+    void push(T* v) { { std::lock_guard<std::mutex> g(m_); q_.push_back(v); } cv_.notify_one(); }
+    T* pop() { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return !q_.empty(); }); T* v = q_.front(); q_.pop_front(); return v; }
+private:
+    std::mutex m_; std::condition_variable cv_; std::deque<T*> q_;
+};
+
+struct PooledBlock : Block {
+    Channel<PooledBlock>* home = nullptr;
+    std::atomic<int> users{0};
+    void acquire() { users.fetch_add(1); }
+    void release() { if (users.fetch_sub(1) == 1) home->push(this); }
+};
+
+// One side (file) of an ordered run: a cursor over scanned blocks.
+struct Side {
+    std::unique_ptr<RecordStream> stream;
+    Channel<PooledBlock> pool;
+    std::vector<std::unique_ptr<PooledBlock>> storage;
+    PooledBlock* cur = nullptr;      // block being consumed (holds one "feeder" reference)
+    size_t pos = 0;                  // next record of cur
+    bool ended = false;              // no further records will come
+    bool failed = false; ParseFailure failure; bool held_back = false;
+
+    void open_file(const std::string& name, Format f, bool want_tag, size_t block_bytes)
+    {
+        stream = std::make_unique<RecordStream>(name, f, want_tag, block_bytes);
+    }
+    void prime(int n_blocks)
+    {
+        for (int k = 0; k < n_blocks; ++k) {
+            storage.emplace_back(new PooledBlock());
+            storage.back()->home = &pool;
+            pool.push(storage.back().get());
+        }
+        advance();                   // the reference parses the first record when the file is set (bufferedinput.hpp:38-42)
+    }
+    // Makes `cur` a block with unread records, or marks the side ended.
+    void advance()
+    {
+        while (!ended && (cur == nullptr || pos >= cur->recs.size())) {
+            if (cur) {
+                const bool was_last = cur->last;
+                if (cur->failure.set) { failed = true; failure = cur->failure; held_back = cur->held_back; }
+                cur->release(); cur = nullptr;
+                if (was_last) { ended = true; break; }
+            }
+            PooledBlock* b = pool.pop();
+            if (!stream->fill(*b)) { pool.push(b); ended = true; break; }
+            b->users.store(1);       // the feeder's reference
+            cur = b; pos = 0;
+        }
+    }
+    size_t available() { advance(); return ended ? 0 : cur->recs.size() - pos; }
+    // Does a fetched-but-unprocessed record sit at the current position?  (see Block::held_back)
+    bool has_record_here() { return available() > 0 || (failed && held_back); }
+};
+
+// One batch travelling feeder -> GPU -> writer.
+struct Work {
+    int S = 1;
+    PooledBlock* blk[2] = {nullptr, nullptr};
+    size_t begin[2] = {0, 0};
+    size_t n = 0;
+    uint64_t first_index = 0;        // pair index of the batch's first record
+    uint64_t emit_below = ~0ull;     // records at or beyond this pair index are not written
+    bool stop = false;               // tells the writer to finish
+    Pinned<uint64_t> off[2]; Pinned<uint32_t> len[2]; Pinned<uint8_t> keep;
+    Device<char> d_text[2]; Device<uint64_t> d_off[2]; Device<uint32_t> d_len[2]; Device<uint8_t> d_keep;
+};
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// Ordered runs: SE (hash_dup_remover.hpp:105-148) and PE (hash_dup_remover.hpp:194-255).
+void HashDupRemover::run_ordered(int S, const std::string* in, const std::string* out)
+{
+    // Outputs are created before the inputs are opened (hpp:110,202-203), so an unreadable
+    // input still leaves (empty) output files behind, as in the reference.
+    std::unique_ptr<OutputFile> sink[2];
+    for (int s = 0; s < S; ++s) sink[s] = std::make_unique<OutputFile>(out[s]);
+
+    Side side[2];
+    for (int s = 0; s < S; ++s) {
+        side[s].open_file(in[s], format_, S == 2, tuning_.block_bytes);      // "Cannot open file" comes first
+        HIP_OK(hipSetDevice(tuning_.device));
+        side[s].prime(4);
+        // A malformed FIRST record fails at open, before anything is processed and before the
+        // next file is touched (bufferedinput.hpp:38-42,81-84; hpp:211-212).
+        if (side[s].available() == 0 && side[s].failed && !side[s].held_back) {
+            std::cerr << side[s].failure.diag;
+            throw std::runtime_error(side[s].failure.what);
+        }
+    }
+
+    hipStream_t stream = nullptr;
+    HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+    EngineHandle eng(S, tuning_.device, stream);
+
+    constexpr int kWorks = 3;
+    std::vector<std::unique_ptr<Work>> works;
+    Channel<Work> free_works, to_write;
+    for (int k = 0; k < kWorks; ++k) { works.emplace_back(new Work()); works.back()->S = S; free_works.push(works.back().get()); }
+
+    // ---- writer thread: survivors, verbatim, in input order ----------------------------
+    std::exception_ptr writer_error;
+    std::thread writer([&] {
+        try {
+            for (;;) {
+                Work* w = to_write.pop();
+                if (w->stop) { free_works.push(w); break; }
+                for (int s = 0; s < S; ++s) {
+                    const Block& b = *w->blk[s];
+                    const char* run_from = nullptr; size_t run_len = 0;
+                    for (size_t k = 0; k < w->n; ++k) {
+                        const RecordRef& r = b.recs[w->begin[s] + k];
+                        const bool keep = w->keep.p[k] != 0 && w->first_index + k < w->emit_below;
+                        if (keep) {
+                            const char* p = b.text.p + r.start;
+                            if (run_from && run_from + run_len == p) run_len += r.size;
+                            else { if (run_len) sink[s]->write(run_from, run_len); run_from = p; run_len = r.size; }
+                        }
+                    }
+                    if (run_len) sink[s]->write(run_from, run_len);
+                }
+                for (int s = 0; s < S; ++s) w->blk[s]->release();
+                free_works.push(w);
+            }
+        } catch (...) { writer_error = std::current_exception(); for (;;) { Work* w = to_write.pop(); bool stop = w->stop; if (!stop) for (int s = 0; s < S; ++s) w->blk[s]->release(); free_works.push(w); if (stop) break; } }
+    });
+    auto stop_writer = [&] {
+        Work* w = free_works.pop(); w->stop = true; to_write.push(w);
+        writer.join();
+    };
+
+    uint64_t next_index = 0;
+    bool bad_base = false; uint8_t bad_byte = 0; uint64_t bad_record = 0;
+    Work* inflight = nullptr;
+    constexpr size_t kMaxBatch = 8u << 20;                 // records per submit
+
+    auto finish = [&](Work* w) {
+        // waits for the batch; on an unknown base cuts the output at that record
+        const int rc = fqd_engine_sync(eng.e);
+        if (rc == FQD_ERR_BAD_BASE) {
+            uint32_t seg, pos;
+            fqd_bad_base(eng.e, &bad_record, &seg, &pos, &bad_byte);
+            bad_base = true;
+            w->emit_below = bad_record;
+        } else if (rc != FQD_OK) {
+            for (int s = 0; s < S; ++s) w->blk[s]->release();
+            free_works.push(w);
+            throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng.e));
+        }
+        to_write.push(w);
+    };
+
+    try {
+        while (!bad_base) {
+            size_t n = kMaxBatch;
+            for (int s = 0; s < S; ++s) n = std::min(n, side[s].available());
+            if (n == 0) break;
+            Work* w = free_works.pop();
+            w->stop = false; w->n = n; w->first_index = next_index; w->emit_below = ~0ull;
+            fqd_reads seg[2] = {};
+            w->keep.reserve(n); w->d_keep.reserve(n);
+            for (int s = 0; s < S; ++s) {
+                PooledBlock* b = side[s].cur;
+                b->acquire();
+                w->blk[s] = b; w->begin[s] = side[s].pos;
+                const RecordRef* r = &b->recs[side[s].pos];
+                const uint64_t text_lo = r[0].start;
+                const uint64_t text_hi = r[n - 1].start + r[n - 1].size;
+                // uniform batch: same sequence length everywhere and equally spaced sequences
+                bool uniform = n > 1;
+                const uint64_t stride = n > 1 ? r[1].seq_start() - r[0].seq_start() : 0;
+                for (size_t k = 1; k < n && uniform; ++k)
+                    uniform = r[k].seq_len == r[0].seq_len && r[k].seq_start() - r[k - 1].seq_start() == stride;
+                uniform = uniform && stride <= 0xFFFFFFFFull;
+                w->d_text[s].reserve(text_hi - text_lo + 32);
+                HIP_OK(hipMemcpyAsync(w->d_text[s].p, b->text.p + text_lo, text_hi - text_lo, hipMemcpyHostToDevice, stream));
+                if (uniform) {
+                    seg[s].bases = reinterpret_cast<const uint8_t*>(w->d_text[s].p) + (r[0].seq_start() - text_lo);
+                    seg[s].uniform_len = r[0].seq_len; seg[s].uniform_stride = static_cast<uint32_t>(stride);
+                } else {
+                    w->off[s].reserve(n); w->len[s].reserve(n); w->d_off[s].reserve(n); w->d_len[s].reserve(n);
+                    for (size_t k = 0; k < n; ++k) { w->off[s].p[k] = r[k].seq_start() - text_lo; w->len[s].p[k] = r[k].seq_len; }
+                    HIP_OK(hipMemcpyAsync(w->d_off[s].p, w->off[s].p, n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+                    HIP_OK(hipMemcpyAsync(w->d_len[s].p, w->len[s].p, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                    seg[s].bases = reinterpret_cast<const uint8_t*>(w->d_text[s].p);
+                    seg[s].offsets = w->d_off[s].p; seg[s].lengths = w->d_len[s].p;
+                }
+                side[s].pos += n;
+            }
+            // the previous batch must be complete before this one's flags can be trusted (and
+            // its scan overlapped the GPU work): finish it first, then launch
+            if (inflight) { Work* p = inflight; inflight = nullptr; finish(p); if (bad_base) { for (int s = 0; s < S; ++s) w->blk[s]->release(); free_works.push(w); break; } }
+            const int rc = fqd_submit(eng.e, seg, n, FQD_MEM_DEVICE, w->d_keep.p);
+            if (rc != FQD_OK) { for (int s = 0; s < S; ++s) w->blk[s]->release(); free_works.push(w);
+                                throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng.e)); }
+            HIP_OK(hipMemcpyAsync(w->keep.p, w->d_keep.p, n, hipMemcpyDeviceToHost, stream));
+            inflight = w;
+            next_index += n;
+        }
+        if (inflight) { Work* p = inflight; inflight = nullptr; finish(p); }
+    } catch (...) {
+        if (inflight) { (void)hipStreamSynchronize(stream); for (int s = 0; s < S; ++s) inflight->blk[s]->release(); free_works.push(inflight); }
+        stop_writer();
+        throw;
+    }
+    stop_writer();
+    if (writer_error) std::rethrow_exception(writer_error);
+    for (int s = 0; s < S; ++s) sink[s]->close();
+
+    fqd_stats st{};
+    fqd_get_stats(eng.e, &st);
+    if (bad_base) throw_unknown_base(bad_byte);                // partial output stays on disk, as in the reference
+
+    // A malformed record is noticed by the one-record lookahead while the record before it is
+    // being fetched; it only fires if that fetch happens, i.e. the other file still has a
+    // record at this position (left file first: hpp:232-233).
+    for (int s = 0; s < S; ++s) {
+        if (side[s].available() == 0 && side[s].failed && side[s].held_back) {
+            bool other_has = true;
+            if (S == 2) other_has = side[1 - s].has_record_here();
+            if (other_has) { std::cerr << side[s].failure.diag; throw std::runtime_error(side[s].failure.what); }
+        }
+    }
+
+    summary_.total = next_index; summary_.duplicates = st.duplicates; summary_.unmatched = 0;
+    if (verbose_) {
+        if (S == 1) std::cout << summary_.total << " reads processed, out of which " << summary_.duplicates << " duplicates were removed.\n";
+        else        std::cout << summary_.total << " read pairs processed, out of which " << summary_.duplicates << " duplicates were removed.\n";
+    }
+}
+
+void HashDupRemover::filterSE(const std::string& infile, const std::string& outfile)
+{
+    run_ordered(1, &infile, &outfile);
+}
+
+void HashDupRemover::filterPE(const std::string& infile1, const std::string& infile2,
+                              const std::string& outfile1, const std::string& outfile2, bool unordered)
+{
+    const std::string in[2] = {infile1, infile2}, out[2] = {outfile1, outfile2};
+    if (unordered) run_unordered(in, out);
+    else           run_ordered(2, in, out);
+}
+
+// ---------------------------------------------------------------------------
+// --unordered (hash_dup_remover.hpp:150-192,257-347): join the two files on the ID tag,
+// dedup the joined pairs in tag order, write survivors in tag order.
+void HashDupRemover::run_unordered(const std::string* in, const std::string* out)
+{
+    (void)memlimit_; (void)tempdir_;          // intermediates live in memory, not in sorted temp files
+    HIP_OK(hipSetDevice(tuning_.device));
+    // 1. load + index both files (the reference's ExternalSorter reads them fully too, hpp:161-173)
+    LoadedFile file[2];
+    for (int s = 0; s < 2; ++s) {
+        load_whole_file(in[s], format_, tuning_.block_bytes, file[s]);
+        if (file[s].failure.set) { std::cerr << file[s].failure.diag; throw std::runtime_error(file[s].failure.what); }
+    }
+
+    // 2. outputs are opened after the sort phase (hpp:265-266)
+    OutputFile sink0(out[0]), sink1(out[1]);
+
+    // 3. join on tags
+    std::vector<std::pair<uint64_t, uint64_t>> pairs;
+    uint64_t unmatched = 0;
+    join_by_tag(file[0], file[1], tuning_.reference_tail_rule, pairs, unmatched);
+
+    // 4. pair-dedup in tag order on the GPU
+    hipStream_t stream = nullptr;
+    HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+    EngineHandle eng(2, tuning_.device, stream);
+    std::vector<uint8_t> keep(pairs.size());
+    uint64_t written_below = pairs.size();
+    bool bad = false; uint8_t bad_byte = 0;
+    {
+        const size_t kBatch = 4u << 20;
+        std::vector<uint8_t> bases[2]; std::vector<uint64_t> off[2]; std::vector<uint32_t> len[2];
+        for (size_t a = 0; a < pairs.size() && !bad; a += kBatch) {
+            const size_t n = std::min(kBatch, pairs.size() - a);
+            fqd_reads seg[2] = {};
+            for (int s = 0; s < 2; ++s) {
+                off[s].resize(n); len[s].resize(n);
+                size_t total = 0;
+                for (size_t k = 0; k < n; ++k) {
+                    const FileRecord& r = file[s].recs[s == 0 ? pairs[a + k].first : pairs[a + k].second];
+                    off[s][k] = total; len[s][k] = r.seq_len; total += r.seq_len;
+                }
+                bases[s].resize(total + 16);
+                for (size_t k = 0; k < n; ++k) {
+                    const FileRecord& r = file[s].recs[s == 0 ? pairs[a + k].first : pairs[a + k].second];
+                    std::memcpy(bases[s].data() + off[s][k], r.text + r.id_len, r.seq_len);
+                }
+                seg[s].bases = bases[s].data(); seg[s].offsets = off[s].data(); seg[s].lengths = len[s].data();
+            }
+            const int rc = fqd_submit(eng.e, seg, n, FQD_MEM_HOST, keep.data() + a);
+            if (rc == FQD_ERR_BAD_BASE) {
+                uint64_t rec; uint32_t sg2, pos;
+                fqd_bad_base(eng.e, &rec, &sg2, &pos, &bad_byte);
+                bad = true; written_below = rec;
+            } else if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng.e));
+        }
+    }
+    // 5. survivors in tag order
+    uint64_t dups = 0;
+    for (uint64_t k = 0; k < pairs.size() && k < written_below; ++k) {
+        if (!keep[k]) { ++dups; continue; }
+        const FileRecord& l = file[0].recs[pairs[k].first];
+        const FileRecord& r = file[1].recs[pairs[k].second];
+        sink0.write(l.text, l.size);
+        sink1.write(r.text, r.size);
+    }
+    sink0.close(); sink1.close();
+    if (bad) throw_unknown_base(bad_byte);
+    summary_.total = pairs.size(); summary_.duplicates = dups; summary_.unmatched = unmatched;
+    if (verbose_) {
+        std::cout << summary_.total << " valid read pairs processed, out of which " << summary_.duplicates << " duplicates were removed.\n";
+        std::cout << summary_.unmatched << " Non-matching entries from both files were skipped.\n";
+    }
+}
+
+} // namespace fqdhost

@@ -1,0 +1,64 @@
+// hash_dup_remover.hpp — host driver of the `--fast` path.
+// Same interface as the reference's HashDupRemover<T> (src/hash_dup_remover.hpp:73-94):
+//   HashDupRemover(memlimit, tempdir, verbose); filterSE(in, out);
+//   filterPE(in1, in2, out1, out2, unordered)
+// with the record type T (FastqView / FastaView [+WithId]) as a runtime Format.
+// Records are parsed on the host (records.hpp), their raw blocks are DMA'd to HBM,
+// the engine behind include/fqdupaway.h answers one keep flag per record (pair), and
+// survivors are written verbatim in input order (tag order for --unordered).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <sys/types.h>
+
+#include "records.hpp"
+
+namespace fqdhost {
+
+// Random 10-character directory in the CWD, removed on destruction
+// (FileUtils::TemporaryDirectory, src/file_utils.hpp:96-108, src/file_utils.cpp:26-40,116-130).
+// The GPU path keeps its intermediates in memory, so the directory is only created when
+// somebody asks for its name.
+class TemporaryDirectory {
+public:
+    TemporaryDirectory() = default;
+    ~TemporaryDirectory();
+    TemporaryDirectory(const TemporaryDirectory&) = delete;
+    TemporaryDirectory& operator=(const TemporaryDirectory&) = delete;
+    const char* name();
+private:
+    std::string name_;
+};
+
+struct Summary {                     // what -v prints (hash_dup_remover.hpp:146-147,253-254,342-346)
+    uint64_t total = 0, duplicates = 0, unmatched = 0;
+};
+
+struct Tuning {
+    int    device = 0;               // HIP device ordinal
+    size_t block_bytes = 64u << 20;  // input block size per file
+    // --unordered: true = the reference's merge-join including its end-of-file rule
+    // (hash_dup_remover.hpp:281,317-340), false = full inner join.
+    bool   reference_tail_rule = true;
+};
+
+class HashDupRemover {
+public:
+    HashDupRemover(Format format, ssize_t memlimit, TemporaryDirectory* tempdir, bool verbose, Tuning tuning = Tuning())
+        : format_(format), memlimit_(memlimit), tempdir_(tempdir), verbose_(verbose), tuning_(tuning) {}
+    void filterSE(const std::string& infile, const std::string& outfile);
+    void filterPE(const std::string& infile1, const std::string& infile2,
+                  const std::string& outfile1, const std::string& outfile2, bool unordered);
+    const Summary& summary() const { return summary_; }
+private:
+    void run_ordered(int n_files, const std::string* in, const std::string* out);
+    void run_unordered(const std::string* in, const std::string* out);
+    Format              format_;
+    ssize_t             memlimit_;
+    TemporaryDirectory* tempdir_;
+    bool                verbose_;
+    Tuning              tuning_;
+    Summary             summary_;
+};
+
+} // namespace fqdhost

@@ -1,0 +1,95 @@
+// records.hpp — the host feeder: block reader + FASTQ/FASTA record scanner.
+// Mirrors BufferedInput<T> (src/bufferedinput.hpp:8-103) and the record views
+// FastqView / FastaView (+WithId) of the reference (src/fastqview.cpp:89-138,190-204,
+// src/fastaview.cpp:75-100,153-167): same record grammar, same validation errors and
+// diagnostics, same ID-tag rule.  Unlike the reference it scans a whole block at once
+// and keeps the raw bytes in pinned memory, so the block can be DMA'd to HBM as is.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "file_io.hpp"
+
+namespace fqdhost {
+
+enum class Format { Fastq, Fasta };
+
+// One record inside a block; positions are byte offsets into the block's text.
+struct RecordRef {
+    uint64_t start;      // first byte of the ID line ('@' or '>')
+    uint32_t size;       // whole record, every newline included (what survivors are written with)
+    uint32_t id_len;     // ID line including its '\n'
+    uint32_t seq_len;    // bases, WITHOUT the '\n' (the reference passes seq_len()-1 to its keys)
+    uint32_t tag_off;    // join key (--unordered): offset from `start`, length — fastqview.cpp:190-204
+    uint32_t tag_len;
+    uint64_t seq_start() const { return start + id_len; }
+};
+
+// A malformed record: the stderr line the reference prints and its exception text.
+struct ParseFailure {
+    bool        set = false;
+    std::string diag;    // e.g. "Invalid record start character: x\n"
+    std::string what;    // e.g. "Fastq record should start with @ symbol!"
+};
+
+// Scans complete records in text[0,n).  Appends to `out`, returns the bytes consumed
+// (start of the first incomplete record).  Stops at a malformed record and fills `fail`.
+size_t scan_records(Format f, bool want_tag, const char* text, size_t n,
+                    std::vector<RecordRef>& out, ParseFailure& fail);
+
+// Order of two ID tags: strncmp over the shorter, then shorter first (fastqview.cpp:168-178).
+int compare_tags(const char* a, uint32_t alen, const char* b, uint32_t blen);
+
+// Page-locked host memory (hipHostMalloc) so blocks can be copied to HBM asynchronously.
+struct PinnedBuffer {
+    char*  p = nullptr;
+    size_t cap = 0;
+    PinnedBuffer() = default;
+    ~PinnedBuffer();
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    void reserve(size_t bytes);          // contents are NOT preserved
+};
+
+// One block of input: raw text of complete records + their index.
+struct Block {
+    PinnedBuffer           text;
+    size_t                 used = 0;       // bytes of complete records in text
+    std::vector<RecordRef> recs;
+    uint64_t               first_record = 0;   // index of recs[0] within the file
+    bool                   last = false;       // nothing follows (end of file or failure)
+    // failure.set: a malformed record ends the stream.  The reference parses one record
+    // ahead (BufferedInput::next, bufferedinput.hpp:91-103), so the good record just before
+    // the malformed one is fetched but never processed: it is withheld from recs
+    // (held_back) unless the malformed record is the very first of the file.
+    ParseFailure           failure;
+    bool                   held_back = false;
+};
+
+// Streams a file as blocks.  Every record handed out is known to be followed by a
+// well-formed record or by the end of the file (the last record of a non-final block
+// is carried into the next block), so a failure never has to be applied retroactively.
+// The first block must hold at least one complete record,
+// else "Not enough memory to read a single object!" (bufferedinput.hpp:82-84), which is
+// also what an empty file gives.  A final record without '\n' is dropped silently
+// (reference README.md:178).
+class RecordStream {
+public:
+    RecordStream(const std::string& name, Format f, bool want_tag, size_t block_bytes);
+    // Fills b (reusing its memory); returns false when the stream had already ended.
+    bool fill(Block& b);
+    uint64_t records_so_far() const { return n_records_; }
+private:
+    InputFile         file_;
+    Format            fmt_;
+    bool              want_tag_;
+    size_t            block_bytes_;
+    std::vector<char> carry_;              // incomplete record left over from the previous block
+    uint64_t          n_records_ = 0;
+    bool              first_ = true, done_ = false;
+};
+
+} // namespace fqdhost

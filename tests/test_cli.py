@@ -1,0 +1,354 @@
+"""The `fastq-dupaway` CLI of the MI355X build, tested the way the reference tests its own
+binary (reference test/test_basic.py, test_fast.py, test_unordered.py: run the executable,
+check the exit code, byte-compare output files) plus byte-for-byte agreement with the CPU
+oracle's file drivers on FASTQ inputs, error cases included.
+
+CPU part (`-m "not gpu"`): option surface, validation messages, exit codes, loud failure
+without a GPU.  GPU part: everything that dedups.
+"""
+import filecmp
+import gzip
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import fastq_dupaway_amd as fqd
+from fastq_dupaway_amd import _lib
+from oracle_binding import FASTA, FASTQ
+
+
+@pytest.fixture(scope="module")
+def exe():
+    if not _lib.CLI_PATH.exists():
+        fqd.build_native("all")
+    return str(_lib.CLI_PATH)
+
+
+def run(exe, *args, env=None, cwd=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([exe, *map(str, args)], capture_output=True, env=e, cwd=cwd)
+    r.stdout = r.stdout.decode("latin-1")          # no newline translation: a reported '\r' must survive
+    r.stderr = r.stderr.decode("latin-1")
+    return r
+
+
+# ---------------------------------------------------------------- CPU: option surface
+
+def test_help_goes_to_stderr_with_exit_code_1(exe):
+    # reference test/test_basic.py:11-22 (main.cpp:85-90,185-186)
+    r = run(exe, "-h")
+    assert r.returncode == 1
+    assert r.stderr.startswith("fastq-dupaway V")
+    for opt in ("--input-1", "--input-2", "--output-1", "--output-2", "--mem-limit", "--format", "--compare-seq",
+                "--distance", "--write-clusters", "--fast", "--unordered", "--verbose"):
+        assert opt in r.stderr
+    assert r.stdout == ""
+
+
+@pytest.mark.parametrize("args,msg", [
+    (["-i", "a", "-o", "b", "-u", "c", "--fast"], "Both input-2 and output-2 arguments are required for paired-end mode!"),
+    (["-i", "a", "-o", "b", "-p", "c", "--fast"], "Both input-2 and output-2 arguments are required for paired-end mode!"),
+    (["-i", "a", "-u", "a", "-o", "b", "-p", "c", "--fast"], "Paired input files should not be the same file!"),
+    (["-i", "a", "-u", "x", "-o", "b", "-p", "b", "--fast"], "Paired output files should not be the same file!"),
+    (["-i", "a", "-o", "b", "--format", "sam", "--fast"], 'Only "fastq" or "fasta" file formats are supported!'),
+    (["-i", "a", "-o", "b", "--compare-seq", "fuzzy"], "Unsupported compare-seq type provided!"),
+    (["-i", "a", "-o", "b", "-m", "100", "--fast"], "Value of unsupported range provided for --mem-limit option!"),
+    (["-i", "a", "-o", "b", "-m", "20000", "--fast"], "Value of unsupported range provided for --mem-limit option!"),
+    (["-i", "a", "-o", "b", "--fast", "--compare-seq", "loose"], "--fast mode was enabled, but argument(s) for sequence-based mode were provided!"),
+    (["-i", "a", "-o", "b", "--fast", "--distance", "3"], "--fast mode was enabled, but argument(s) for sequence-based mode were provided!"),
+    (["-i", "a", "-o", "b", "--fast", "--write-clusters"], "--fast mode was enabled, but argument(s) for sequence-based mode were provided!"),
+    (["-i", "a", "-o", "b", "--unordered"], "--unordered argument can only be used with --fast mode!"),
+    (["-i", "a", "-o", "b", "--fast", "--unordered"], "--unordered argument can only be used with paired inputs!"),
+    (["-o", "b", "--fast"], "the option '--input-1' is required but missing"),
+    (["-i", "a", "--fast"], "the option '--output-1' is required but missing"),
+    (["-i", "a", "-o", "b", "--bogus"], "unrecognised option '--bogus'"),
+    (["-i", "a", "-o", "b", "-m", "abc", "--fast"], "the argument ('abc') for option '--mem-limit' is invalid"),
+    (["-i"], "the required argument for option '--input-1' is missing"),
+])
+def test_argument_errors(exe, args, msg):
+    # main.cpp:94-177: message under "An error occured during arguments parsing:", exit 1
+    r = run(exe, *args)
+    assert r.returncode == 1
+    assert r.stderr == "An error occured during arguments parsing:\n" + msg + "\n"
+
+
+def test_sequence_based_modes_are_refused(exe, tmp_path):
+    r = run(exe, "-i", "a", "-o", tmp_path / "b")
+    assert r.returncode == 1
+    assert r.stderr.startswith("An error occured during fastq-dupaway execution:\n")
+    assert "--fast mode only" in r.stderr
+
+
+def test_option_spellings(exe, tmp_path):
+    # --name=value, -xVALUE and unambiguous prefixes parse as in Boost.program_options;
+    # the run itself then fails on the missing input with the reference's text
+    out = tmp_path / "o.fq"
+    for args in (["--input-1=/nonexistent/in.fq", f"--output-1={out}", "--fast"],
+                 ["-i/nonexistent/in.fq", f"-o{out}", "--fast", "-v"],
+                 ["--input-1", "/nonexistent/in.fq", "--output-1", out, "--fas", "--verb"]):
+        r = run(exe, *args)
+        assert r.returncode == 1
+        assert r.stderr == ("Cannot open file /nonexistent/in.fq\nAn error occured during fastq-dupaway execution:\n"
+                            "File does not exist or cannot be opened!\n")
+        assert out.exists() and out.stat().st_size == 0          # outputs are created first (hash_dup_remover.hpp:110)
+        out.unlink()
+
+
+def test_no_gpu_is_a_loud_error(exe, tmp_path):
+    import ctypes as C
+    n = C.c_int(0)
+    if fqd.load_library().fqd_device_count(C.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    src = tmp_path / "in.fa"; src.write_bytes(b">1\nACGT\n")
+    r = run(exe, "-i", src, "-o", tmp_path / "o.fa", "--format", "fasta", "--fast")
+    assert r.returncode == 1
+    assert "An error occured during fastq-dupaway execution:" in r.stderr
+
+
+# ---------------------------------------------------------------- GPU: the reference's own tests
+
+FAST = ("--format", "fasta", "--fast")
+
+
+@pytest.mark.gpu
+def test_single_fast(exe, golden_dir, tmp_path):
+    # reference test/test_fast.py:7-26
+    fx = golden_dir / "reference_fixtures"
+    out = tmp_path / "single_fast.fa"
+    r = run(exe, "-i", fx / "inputs" / "single_fast.fa", "-o", out, *FAST)
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(out, fx / "expected" / "single_fast.fa", shallow=False)
+
+
+@pytest.mark.gpu
+def test_paired_fast(exe, golden_dir, tmp_path):
+    # reference test/test_fast.py:29-57
+    fx = golden_dir / "reference_fixtures"
+    o1, o2 = tmp_path / "paired_fast_r1.fa", tmp_path / "paired_fast_r2.fa"
+    r = run(exe, "-i", fx / "inputs" / "paired_fast_r1.fa", "-u", fx / "inputs" / "paired_fast_r2.fa",
+            "-o", o1, "-p", o2, *FAST)
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(o1, fx / "expected" / "paired_fast_r1.fa", shallow=False)
+    assert filecmp.cmp(o2, fx / "expected" / "paired_fast_r2.fa", shallow=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["shuffled", "skewed", "deletion", "interleaved", "not_overlapped"])
+@pytest.mark.parametrize("full_join", ["0", "1"])
+def test_unordered(exe, golden_dir, tmp_path, name, full_join):
+    # reference test/test_unordered.py:7-48 (both join rules reproduce the fixtures)
+    fx = golden_dir / "reference_fixtures"
+    o1, o2 = tmp_path / "r1.fa", tmp_path / "r2.fa"
+    r = run(exe, "-i", fx / "inputs" / f"unordered_{name}_r1.fa", "-u", fx / "inputs" / f"unordered_{name}_r2.fa",
+            "-o", o1, "-p", o2, *FAST, "--unordered", env={"FQD_FULL_JOIN": full_join})
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(o1, fx / "expected" / f"unordered_{name}_r1.fa", shallow=False)
+    assert filecmp.cmp(o2, fx / "expected" / f"unordered_{name}_r2.fa", shallow=False)
+
+
+# ---------------------------------------------------------------- GPU: FASTQ, against the oracle's drivers
+
+def fastq(recs, qual=None):
+    out = []
+    for k, (i, s) in enumerate(recs):
+        q = (qual[k] if qual else b"I" * len(s))
+        out.append(b"@" + i + b"\n" + s + b"\n+\n" + q + b"\n")
+    return b"".join(out)
+
+
+def random_reads(rnd, n, pool, lo, hi, alphabet=b"ACGTN"):
+    seqs = [bytes(rnd.choice(alphabet) for _ in range(rnd.randrange(lo, hi + 1))) for _ in range(pool)]
+    return [rnd.choice(seqs) for _ in range(n)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block_mb", [None, "1"])
+def test_se_fastq_matches_oracle_bytes(exe, oracle, tmp_path, block_mb):
+    rnd = random.Random(31)
+    seqs = random_reads(rnd, 30000, 6000, 0, 160)
+    quals = [bytes(rnd.choice(b"!#5?IJ") for _ in s) for s in seqs]
+    src = tmp_path / "in.fq"
+    src.write_bytes(fastq([(b"r%07d some comment" % k, s) for k, s in enumerate(seqs)], quals))
+    exp, got = tmp_path / "exp.fq", tmp_path / "got.fq"
+    tot, dup = oracle.filter_single(src, exp, FASTQ)
+    r = run(exe, "-i", src, "-o", got, "--fast", "-v", env={"FQD_BLOCK_MB": block_mb} if block_mb else None)
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(got, exp, shallow=False)
+    assert r.stdout == f"{tot} reads processed, out of which {dup} duplicates were removed.\n"      # hpp:146-147
+
+
+@pytest.mark.gpu
+def test_se_uniform_150bp_fastq(exe, oracle, tmp_path):
+    # fixed-size records: the host picks the uniform descriptor and the LDS-staged encoder
+    rng = np.random.default_rng(8)
+    n, L = 50000, 150
+    pool = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=(n // 2, L), p=[.245, .245, .245, .245, .02])
+    recs = [(b"r%09d" % k, pool[rng.integers(0, len(pool))].tobytes()) for k in range(n)]
+    src = tmp_path / "in.fq"; src.write_bytes(fastq(recs))
+    exp, got = tmp_path / "exp.fq", tmp_path / "got.fq"
+    oracle.filter_single(src, exp, FASTQ)
+    r = run(exe, "-i", src, "-o", got, "--fast", env={"FQD_BLOCK_MB": "4"})
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(got, exp, shallow=False)
+
+
+@pytest.mark.gpu
+def test_pe_fastq_matches_oracle_bytes(exe, oracle, tmp_path):
+    rnd = random.Random(41)
+    n = 20000
+    s1 = random_reads(rnd, n, 1500, 1, 120)
+    s2 = random_reads(rnd, n, 30, 1, 120)
+    f1, f2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    f1.write_bytes(fastq([(b"p%06d/1" % k, s) for k, s in enumerate(s1)]))
+    f2.write_bytes(fastq([(b"p%06d/2" % k, s) for k, s in enumerate(s2[: n - 7])]))      # shorter second file
+    e1, e2, g1, g2 = (tmp_path / x for x in ("e1.fq", "e2.fq", "g1.fq", "g2.fq"))
+    tot, dup, _ = oracle.filter_paired(f1, f2, e1, e2, FASTQ)
+    assert tot == n - 7
+    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "-v", env={"FQD_BLOCK_MB": "1"})
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(g1, e1, shallow=False) and filecmp.cmp(g2, e2, shallow=False)
+    assert r.stdout == f"{tot} read pairs processed, out of which {dup} duplicates were removed.\n"   # hpp:253-254
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("style", ["illumina", "sra", "slash"])
+@pytest.mark.parametrize("full_join", ["0", "1"])
+def test_unordered_fastq_matches_oracle_bytes(exe, oracle, tmp_path, style, full_join):
+    rnd = random.Random(51)
+    n = 3000
+    seqs1 = random_reads(rnd, n, 400, 20, 60); seqs2 = random_reads(rnd, n, 10, 20, 60)
+
+    def ident(k, mate):
+        if style == "illumina":
+            return b"M01:7:FC:1:%d:%d:%d %d:N:0:ACGT" % (1100 + k % 7, 1000 + k, 2000 + 3 * k, mate)
+        if style == "sra":
+            return b"SRR99.%d len=%d" % (k + 1, 50 + mate)
+        return b"read%d/%d" % (k, mate)                    # no space: never joins
+    r1 = [(ident(k, 1), seqs1[k]) for k in range(n)]
+    r2 = [(ident(k, 2), seqs2[k]) for k in range(n)]
+    del r1[100:130]; del r2[2000:2050]                     # orphans on both sides
+    rnd.shuffle(r2)
+    f1, f2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    f1.write_bytes(fastq(r1)); f2.write_bytes(fastq(r2))
+    e1, e2, g1, g2 = (tmp_path / x for x in ("e1.fq", "e2.fq", "g1.fq", "g2.fq"))
+    tail = full_join == "0"
+    tot, dup, un = oracle.filter_paired(f1, f2, e1, e2, FASTQ, unordered=True, tail_rule=tail)
+    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", env={"FQD_FULL_JOIN": full_join})
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(g1, e1, shallow=False) and filecmp.cmp(g2, e2, shallow=False)
+    assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
+                        f"{un} Non-matching entries from both files were skipped.\n")                # hpp:342-346
+    if style == "slash":
+        assert tot == 0
+    else:
+        assert tot > 2000
+
+
+@pytest.mark.gpu
+def test_gz_in_and_out(exe, oracle, tmp_path):
+    rnd = random.Random(61)
+    raw = fastq([(b"g%05d" % k, s) for k, s in enumerate(random_reads(rnd, 5000, 700, 30, 80))])
+    src = tmp_path / "in.fq.gz"
+    with gzip.open(src, "wb") as f:
+        f.write(raw)
+    plain = tmp_path / "in.fq"; plain.write_bytes(raw)
+    exp = tmp_path / "exp.fq"; oracle.filter_single(plain, exp, FASTQ)
+    got = tmp_path / "got.fq.gz"
+    r = run(exe, "-i", src, "-o", got, "--fast")
+    assert r.returncode == 0, r.stderr
+    assert gzip.open(got, "rb").read() == exp.read_bytes()
+
+
+# ---------------------------------------------------------------- GPU: error behaviour
+
+def both(exe, oracle, tmp_path, data: bytes, fmt=FASTQ):
+    """Runs CLI and oracle on the same bytes; returns (cli result, cli output, oracle output, oracle error)."""
+    src = tmp_path / "in.txt"; src.write_bytes(data)
+    exp, got = tmp_path / "exp.out", tmp_path / "got.out"
+    err = None
+    try:
+        oracle.filter_single(src, exp, fmt)
+    except RuntimeError as e:
+        err = str(e)
+    args = ["-i", src, "-o", got, "--fast"] + (["--format", "fasta"] if fmt == FASTA else [])
+    r = run(exe, *args)
+    return r, got.read_bytes() if got.exists() else None, exp.read_bytes() if exp.exists() else None, err
+
+
+@pytest.mark.gpu
+def test_error_empty_input(exe, oracle, tmp_path, capfd):
+    r, got, exp, err = both(exe, oracle, tmp_path, b"")
+    assert r.returncode == 1 and err == "Not enough memory to read a single object!"
+    assert r.stderr == "An error occured during fastq-dupaway execution:\nNot enough memory to read a single object!\n"
+    assert got == exp == b""
+
+
+@pytest.mark.gpu
+def test_missing_final_newline_drops_last_record(exe, oracle, tmp_path):
+    r, got, exp, err = both(exe, oracle, tmp_path, fastq([(b"1", b"AC"), (b"2", b"GT"), (b"3", b"AC")])[:-1])
+    assert r.returncode == 0 and err is None and got == exp == fastq([(b"1", b"AC"), (b"2", b"GT")])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bad", [b"Ag", b"AC\r", b"RYKM", b"ac"])
+def test_error_unknown_base_keeps_partial_output(exe, oracle, tmp_path, bad, capfd):
+    recs = [(b"%d" % k, s) for k, s in enumerate([b"ACGT", b"ACGT", b"GGCC", bad, b"TTTT", b"ACGT"])]
+    r, got, exp, err = both(exe, oracle, tmp_path, fastq(recs))
+    capfd.readouterr()
+    first = next(c for c in bad if c not in b"ACGTN")
+    assert r.returncode == 1 and err == "Supported sequence character set: {A, N, C, G, T}!"
+    assert r.stderr == (f"Error: unknown character in DNA sequence: {chr(first)}\n"
+                        "An error occured during fastq-dupaway execution:\nSupported sequence character set: {A, N, C, G, T}!\n")
+    assert got == exp == fastq([recs[0], recs[2]])           # records before the bad one, deduplicated
+
+
+@pytest.mark.gpu
+def test_error_bad_start_character_lookahead(exe, oracle, tmp_path, capfd):
+    # the record BEFORE the malformed one is fetched but never written (one-record lookahead)
+    data = fastq([(b"1", b"ACGT"), (b"2", b"GGGG"), (b"3", b"TTTT")]) + b"x4\nAC\n+\nII\n" + fastq([(b"5", b"CC")])
+    r, got, exp, err = both(exe, oracle, tmp_path, data)
+    capfd.readouterr()
+    assert r.returncode == 1 and err == "Fastq record should start with @ symbol!"
+    assert r.stderr == ("Invalid record start character: x\nAn error occured during fastq-dupaway execution:\n"
+                        "Fastq record should start with @ symbol!\n")
+    assert got == exp == fastq([(b"1", b"ACGT"), (b"2", b"GGGG")])
+
+
+@pytest.mark.gpu
+def test_error_quality_length_mismatch(exe, oracle, tmp_path, capfd):
+    data = fastq([(b"1", b"ACGT"), (b"2", b"GGGG")]) + b"@3\nACGT\n+\nIII\n"
+    r, got, exp, err = both(exe, oracle, tmp_path, data)
+    capfd.readouterr()
+    assert r.returncode == 1 and err == "Sequence and Quality fields of Fastq record should have the same length!"
+    assert r.stderr.startswith("Found sequence ACGT of length 5 and quality string III of length 4\n")
+    assert got == exp == fastq([(b"1", b"ACGT")])
+
+
+@pytest.mark.gpu
+def test_error_first_record_malformed(exe, oracle, tmp_path, capfd):
+    r, got, exp, err = both(exe, oracle, tmp_path, b"ACGT\n", FASTA)
+    capfd.readouterr()
+    assert r.returncode == 1 and err == "Fasta record should start with > symbol!"
+    assert r.stderr.startswith("Invalid record start character: A\n")
+    assert got == exp == b""
+
+
+@pytest.mark.gpu
+def test_bad_base_before_malformed_record_wins(exe, oracle, tmp_path, capfd):
+    data = fastq([(b"1", b"ACGT"), (b"2", b"AxGT"), (b"3", b"TTTT")]) + b"bad\n"
+    r, got, exp, err = both(exe, oracle, tmp_path, data)
+    capfd.readouterr()
+    assert err == "Supported sequence character set: {A, N, C, G, T}!"
+    assert r.returncode == 1 and "unknown character in DNA sequence: x" in r.stderr
+    assert got == exp == fastq([(b"1", b"ACGT")])
+    # ...but a bad base in the record right before the malformed one is never reached
+    data = fastq([(b"1", b"ACGT"), (b"2", b"AxGT")]) + b"bad\n"
+    r, got, exp, err = both(exe, oracle, tmp_path, data)
+    capfd.readouterr()
+    assert err == "Fastq record should start with @ symbol!"
+    assert r.returncode == 1 and "Fastq record should start with @ symbol!" in r.stderr
+    assert got == exp == fastq([(b"1", b"ACGT")])

@@ -75,7 +75,8 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get("FQD_BENCH_FORCE_SHARDED") == "1"      # rehearse the N>1 path on one GPU
+    if world > 1 or force_sharded:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
@@ -86,19 +87,30 @@ def main():
     keep = torch.empty(n, dtype=torch.uint8, device=dev)
 
     eng = Engine(segments=S, device=local, capacity_reads=n, capacity_bases=S * n * L, profile=True)
-    first = rank * n
-    for m in range(S):
-        eng.synth_reads(a.seed, first, n, L, a.dup_permille, m, bases[m], expect if m == S - 1 else None)
+    sharded_mode = dist is not None
+    # Sharded runs move a step's reads in rounds of <= 16 M reads per rank (one all-to-all each, every
+    # message well under 4 GB).  The job's input order is (round, rank, position) — file blocks dealt
+    # round-robin to the ranks — so round k of rank r holds the global indices below.
+    rounds = max(1, -(-n // 16_000_000)) if sharded_mode else 1
+    m = -(-n // rounds)
+    spans = [(k * m, min(m, n - k * m)) for k in range(rounds)]
+    for k, (lo, cnt) in enumerate(spans):
+        first = (k * world * m + rank * cnt) if sharded_mode else 0
+        for mate in range(S):
+            eng.synth_reads(a.seed, first, cnt, L, a.dup_permille, mate, bases[mate][lo * L:],
+                            expect[lo:] if mate == S - 1 else None)
     eng.sync()
-    segs = [Reads(bases[m], uniform_len=L, uniform_stride=L) for m in range(S)]
+    segs = [Reads(bases[mate], uniform_len=L, uniform_stride=L) for mate in range(S)]
 
-    if world > 1:
-        from fastq_dupaway_amd.sharded import ShardedDedup
-        sharded = ShardedDedup(eng, dist, dev, n_max=n, len0=L, len1=(L if S == 2 else 0))
+    if sharded_mode:
+        from fastq_dupaway_amd.sharded import HipOps, ShardedDedup
+        sharded = ShardedDedup(HipOps(eng), dist, dev, n_max=m, len0=L, len1=(L if S == 2 else 0))
 
         def step():
             eng.reset()
-            sharded.dedup(segs, n, keep)
+            for lo, cnt in spans:
+                sub = [Reads(bases[mate][lo * L:], uniform_len=L, uniform_stride=L) for mate in range(S)]
+                sharded.dedup(sub, cnt, keep[lo:])
             eng.sync()
     else:
         def step():
@@ -159,7 +171,7 @@ def main():
                                        "100M single-end 150 bp FASTQ (~20% dups), --fast" if n == 100_000_000 else
                                        f"{n} {'pairs' if a.paired else 'reads'} x {L} bp per GPU"),
                           "reads_per_gpu": n, "read_len": L, "dup_fraction": a.dup_permille / 1000.0,
-                          "sharding": "none" if world == 1 else f"hash-prefix all-to-all over {world} GPUs"},
+                          "sharding": "none" if not sharded_mode else f"hash-prefix all-to-all over {world} GPU(s), {rounds} round(s) per step"},
                "parity": parity, "roofline": roofline}
         if world == 1 and a.cpu_sample > 0:
             m = min(a.cpu_sample, n)

@@ -91,6 +91,7 @@ def load_library():
     L.fqd_encode_uniform.argtypes = [vp, C.POINTER(ReadsDesc), u64, vp]
     L.fqd_partition_records.argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
     L.fqd_insert_records.argtypes = [vp, vp, u64, u32, u32, vp]
+    L.fqd_scatter_flags.argtypes = [vp, vp, vp, u64, vp]
     L.fqd_synth_reads.argtypes = [vp, u64, u64, u64, u32, u32, i32, vp, vp]
     for name in declared_symbols():
         fn = getattr(L, name)          # AttributeError here = header and library disagree

@@ -632,6 +632,18 @@ int fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n, uint3
     return FQD_OK;
 }
 
+int fqd_scatter_flags(fqd_engine* e, const uint8_t* flags, const uint32_t* origin, uint64_t n, uint8_t* keep_out)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (n && (!flags || !origin || !keep_out)) return e->fail(FQD_ERR_ARG, "fqd_scatter_flags: bad arguments");
+    if (n == 0) return FQD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    Bracket br(e, K_OTHER, 0);
+    hipLaunchKernelGGL(scatter_flags_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream, flags, origin, n, keep_out);
+    HIP_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
 int fqd_synth_reads(fqd_engine* e, uint64_t seed, uint64_t first, uint64_t n, uint32_t len,
                     uint32_t dup_permille, int mate, uint8_t* bases, uint8_t* expect_keep)
 {

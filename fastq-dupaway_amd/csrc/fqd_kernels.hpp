@@ -425,6 +425,14 @@ __global__ void part_totals_kernel(const uint64_t* __restrict__ starts2d, uint32
     counts[p] = hi - lo;
 }
 
+__global__ __launch_bounds__(kBlock)
+void scatter_flags_kernel(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ origin, uint64_t n,
+                          uint8_t* __restrict__ keep_out)
+{
+    for (uint64_t k = blockIdx.x * uint64_t(kBlock) + threadIdx.x; k < n; k += uint64_t(gridDim.x) * kBlock)
+        keep_out[origin[k]] = flags[k];
+}
+
 // ---------------------------------------------------------------------------
 // Synthetic workload.  Counter-based: every value is a pure function of
 // (seed, global index), so ranks generate their slices independently and the expected

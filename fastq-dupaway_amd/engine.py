@@ -147,6 +147,9 @@ class Engine:
     def insert_records(self, records, n: int, len0: int, len1: int, keep):
         self._check(self._L.fqd_insert_records(self._h, _addr(records), n, len0, len1, _addr(keep)))
 
+    def scatter_flags(self, flags, origin, n: int, keep_out):
+        self._check(self._L.fqd_scatter_flags(self._h, _addr(flags), _addr(origin), n, _addr(keep_out)))
+
     def synth_reads(self, seed: int, first: int, n: int, length: int, dup_permille: int, mate: int, bases, expect_keep=None):
         self._check(self._L.fqd_synth_reads(self._h, seed, first, n, length, dup_permille, mate,
                                             _addr(bases), _addr(expect_keep)))

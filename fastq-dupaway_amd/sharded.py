@@ -1,0 +1,96 @@
+"""Hash-prefix sharding of one dedup job over the GPUs of a node.
+
+One process per GPU.  Every rank encodes its own reads into fixed-size records
+[hash | key words], groups them by owner = (hash >> 40) % world, and ONE all-to-all over
+RCCL/xGMI moves each record to its owner, which inserts it into its own disjoint part of
+the set.  The keep flags travel back through the reverse all-to-all and are put back into
+input order.  First-occurrence-wins holds globally because rank r's reads are the global
+indices [r*n, (r+1)*n) of a step and the owner receives records ordered by (source rank,
+position at the source).
+
+The device work goes through an `ops` object: HipOps (the C ABI; production) — or whatever
+a CPU test injects to exercise the exchange logic under gloo.  There is no CPU fallback in
+the product: HipOps raises if the HIP library or a GPU is missing.
+"""
+from typing import Sequence
+
+import torch
+
+
+class HipOps:
+    """The sharding halves of include/fqdupaway.h on one GPU."""
+
+    def __init__(self, engine):
+        self.e = engine
+
+    def key_words(self, len0, len1):
+        return self.e.key_words(len0, len1)
+
+    def encode(self, segs, n, records):
+        self.e.encode_uniform(segs, n, records)
+
+    def partition(self, records, n, key_words, parts, out, counts, origin):
+        self.e.partition_records(records, n, key_words, parts, out, counts, origin)
+
+    def insert(self, records, n, len0, len1, keep):
+        self.e.insert_records(records, n, len0, len1, keep)
+
+    def scatter(self, flags, origin, n, keep_out):
+        self.e.scatter_flags(flags, origin, n, keep_out)
+
+    def sync(self):
+        self.e.sync()
+
+
+class ShardedDedup:
+    """dedup(segs, n, keep): keep[i] = 1 iff read i of THIS rank's batch is the first with its
+    key among all ranks' batches so far (global order: step, then rank, then position)."""
+
+    def __init__(self, ops, dist, device, n_max: int, len0: int, len1: int = 0, slack: float = 1.15):
+        self.ops, self.dist, self.device = ops, dist, device
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.len0, self.len1 = len0, len1
+        self.W = ops.key_words(len0, len1)
+        self.rw = self.W + 1
+        self.n_max = n_max
+        i64 = torch.int64
+        self.records = torch.empty(n_max * self.rw, dtype=i64, device=device)
+        self.grouped = torch.empty(n_max * self.rw, dtype=i64, device=device)
+        self.origin = torch.empty(n_max, dtype=torch.int32, device=device)
+        self.counts = torch.zeros(self.world, dtype=i64, device=device)
+        self.recv_counts = torch.zeros(self.world, dtype=i64, device=device)
+        self.cap_recv = int(n_max * slack) + 4096
+        self.recv = torch.empty(self.cap_recv * self.rw, dtype=i64, device=device)
+        self.keep_recv = torch.empty(self.cap_recv, dtype=torch.uint8, device=device)
+        self.keep_back = torch.empty(n_max, dtype=torch.uint8, device=device)
+
+    def dedup(self, segs: Sequence, n: int, keep):
+        ops, dist, rw = self.ops, self.dist, self.rw
+        if n > self.n_max:
+            raise ValueError("batch larger than the buffers this ShardedDedup was built for")
+        ops.encode(segs, n, self.records)
+        ops.partition(self.records, n, self.W, self.world, self.grouped, self.counts, self.origin)
+        ops.sync()                                   # the collectives run on torch's stream
+        dist.all_to_all_single(self.recv_counts, self.counts)
+        send = [int(c) for c in self.counts.tolist()]
+        recv = [int(c) for c in self.recv_counts.tolist()]
+        n_recv = sum(recv)
+        if n_recv > self.cap_recv:                   # a skewed step: grow once, keep going
+            self.cap_recv = int(n_recv * 1.1) + 4096
+            self.recv = torch.empty(self.cap_recv * rw, dtype=torch.int64, device=self.device)
+            self.keep_recv = torch.empty(self.cap_recv, dtype=torch.uint8, device=self.device)
+        dist.all_to_all_single(self.recv[: n_recv * rw], self.grouped[: n * rw],
+                               output_split_sizes=[c * rw for c in recv], input_split_sizes=[c * rw for c in send])
+        self._sync_comm()
+        ops.insert(self.recv, n_recv, self.len0, self.len1, self.keep_recv)
+        ops.sync()
+        dist.all_to_all_single(self.keep_back[:n], self.keep_recv[:n_recv],
+                               output_split_sizes=send, input_split_sizes=recv)
+        self._sync_comm()
+        ops.scatter(self.keep_back, self.origin, n, keep)
+        return n_recv
+
+    def _sync_comm(self):
+        if self.device is not None and getattr(self.device, "type", "cpu") == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()

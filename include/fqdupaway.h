@@ -150,6 +150,10 @@ int  fqd_partition_records(fqd_engine* e, const uint64_t* records, uint64_t n, u
 int  fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n,
                         uint32_t len0, uint32_t len1, uint8_t* keep);
 
+/* keep_out[origin[k]] = flags[k] for k < n: puts the flags that came back from the
+ * owners (in partition order) into input order.  All device pointers. */
+int  fqd_scatter_flags(fqd_engine* e, const uint8_t* flags, const uint32_t* origin, uint64_t n, uint8_t* keep_out);
+
 /* ---- synthetic workload (bench.py, tests): SURVEY §8(d) ---------------------
  * Fills `bases` (device) with n reads of `len` bases at stride `len`, global
  * indices [first, first+n): read g>0 is with probability dup_permille/1000 a

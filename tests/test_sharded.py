@@ -1,0 +1,228 @@
+"""The multi-GPU path: hash-prefix sharding with one all-to-all.
+
+CPU part: the exchange logic of fastq-dupaway_amd/sharded.py under REAL torch.distributed
+(gloo, world_size 2 and 3, separate processes), with the device halves replaced by a
+numpy stand-in that the TEST injects (the product has no CPU path).  Result must equal the
+oracle's keep flags on the concatenated global input, over several steps.
+
+GPU part (one MI355X): the same ShardedDedup + the real HipOps for 2 and 4 virtual ranks
+run as threads of one process sharing the card, the all-to-all emulated in-process; plus
+the partition kernel's stability and totals.
+"""
+import hashlib
+import os
+import socket
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from fastq_dupaway_amd.sharded import ShardedDedup
+
+L = 50
+
+
+def make_global_reads(world, n_per, steps, seed=0):
+    rng = np.random.default_rng(seed)
+    pool = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=(world * n_per * steps // 3 + 1, L))
+    pick = rng.integers(0, len(pool), size=(steps, world, n_per))
+    return pool[pick]                       # [step][rank][i][L]
+
+
+class NumpyOps:
+    """Test stand-in for the device halves: any injective key + any hash exercises the exchange."""
+
+    def __init__(self):
+        self.seen = set()
+
+    def key_words(self, len0, len1):
+        return (len0 + len1 + 7) // 8
+
+    def encode(self, segs, n, records):
+        W = self.key_words(L, 0)
+        rec = records.numpy().view(np.uint64)[: n * (W + 1)].reshape(n, W + 1)
+        bases = segs[0].bases
+        for i in range(n):
+            s = bases[i * L:(i + 1) * L].tobytes()
+            rec[i, 0] = int.from_bytes(hashlib.blake2b(s, digest_size=8).digest(), "little")
+            rec[i, 1:] = np.frombuffer(s.ljust(8 * W, b"\0"), dtype=np.uint64)
+
+    def partition(self, records, n, key_words, parts, out, counts, origin):
+        rw = key_words + 1
+        rec = records.numpy().view(np.uint64)[: n * rw].reshape(n, rw)
+        owner = ((rec[:, 0] >> np.uint64(40)) % np.uint64(parts)).astype(np.int64)
+        order = np.argsort(owner, kind="stable")
+        out.numpy().view(np.uint64)[: n * rw].reshape(n, rw)[:] = rec[order]
+        origin.numpy()[:n] = order.astype(np.int32)
+        counts.numpy()[:] = np.bincount(owner, minlength=parts)
+
+    def insert(self, records, n, len0, len1, keep):
+        rw = self.key_words(len0, len1) + 1
+        rec = records.numpy().view(np.uint64)[: n * rw].reshape(n, rw)
+        k = keep.numpy()
+        for i in range(n):                  # arrival order = (source rank, position): first arrival wins
+            key = rec[i, 1:].tobytes()
+            k[i] = 0 if key in self.seen else 1
+            self.seen.add(key)
+
+    def scatter(self, flags, origin, n, keep_out):
+        keep_out.numpy()[origin.numpy()[:n]] = flags.numpy()[:n]
+
+    def sync(self):
+        pass
+
+
+class _Seg:
+    def __init__(self, bases):
+        self.bases = bases
+
+
+def _gloo_worker(rank, world, port, reads, result_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        steps, _, n_per, _ = reads.shape
+        sd = ShardedDedup(NumpyOps(), dist, torch.device("cpu"), n_max=n_per, len0=L)
+        out = np.zeros((steps, n_per), np.uint8)
+        for st in range(steps):
+            keep = torch.zeros(n_per, dtype=torch.uint8)
+            n_here = n_per if not (st == 1 and rank == 1) else n_per - 7       # ragged step: fewer reads on one rank
+            sd.dedup([_Seg(reads[st, rank].reshape(-1))], n_here, keep)
+            out[st, :n_here] = keep.numpy()[:n_here]
+        np.save(os.path.join(result_dir, f"keep{rank}.npy"), out)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_exchange_under_gloo(oracle, tmp_path, world):
+    import torch.multiprocessing as mp
+    n_per, steps = 600, 3
+    reads = make_global_reads(world, n_per, steps, seed=world)
+    mp.spawn(_gloo_worker, args=(world, _free_port(), reads, str(tmp_path)), nprocs=world, join=True)
+    got = np.stack([np.load(tmp_path / f"keep{r}.npy") for r in range(world)], axis=1)     # [step][rank][i]
+    # the ragged step dropped the last 7 reads of rank 1 in step 1: remove them from the oracle's input too
+    mask = np.ones((steps, world, n_per), bool); mask[1, 1, n_per - 7:] = False
+    flat = reads[mask].reshape(-1, L)
+    n = len(flat)
+    exp = oracle.dedup_single(np.concatenate([flat.reshape(-1), np.zeros(8, np.uint8)]),
+                              np.arange(n, dtype=np.uint64) * np.uint64(L), np.full(n, L, np.uint32))
+    assert np.array_equal(got[mask], exp)
+    assert 0 < int((exp == 0).sum()) < n
+
+
+# ---------------------------------------------------------------- GPU: real kernels, virtual ranks
+
+class ThreadDist:
+    """In-process all-to-all between threads that each play one rank (one GPU box has one card)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.local = threading.local()
+
+    def bind(self, rank):
+        self.local.rank = rank
+
+    def get_world_size(self):
+        return self.world
+
+    def get_rank(self):
+        return self.local.rank
+
+    def all_to_all_single(self, output, input, output_split_sizes=None, input_split_sizes=None):
+        r, w = self.local.rank, self.world
+        if input_split_sizes is None:
+            per = input.numel() // w
+            input_split_sizes = [per] * w
+        torch.cuda.synchronize()
+        self.slots[r] = (input, np.concatenate([[0], np.cumsum(input_split_sizes)]))
+        self.barrier.wait()
+        pos = 0
+        for src in range(w):
+            t, offs = self.slots[src]
+            chunk = t[int(offs[r]):int(offs[r + 1])]
+            output[pos:pos + chunk.numel()].copy_(chunk)
+            pos += chunk.numel()
+        torch.cuda.synchronize()
+        self.barrier.wait()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("paired", [False, True])
+def test_sharded_on_gpu_with_virtual_ranks(oracle, world, paired):
+    from fastq_dupaway_amd import Engine, Reads
+    from fastq_dupaway_amd.sharded import HipOps
+    n_per, steps, LL = 20000, 2, 150
+    S = 2 if paired else 1
+    dev = torch.device("cuda", 0)
+    bases = [[[torch.empty(n_per * LL + 16, dtype=torch.uint8, device=dev) for _ in range(S)]
+              for _ in range(world)] for _ in range(steps)]
+    gen = Engine(segments=S)
+    for st in range(steps):
+        for r in range(world):
+            for m in range(S):
+                gen.synth_reads(5, (st * world + r) * n_per, n_per, LL, 300, m, bases[st][r][m], None)
+    gen.sync(); gen.close()
+    tdist = ThreadDist(world)
+    keeps = [[torch.zeros(n_per, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(steps)]
+    errors = []
+
+    def worker(rank):
+        try:
+            tdist.bind(rank)
+            torch.cuda.set_device(0)
+            with Engine(segments=S) as eng:
+                sd = ShardedDedup(HipOps(eng), tdist, dev, n_max=n_per, len0=LL, len1=LL if paired else 0)
+                for st in range(steps):
+                    segs = [Reads(bases[st][rank][m], uniform_len=LL, uniform_stride=LL) for m in range(S)]
+                    sd.dedup(segs, n_per, keeps[st][rank])
+                    eng.sync()
+        except Exception as ex:                       # surface in the main thread
+            errors.append(ex)
+            tdist.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]; [t.join() for t in threads]
+    assert not errors, errors
+    n = steps * world * n_per
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(LL); lens = np.full(n, LL, np.uint32)
+    host = [np.concatenate([bases[st][r][m][: n_per * LL].cpu().numpy() for st in range(steps) for r in range(world)]
+                           + [np.zeros(8, np.uint8)]) for m in range(S)]
+    exp = oracle.dedup_paired(host[0], offs, lens, host[1], offs, lens) if paired else oracle.dedup_single(host[0], offs, lens)
+    got = np.concatenate([keeps[st][r].cpu().numpy() for st in range(steps) for r in range(world)])
+    assert np.array_equal(got, exp)
+    assert 0 < int((exp == 0).sum()) < n
+
+
+@pytest.mark.gpu
+def test_partition_is_stable_and_complete():
+    from fastq_dupaway_amd import Engine, Reads
+    n, LL, parts = 100_003, 150, 8
+    dev = torch.device("cuda", 0)
+    with Engine(segments=1) as e:
+        W = e.key_words(LL); rw = W + 1
+        bases = torch.empty(n * LL + 16, dtype=torch.uint8, device=dev)
+        e.synth_reads(9, 0, n, LL, 200, 0, bases, None)
+        rec = torch.empty(n * rw, dtype=torch.int64, device=dev); out = torch.empty_like(rec)
+        counts = torch.zeros(parts, dtype=torch.int64, device=dev); origin = torch.empty(n, dtype=torch.int32, device=dev)
+        e.encode_uniform([Reads(bases, uniform_len=LL, uniform_stride=LL)], n, rec)
+        e.partition_records(rec, n, W, parts, out, counts, origin)
+        e.sync()
+    r = rec.cpu().numpy().view(np.uint64).reshape(n, rw); o = out.cpu().numpy().view(np.uint64).reshape(n, rw)
+    owner = ((r[:, 0] >> np.uint64(40)) % np.uint64(parts)).astype(np.int64)
+    order = np.argsort(owner, kind="stable")
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(owner, minlength=parts))
+    assert np.array_equal(origin.cpu().numpy(), order.astype(np.int32))
+    assert np.array_equal(o, r[order])

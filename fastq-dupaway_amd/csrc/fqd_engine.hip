@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,7 +42,12 @@ struct fqd_engine {
     uint32_t     flags = 0;
     hipStream_t  stream = nullptr;
     bool         own_stream = false;
+    hipStream_t  aux = nullptr;                      // encoder side of the encode/insert overlap
+    std::vector<hipEvent_t> sync_events;             // untimed events for cross-stream ordering
+    size_t       sync_next = 0;
     int          n_cu = 256;
+    uint64_t     chunk_reads = 8u << 20;             // sub-batch of the overlapped pipeline
+    uint32_t     enc_blocks_per_cu = 4, ins_blocks_per_cu = 4;
 
     DevBuf   table;    uint64_t slots = 0;
     DevBuf   keys;     uint64_t keys_used = 0;       // words
@@ -118,15 +124,25 @@ hipEvent_t take_event(fqd_engine* e)
     return ev;
 }
 struct Bracket {
-    fqd_engine* e; Timed t; bool on;
-    Bracket(fqd_engine* eng, int kind, uint64_t reads) : e(eng), on((eng->flags & FQD_FLAG_PROFILE) != 0)
+    fqd_engine* e; Timed t; bool on; hipStream_t s;
+    Bracket(fqd_engine* eng, int kind, uint64_t reads, hipStream_t on_stream = nullptr)
+        : e(eng), on((eng->flags & FQD_FLAG_PROFILE) != 0), s(on_stream ? on_stream : eng->stream)
     {
         if (!on) return;
         t.a = take_event(e); t.b = take_event(e); t.kind = kind; t.reads = reads;
-        (void)hipEventRecord(t.a, e->stream);
+        (void)hipEventRecord(t.a, s);
     }
-    ~Bracket() { if (on) { (void)hipEventRecord(t.b, e->stream); e->pending.push_back(t); } }
+    ~Bracket() { if (on) { (void)hipEventRecord(t.b, s); e->pending.push_back(t); } }
 };
+hipEvent_t next_sync_event(fqd_engine* e)
+{
+    if (e->sync_next == e->sync_events.size()) {
+        hipEvent_t ev = nullptr;
+        (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        e->sync_events.push_back(ev);
+    }
+    return e->sync_events[e->sync_next++];
+}
 void drain_profile(fqd_engine* e)
 {
     for (const Timed& t : e->pending) {
@@ -250,28 +266,31 @@ StagedChoice choose_staged(const fqd_engine* e, const fqd_reads* seg, bool unifo
 }
 
 int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_reads* seg, uint64_t n,
-                  uint64_t first_idx, const KeyStore& ks, uint64_t* hash_out)
+                  uint64_t first_idx, const KeyStore& ks, uint64_t* hash_out,
+                  hipStream_t stream = nullptr, uint32_t blocks_per_cu = 8)
 {
-    Bracket br(e, K_ENCODE, n);
+    if (!stream) stream = e->stream;
+    Bracket br(e, K_ENCODE, n, stream);
     const StagedChoice c = choose_staged(e, seg, uniform, ks);
     uint64_t* err = e->d_state;
     if (c.staged) {
-        const uint32_t grid = uint32_t(std::min<uint64_t>((n + c.R - 1) / c.R, uint64_t(e->n_cu) * 8u));
+        const uint32_t grid = uint32_t(std::min<uint64_t>((n + c.R - 1) / c.R, uint64_t(e->n_cu) * blocks_per_cu));
         const size_t lds = size_t(c.tile0) + c.tile1;
         const uint32_t rw = ks.W0 + ks.lead;
         const uint32_t magic = rw > 1 ? uint32_t(((1ull << 32) + rw - 1) / rw) : 0xFFFFFFFFu;   // x/rw for x < 2^16
         auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, e->stream,
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream,
                                sv[0], sv[1], n, first_idx, ks, hash_out, err, c.tile0, magic);
         };
         if (e->S == 1) { if (c.lds_out) launch(encode_staged_kernel<1, true>); else launch(encode_staged_kernel<1, false>); }
         else           { if (c.lds_out) launch(encode_staged_kernel<2, true>); else launch(encode_staged_kernel<2, false>); }
     } else {
+        const uint32_t grid = uint32_t(std::min<uint64_t>(grid_for(e, n), uint64_t(e->n_cu) * blocks_per_cu));
         if (e->S == 1)
-            hipLaunchKernelGGL(encode_general_kernel<1>, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
+            hipLaunchKernelGGL(encode_general_kernel<1>, dim3(grid), dim3(kBlock), 0, stream,
                                sv[0], sv[1], n, first_idx, ks, hash_out, err);
         else
-            hipLaunchKernelGGL(encode_general_kernel<2>, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
+            hipLaunchKernelGGL(encode_general_kernel<2>, dim3(grid), dim3(kBlock), 0, stream,
                                sv[0], sv[1], n, first_idx, ks, hash_out, err);
     }
     HIP_TRY(e, hipGetLastError());
@@ -279,14 +298,15 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
 }
 
 int launch_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes, uint32_t hash_stride,
-                  uint64_t n, uint64_t first_idx, uint8_t* keep)
+                  uint64_t n, uint64_t first_idx, uint8_t* keep, bool preset_keep = true, uint32_t blocks_per_cu = 8)
 {
-    {
+    if (preset_keep) {
         Bracket br(e, K_OTHER, 0);
         HIP_TRY(e, hipMemsetAsync(keep, 1, n, e->stream));
     }
     Bracket br(e, K_INSERT, n);
-    hipLaunchKernelGGL(insert_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
+    const uint32_t grid = uint32_t(std::min<uint64_t>(grid_for(e, n), uint64_t(e->n_cu) * blocks_per_cu));
+    hipLaunchKernelGGL(insert_kernel, dim3(grid), dim3(kBlock), 0, e->stream,
                        e->table.as<uint64_t>(), e->slots - 1, ks, hashes, hash_stride, n, uint32_t(first_idx), keep,
                        reinterpret_cast<unsigned long long*>(e->d_state + 1));
     HIP_TRY(e, hipGetLastError());
@@ -362,6 +382,10 @@ int fqd_engine_create(const fqd_config* cfg, fqd_engine** out)
         if ((err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", err);
         e->own_stream = true;
     }
+    if ((err = hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate(aux)", err);
+    if (const char* v = std::getenv("FQD_CHUNK_READS")) { const long long x = std::atoll(v); e->chunk_reads = x > 0 ? uint64_t(x) : ~0ull; }
+    if (const char* v = std::getenv("FQD_ENC_BLOCKS_PER_CU")) e->enc_blocks_per_cu = uint32_t(std::max(1, std::atoi(v)));
+    if (const char* v = std::getenv("FQD_INS_BLOCKS_PER_CU")) e->ins_blocks_per_cu = uint32_t(std::max(1, std::atoi(v)));
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->d_state), 4 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc(state)", err);
     if ((err = hipHostMalloc(reinterpret_cast<void**>(&e->h_state), 4 * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc(state)", err);
@@ -383,7 +407,10 @@ int fqd_engine_destroy(fqd_engine* e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     drain_profile(e);
+    if (e->aux) (void)hipStreamSynchronize(e->aux);
     for (hipEvent_t ev : e->free_events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     release(e->table); release(e->keys); release(e->koff); release(e->hashes);
     release(e->scan_scratch); release(e->part_scratch); release(e->st_keep);
     for (int s = 0; s < 2; ++s) { release(e->st_bases[s]); release(e->st_off[s]); release(e->st_len[s]); }
@@ -502,8 +529,38 @@ int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint
     }
 
     KeyStore ks{e->keys.as<uint64_t>(), e->ragged ? e->koff.as<uint64_t>() : nullptr, e->W0, e->W0, 0};
-    if ((rc = launch_encode(e, sv, uniform, seg, n, first, ks, e->hashes.as<uint64_t>()))) return rc;
-    if ((rc = launch_insert(e, ks, e->hashes.as<uint64_t>(), 1, n, first, d_keep))) return rc;
+    if (n >= 2 * e->chunk_reads && e->aux) {
+        // Overlap: the encoder streams HBM, the insert is bound by memory-side atomics, so the
+        // two run side by side on two streams, sub-batch k+1 being encoded while k is inserted.
+        // Each kernel is launched on half of the wave slots so the other one can be resident.
+        {
+            Bracket br(e, K_OTHER, 0);
+            HIP_TRY(e, hipMemsetAsync(d_keep, 1, n, e->stream));
+        }
+        e->sync_next = 0;
+        hipEvent_t start = next_sync_event(e);
+        HIP_TRY(e, hipEventRecord(start, e->stream));
+        HIP_TRY(e, hipStreamWaitEvent(e->aux, start, 0));
+        for (uint64_t a = 0; a < n; a += e->chunk_reads) {
+            const uint64_t c = std::min<uint64_t>(e->chunk_reads, n - a);
+            SegView sub[2] = {sv[0], sv[1]};
+            fqd_reads subseg[2] = {seg[0], seg[1]};
+            for (int s2 = 0; s2 < e->S; ++s2) {
+                if (sub[s2].offsets) { sub[s2].offsets += a; sub[s2].lengths += a; }
+                else sub[s2].bases += a * uint64_t(sub[s2].ustride);
+            }
+            if ((rc = launch_encode(e, sub, uniform, subseg, c, first + a, ks, e->hashes.as<uint64_t>() + a,
+                                    e->aux, e->enc_blocks_per_cu))) return rc;
+            hipEvent_t done = next_sync_event(e);
+            HIP_TRY(e, hipEventRecord(done, e->aux));
+            HIP_TRY(e, hipStreamWaitEvent(e->stream, done, 0));
+            if ((rc = launch_insert(e, ks, e->hashes.as<uint64_t>() + a, 1, c, first + a, d_keep + a, false,
+                                    e->ins_blocks_per_cu))) return rc;
+        }
+    } else {
+        if ((rc = launch_encode(e, sv, uniform, seg, n, first, ks, e->hashes.as<uint64_t>()))) return rc;
+        if ((rc = launch_insert(e, ks, e->hashes.as<uint64_t>(), 1, n, first, d_keep))) return rc;
+    }
     e->n_records += n;
     e->keys_used += new_words;
 

@@ -32,6 +32,10 @@ class ReadsDesc(C.Structure):
                 ("uniform_len", C.c_uint32), ("uniform_stride", C.c_uint32)]
 
 
+class TagsDesc(C.Structure):
+    _fields_ = [("bytes", C.c_void_p), ("offsets", C.c_void_p), ("lengths", C.c_void_p), ("n", C.c_uint64)]
+
+
 class Stats(C.Structure):
     _fields_ = [("records", C.c_uint64), ("duplicates", C.c_uint64), ("table_slots", C.c_uint64), ("key_bytes", C.c_uint64)]
 
@@ -91,6 +95,8 @@ def load_library():
     L.fqd_encode_uniform.argtypes = [vp, C.POINTER(ReadsDesc), u64, vp]
     L.fqd_partition_records.argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
     L.fqd_insert_records.argtypes = [vp, vp, u64, u32, u32, vp]
+    L.fqd_sort_tags.argtypes = [vp, C.POINTER(TagsDesc), vp]
+    L.fqd_match_sorted_tags.argtypes = [vp, C.POINTER(TagsDesc), vp, C.POINTER(TagsDesc), vp, vp]
     L.fqd_scatter_flags.argtypes = [vp, vp, vp, u64, vp]
     L.fqd_synth_reads.argtypes = [vp, u64, u64, u64, u32, u32, i32, vp, vp]
     for name in declared_symbols():

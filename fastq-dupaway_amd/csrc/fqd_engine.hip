@@ -338,6 +338,19 @@ bool seg_is_uniform(const fqd_reads& r) { return r.offsets == nullptr && r.lengt
 
 } // namespace
 
+// ---- what fqd_join.hip needs from an engine (same library, not exported) -----------------
+#define FQD_HIDDEN __attribute__((visibility("hidden")))
+FQD_HIDDEN hipStream_t fqd_internal_stream(fqd_engine* e) { return e->stream; }
+FQD_HIDDEN int fqd_internal_device(fqd_engine* e) { return e->device; }
+FQD_HIDDEN int fqd_internal_fail(fqd_engine* e, int code, const char* msg) { return e->fail(code, msg); }
+FQD_HIDDEN int fqd_internal_scratch(fqd_engine* e, int which, size_t bytes, void** out)
+{
+    DevBuf& b = which == 0 ? e->scan_scratch : e->part_scratch;
+    const int rc = reserve(e, b, bytes);
+    *out = b.p;
+    return rc;
+}
+
 // =============================== C ABI ==========================================
 extern "C" {
 

@@ -147,6 +147,19 @@ class Engine:
     def insert_records(self, records, n: int, len0: int, len1: int, keep):
         self._check(self._L.fqd_insert_records(self._h, _addr(records), n, len0, len1, _addr(keep)))
 
+    # -- --unordered ID join ---------------------------------------------------------------
+    @staticmethod
+    def _tags(bytes_, offsets, lengths, n):
+        return _lib.TagsDesc(bytes=_addr(bytes_), offsets=_addr(offsets), lengths=_addr(lengths), n=n)
+
+    def sort_tags(self, bytes_, offsets, lengths, n: int, perm):
+        t = self._tags(bytes_, offsets, lengths, n)
+        self._check(self._L.fqd_sort_tags(self._h, C.byref(t), _addr(perm)))
+
+    def match_sorted_tags(self, a, perm_a, b, perm_b, match):
+        ta, tb = self._tags(*a), self._tags(*b)
+        self._check(self._L.fqd_match_sorted_tags(self._h, C.byref(ta), _addr(perm_a), C.byref(tb), _addr(perm_b), _addr(match)))
+
     def scatter_flags(self, flags, origin, n: int, keep_out):
         self._check(self._L.fqd_scatter_flags(self._h, _addr(flags), _addr(origin), n, _addr(keep_out)))
 

@@ -347,6 +347,61 @@ void HashDupRemover::filterPE(const std::string& infile1, const std::string& inf
     else           run_ordered(2, in, out);
 }
 
+namespace {
+
+// Uploads a file's tags once (bytes back to back + offset/length per record) and runs the
+// device primitives of the join.
+class GpuTagJoin : public TagJoinDevice {
+public:
+    GpuTagJoin(fqd_engine* e, hipStream_t s) : e_(e), s_(s) {}
+    void sort(const LoadedFile& f, std::vector<uint32_t>& perm) override
+    {
+        Uploaded& u = upload(f);
+        Device<uint32_t> d_perm; d_perm.reserve(u.n);
+        fqd_tags t{reinterpret_cast<const uint8_t*>(u.bytes.p), u.off.p, u.len.p, u.n};
+        if (fqd_sort_tags(e_, &t, d_perm.p) != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(e_));
+        perm.resize(u.n);
+        HIP_OK(hipMemcpyAsync(perm.data(), d_perm.p, u.n * sizeof(uint32_t), hipMemcpyDeviceToHost, s_));
+        HIP_OK(hipStreamSynchronize(s_));
+    }
+    void match(const LoadedFile& a, const std::vector<uint32_t>& perm_a,
+               const LoadedFile& b, const std::vector<uint32_t>& perm_b, std::vector<uint32_t>& out) override
+    {
+        Uploaded& ua = upload(a); Uploaded& ub = upload(b);
+        Device<uint32_t> pa, pb, m; pa.reserve(ua.n); pb.reserve(ub.n); m.reserve(ua.n);
+        HIP_OK(hipMemcpyAsync(pa.p, perm_a.data(), ua.n * sizeof(uint32_t), hipMemcpyHostToDevice, s_));
+        HIP_OK(hipMemcpyAsync(pb.p, perm_b.data(), ub.n * sizeof(uint32_t), hipMemcpyHostToDevice, s_));
+        fqd_tags ta{reinterpret_cast<const uint8_t*>(ua.bytes.p), ua.off.p, ua.len.p, ua.n};
+        fqd_tags tb{reinterpret_cast<const uint8_t*>(ub.bytes.p), ub.off.p, ub.len.p, ub.n};
+        if (fqd_match_sorted_tags(e_, &ta, pa.p, &tb, pb.p, m.p) != FQD_OK)
+            throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(e_));
+        out.resize(ua.n);
+        HIP_OK(hipMemcpyAsync(out.data(), m.p, ua.n * sizeof(uint32_t), hipMemcpyDeviceToHost, s_));
+        HIP_OK(hipStreamSynchronize(s_));
+    }
+private:
+    struct Uploaded { const LoadedFile* f = nullptr; uint64_t n = 0; Device<char> bytes; Device<uint64_t> off; Device<uint32_t> len; };
+    Uploaded& upload(const LoadedFile& f)
+    {
+        for (Uploaded& u : up_) if (u.f == &f) return u;
+        Uploaded& u = up_[used_++ & 1]; u.f = &f; u.n = f.recs.size();
+        std::vector<uint64_t> off(u.n); std::vector<uint32_t> len(u.n);
+        uint64_t total = 0;
+        for (uint64_t k = 0; k < u.n; ++k) { off[k] = total; len[k] = f.recs[k].tag_len; total += f.recs[k].tag_len; }
+        std::vector<char> bytes(total + 16);
+        for (uint64_t k = 0; k < u.n; ++k) std::memcpy(bytes.data() + off[k], f.recs[k].tag(), len[k]);
+        u.bytes.reserve(total + 16); u.off.reserve(u.n); u.len.reserve(u.n);
+        HIP_OK(hipMemcpyAsync(u.bytes.p, bytes.data(), total, hipMemcpyHostToDevice, s_));
+        HIP_OK(hipMemcpyAsync(u.off.p, off.data(), u.n * sizeof(uint64_t), hipMemcpyHostToDevice, s_));
+        HIP_OK(hipMemcpyAsync(u.len.p, len.data(), u.n * sizeof(uint32_t), hipMemcpyHostToDevice, s_));
+        HIP_OK(hipStreamSynchronize(s_));
+        return u;
+    }
+    fqd_engine* e_; hipStream_t s_; Uploaded up_[2]; unsigned used_ = 0;
+};
+
+} // namespace
+
 // ---------------------------------------------------------------------------
 // --unordered (hash_dup_remover.hpp:150-192,257-347): join the two files on the ID tag,
 // dedup the joined pairs in tag order, write survivors in tag order.
@@ -364,16 +419,20 @@ void HashDupRemover::run_unordered(const std::string* in, const std::string* out
     // 2. outputs are opened after the sort phase (hpp:265-266)
     OutputFile sink0(out[0]), sink1(out[1]);
 
-    // 3. join on tags
-    std::vector<std::pair<uint64_t, uint64_t>> pairs;
-    uint64_t unmatched = 0;
-    join_by_tag(file[0], file[1], tuning_.reference_tail_rule, pairs, unmatched);
-
-    // 4. pair-dedup in tag order on the GPU
     hipStream_t stream = nullptr;
     HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
     EngineHandle eng(2, tuning_.device, stream);
+
+    // 3. join on tags: sort + match on the GPU (fqd_sort_tags / fqd_match_sorted_tags)
+    std::vector<std::pair<uint64_t, uint64_t>> pairs;
+    uint64_t unmatched = 0;
+    {
+        GpuTagJoin dev(eng.e, stream);
+        join_by_tag(file[0], file[1], tuning_.reference_tail_rule, dev, pairs, unmatched);
+    }
+
+    // 4. pair-dedup in tag order on the GPU
     std::vector<uint8_t> keep(pairs.size());
     uint64_t written_below = pairs.size();
     bool bad = false; uint8_t bad_byte = 0;

@@ -37,48 +37,61 @@ void load_whole_file(const std::string& name, Format f, size_t block_bytes, Load
     }
 }
 
-static std::vector<uint64_t> order_by_tag(const LoadedFile& f)
-{
-    std::vector<uint64_t> idx(f.recs.size());
-    std::iota(idx.begin(), idx.end(), 0);
-    // the reference's std::sort over views with operator< = tag compare (external_sort.hpp:105)
-    std::stable_sort(idx.begin(), idx.end(), [&](uint64_t x, uint64_t y) {
-        const FileRecord& a = f.recs[x]; const FileRecord& b = f.recs[y];
-        return compare_tags(a.tag(), a.tag_len, b.tag(), b.tag_len) < 0;
-    });
-    return idx;
-}
-
-void join_by_tag(const LoadedFile& a, const LoadedFile& b, bool tail_rule,
+void join_by_tag(const LoadedFile& a, const LoadedFile& b, bool tail_rule, TagJoinDevice& dev,
                  std::vector<std::pair<uint64_t, uint64_t>>& pairs, uint64_t& unmatched)
 {
     pairs.clear(); unmatched = 0;
-    const std::vector<uint64_t> oa = order_by_tag(a), ob = order_by_tag(b);
-    const size_t n = oa.size(), m = ob.size();
+    const size_t n = a.recs.size(), m = b.recs.size();
     if (n == 0 || m == 0) return;
-    auto cmp = [&](size_t i, size_t j) {
-        const FileRecord& l = a.recs[oa[i]]; const FileRecord& r = b.recs[ob[j]];
-        return compare_tags(l.tag(), l.tag_len, r.tag(), r.tag_len);
-    };
-    size_t i = 0, j = 0;
-    if (tail_rule) {
-        while (i + 1 < n && j + 1 < m) {                     // hpp:281: neither side on its last record
-            const int c = cmp(i, j);
-            if (c < 0)      { ++i; ++unmatched; }            // hpp:284-287
-            else if (c > 0) { ++j; ++unmatched; }            // hpp:288-290
-            else            { pairs.emplace_back(oa[i], ob[j]); ++i; ++j; }
-        }
-        if (cmp(i, j) == 0) pairs.emplace_back(oa[i], ob[j]); // hpp:317-340 "check 2 last records"
-        else ++unmatched;
-    } else {
-        while (i < n && j < m) {
-            const int c = cmp(i, j);
-            if (c < 0)      { ++i; ++unmatched; }
-            else if (c > 0) { ++j; ++unmatched; }
-            else            { pairs.emplace_back(oa[i], ob[j]); ++i; ++j; }
-        }
-        unmatched += (n - i) + (m - j);
+    // the sort phase (hpp:161-173) and the equality tests of the merge (hpp:283-309) run on the GPU
+    std::vector<uint32_t> oa, ob, match;
+    dev.sort(a, oa);
+    dev.sort(b, ob);
+    dev.match(a, oa, b, ob, match);
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    auto tag_a = [&](size_t k) -> const FileRecord& { return a.recs[oa[k]]; };
+    auto tag_b = [&](size_t k) -> const FileRecord& { return b.recs[ob[k]]; };
+    auto cmp_ab = [&](size_t i, size_t j) { return compare_tags(tag_a(i).tag(), tag_a(i).tag_len, tag_b(j).tag(), tag_b(j).tag_len); };
+
+    if (!tail_rule) {                                        // intended semantics: full inner join
+        for (size_t k = 0; k < n; ++k)
+            if (match[k] != kNone) pairs.emplace_back(oa[k], ob[match[k]]);
+        unmatched = n + m - 2 * pairs.size();
+        return;
     }
+    // The reference's loop (hpp:279-340) advances only while NEITHER cursor is on its file's last
+    // record, then compares once more.  Everything it finds before that point is exactly the set
+    // of matches below both second-to-last tags; what remains is one comparison at the exit state.
+    if (n == 1 || m == 1) {
+        if (cmp_ab(0, 0) == 0) pairs.emplace_back(oa[0], ob[0]); else unmatched = 1;
+        return;
+    }
+    size_t i_exit, j_exit;
+    const int c = cmp_ab(n - 2, m - 2);
+    if (c <= 0) {
+        // a's cursor reaches its last record first (or both together): b stands on its first tag > a[n-2]
+        i_exit = n - 1;
+        if (c == 0) j_exit = m - 1;
+        else if (match[n - 2] != kNone) j_exit = size_t(match[n - 2]) + 1;
+        else {
+            size_t lo = 0, hi = m;                           // first b tag greater than a[n-2]
+            while (lo < hi) { const size_t mid = (lo + hi) / 2; if (cmp_ab(n - 2, mid) >= 0) lo = mid + 1; else hi = mid; }
+            j_exit = lo;
+        }
+        for (size_t k = 0; k + 1 < n; ++k)
+            if (match[k] != kNone) pairs.emplace_back(oa[k], ob[match[k]]);
+    } else {
+        j_exit = m - 1;
+        size_t lo = 0, hi = n;                               // first a tag greater than b[m-2]
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (cmp_ab(mid, m - 2) <= 0) lo = mid + 1; else hi = mid; }
+        i_exit = lo;
+        for (size_t k = 0; k < i_exit; ++k)
+            if (match[k] != kNone) pairs.emplace_back(oa[k], ob[match[k]]);
+    }
+    const size_t before = pairs.size();
+    const bool last_equal = cmp_ab(i_exit, j_exit) == 0;     // hpp:317-340 "check 2 last records"
+    if (last_equal) pairs.emplace_back(oa[i_exit], ob[j_exit]);
+    unmatched = i_exit + j_exit - 2 * before + (last_equal ? 0 : 1);
 }
 
 } // namespace fqdhost

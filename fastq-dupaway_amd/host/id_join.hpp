@@ -29,11 +29,23 @@ struct LoadedFile {
 // throws "Not enough memory to read a single object!" like the reference's sorter does.
 void load_whole_file(const std::string& name, Format f, size_t block_bytes, LoadedFile& out);
 
+// The two device primitives the join is built on (include/fqdupaway.h: fqd_sort_tags,
+// fqd_match_sorted_tags), bound to an engine by the caller.
+struct fqd_engine_fwd;
+struct TagJoinDevice {
+    // perm[k] = record index of the k-th smallest tag
+    virtual void sort(const LoadedFile& f, std::vector<uint32_t>& perm) = 0;
+    // match[k] = position in perm_b of the record whose tag equals a's perm_a[k], or 0xFFFFFFFF
+    virtual void match(const LoadedFile& a, const std::vector<uint32_t>& perm_a,
+                       const LoadedFile& b, const std::vector<uint32_t>& perm_b, std::vector<uint32_t>& match) = 0;
+    virtual ~TagJoinDevice() = default;
+};
+
 // Joins on the ID tag.  `pairs` receives (index in a, index in b) in tag order; unmatched
 // counts skipped records the way the reference does.  tail_rule: stop as the reference's
 // merge loop does, as soon as either side is on its LAST record, then compare once more
 // (hash_dup_remover.hpp:279-340).
-void join_by_tag(const LoadedFile& a, const LoadedFile& b, bool tail_rule,
+void join_by_tag(const LoadedFile& a, const LoadedFile& b, bool tail_rule, TagJoinDevice& dev,
                  std::vector<std::pair<uint64_t, uint64_t>>& pairs, uint64_t& unmatched);
 
 } // namespace fqdhost

@@ -150,6 +150,28 @@ int  fqd_partition_records(fqd_engine* e, const uint64_t* records, uint64_t n, u
 int  fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n,
                         uint32_t len0, uint32_t len1, uint8_t* keep);
 
+/* ---- the `--unordered` read-ID join (hash_dup_remover.hpp:150-192,257-347) ------------
+ * ID tags of one file (FastqViewWithId::read_new, fastqview.cpp:190-204): the tag bytes of
+ * all records back to back plus per-record offset and length.  Device pointers; n < 2^32-1. */
+typedef struct fqd_tags {
+    const uint8_t*  bytes;
+    const uint64_t* offsets;
+    const uint32_t* lengths;
+    uint64_t        n;
+} fqd_tags;
+
+/* perm[k] (device, n uint32) = index of the record with the k-th smallest tag, in the order of
+ * FastqViewWithId::cmp (fastqview.cpp:168-178): bytewise over the shorter length, shorter
+ * first on a tie; equal tags keep their input order.  Replaces ExternalSorter<T>::sort
+ * (external_sort.hpp:66-71,88-117) by an LSD radix sort in HBM. */
+int  fqd_sort_tags(fqd_engine* e, const fqd_tags* t, uint32_t* perm);
+
+/* The equality branch of the merge-join (hpp:283-309) for two tag-sorted files: match[k]
+ * (device, a->n uint32) = position in perm_b of the record of b whose tag equals the tag of
+ * a's record perm_a[k], or 0xFFFFFFFF when b has none. */
+int  fqd_match_sorted_tags(fqd_engine* e, const fqd_tags* a, const uint32_t* perm_a,
+                           const fqd_tags* b, const uint32_t* perm_b, uint32_t* match);
+
 /* keep_out[origin[k]] = flags[k] for k < n: puts the flags that came back from the
  * owners (in partition order) into input order.  All device pointers. */
 int  fqd_scatter_flags(fqd_engine* e, const uint8_t* flags, const uint32_t* origin, uint64_t n, uint8_t* keep_out);

@@ -151,14 +151,16 @@ def main():
         value = world * n * a.steps / dt / 1e6
         bytes_per_unit = S * L                       # sequence bytes read once from HBM
         kernels = {}
-        for k in ("encode", "insert"):
+        names = {"encode": "fqd::encode_staged_kernel", "insert": "fqd::insert_kernel",
+                 "partition": "fqd::bulk_hist/scatter passes (4 kernels, timed as one group)", "dedup": "fqd::bucket_dedup_kernel"}
+        for k in ("encode", "insert", "partition", "dedup"):
             if prof[f"{k}_launches"]:
                 avg_ms = prof[f"{k}_ms"] / prof[f"{k}_launches"]
                 per_launch = prof[f"{k}_reads"] / prof[f"{k}_launches"]
                 kernels[k] = {"avg_ms": round(avg_ms, 4), "launches": prof[f"{k}_launches"],
                               "GBps": round(per_launch * bytes_per_unit / (avg_ms * 1e-3) / 1e9, 1)}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
-        roofline = {"bound": "hbm", "kernel": f"fqd::{dom}_kernel", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": names[dom], "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes_per_unit": bytes_per_unit, "kernels": kernels,
                     "whole_step_frac": round(value * 1e6 / world * bytes_per_unit / 1e9 / HBM_PEAK_GBS, 4)}

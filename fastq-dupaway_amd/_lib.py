@@ -43,6 +43,8 @@ class Stats(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("encode_ms", C.c_double), ("encode_launches", C.c_uint64), ("encode_reads", C.c_uint64),
                 ("insert_ms", C.c_double), ("insert_launches", C.c_uint64), ("insert_reads", C.c_uint64),
+                ("partition_ms", C.c_double), ("partition_launches", C.c_uint64), ("partition_reads", C.c_uint64),
+                ("dedup_ms", C.c_double), ("dedup_launches", C.c_uint64), ("dedup_reads", C.c_uint64),
                 ("other_ms", C.c_double), ("other_launches", C.c_uint64)]
 
 

@@ -30,7 +30,7 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-enum Kind { K_ENCODE = 0, K_INSERT = 1, K_OTHER = 2 };
+enum Kind { K_ENCODE = 0, K_INSERT = 1, K_OTHER = 2, K_PARTITION = 3, K_DEDUP = 4 };
 
 struct Timed { hipEvent_t a, b; int kind; uint64_t reads; };
 
@@ -50,6 +50,11 @@ struct fqd_engine {
     uint32_t     enc_blocks_per_cu = 4, ins_blocks_per_cu = 4;
 
     DevBuf   table;    uint64_t slots = 0;
+    uint32_t seg_bits = 0;                           // log2(slots per probing segment)
+    bool     table_clear = false;                    // every slot is EMPTY right now
+    bool     table_stale = false;                    // contents are garbage: clear (or rebuild) before use
+    DevBuf   bulk_recs, bulk_meta;                   // scratch of the bulk (partitioned) insert
+    uint64_t bulk_min = 1u << 20;                    // batches at least this large take the bulk path
     DevBuf   keys;     uint64_t keys_used = 0;       // words
     DevBuf   koff;                                   // ragged only: word offset per record
     bool     ragged = false, have_shape = false;
@@ -150,6 +155,8 @@ void drain_profile(fqd_engine* e)
         if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
             if (t.kind == K_ENCODE)      { e->prof.encode_ms += ms; e->prof.encode_launches++; e->prof.encode_reads += t.reads; }
             else if (t.kind == K_INSERT) { e->prof.insert_ms += ms; e->prof.insert_launches++; e->prof.insert_reads += t.reads; }
+            else if (t.kind == K_PARTITION) { e->prof.partition_ms += ms; e->prof.partition_launches++; e->prof.partition_reads += t.reads; }
+            else if (t.kind == K_DEDUP) { e->prof.dedup_ms += ms; e->prof.dedup_launches++; e->prof.dedup_reads += t.reads; }
             else                         { e->prof.other_ms += ms;  e->prof.other_launches++; }
         }
         e->free_events.push_back(t.a); e->free_events.push_back(t.b);
@@ -193,6 +200,17 @@ int scan_exclusive(fqd_engine* e, uint64_t* data, uint64_t n, uint64_t add, cons
     return FQD_OK;
 }
 
+// Probing segments: 4096..16384 slots so that (slots / segment) <= 65536 buckets, or the whole
+// table when it is smaller than one segment.
+uint32_t seg_bits_for(uint64_t slots)
+{
+    uint32_t t = 0; while ((1ull << t) < slots) ++t;
+    if (t <= 12) return t;
+    uint32_t want = 13u;                                 // 64 KiB of LDS per segment: best of the 12/13/14 sweep
+    if (const char* v = std::getenv("FQD_SEG_BITS")) want = uint32_t(std::min(14, std::max(12, std::atoi(v))));
+    return std::min<uint32_t>(14u, std::max<uint32_t>(want, t >= 16 ? t - 16 : 12u));
+}
+
 // Keeps the table at <= 50 % load.  `exact`: size for a known total (capacity hint);
 // otherwise grow geometrically so rehashes stay rare.
 int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
@@ -201,18 +219,23 @@ int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
     const uint64_t want = std::max<uint64_t>(pow2_at_least((exact ? 2 : 4) * records_after), 1ull << 16);
     void* nt = nullptr;
     HIP_TRY(e, hipMalloc(&nt, want * sizeof(uint64_t)));
-    HIP_TRY(e, hipMemsetAsync(nt, 0xFF, want * sizeof(uint64_t), e->stream));
+    const uint32_t new_seg_bits = seg_bits_for(want);
     if (e->slots && e->n_records) {
         Bracket br(e, K_OTHER, 0);
+        HIP_TRY(e, hipMemsetAsync(nt, 0xFF, want * sizeof(uint64_t), e->stream));
         KeyStore ks{e->keys.as<uint64_t>(), e->ragged ? e->koff.as<uint64_t>() : nullptr, e->W0, e->W0, 0};
         hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(e, e->slots)), dim3(kBlock), 0, e->stream,
-                           e->table.as<uint64_t>(), e->slots, static_cast<uint64_t*>(nt), want - 1, ks, e->L0, e->L1);
+                           e->table.as<uint64_t>(), e->slots, static_cast<uint64_t*>(nt), want - 1,
+                           (1ull << new_seg_bits) - 1, ks, e->L0, e->L1);
+        e->table_clear = false; e->table_stale = false;
+    } else {
+        e->table_clear = false; e->table_stale = true;       // cleared lazily by whoever uses it first
     }
     if (e->table.p) {
         HIP_TRY(e, hipStreamSynchronize(e->stream));
         HIP_TRY(e, hipFree(e->table.p));
     }
-    e->table.p = nt; e->table.cap = want * sizeof(uint64_t); e->slots = want;
+    e->table.p = nt; e->table.cap = want * sizeof(uint64_t); e->slots = want; e->seg_bits = new_seg_bits;
     return FQD_OK;
 }
 
@@ -300,6 +323,12 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
 int launch_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes, uint32_t hash_stride,
                   uint64_t n, uint64_t first_idx, uint8_t* keep, bool preset_keep = true, uint32_t blocks_per_cu = 8)
 {
+    if (e->table_stale) {
+        Bracket br(e, K_OTHER, 0);
+        HIP_TRY(e, hipMemsetAsync(e->table.p, 0xFF, e->slots * sizeof(uint64_t), e->stream));
+        e->table_stale = false;
+    }
+    e->table_clear = false;
     if (preset_keep) {
         Bracket br(e, K_OTHER, 0);
         HIP_TRY(e, hipMemsetAsync(keep, 1, n, e->stream));
@@ -307,9 +336,90 @@ int launch_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes, uin
     Bracket br(e, K_INSERT, n);
     const uint32_t grid = uint32_t(std::min<uint64_t>(grid_for(e, n), uint64_t(e->n_cu) * blocks_per_cu));
     hipLaunchKernelGGL(insert_kernel, dim3(grid), dim3(kBlock), 0, e->stream,
-                       e->table.as<uint64_t>(), e->slots - 1, ks, hashes, hash_stride, n, uint32_t(first_idx), keep,
+                       e->table.as<uint64_t>(), e->slots - 1, (1ull << e->seg_bits) - 1, ks, hashes, hash_stride, n, uint32_t(first_idx), keep,
                        reinterpret_cast<unsigned long long*>(e->d_state + 1));
     HIP_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+// Bulk insert (bulk_* kernels): partition the batch by table segment, then one workgroup per
+// segment dedups in LDS.  Worth it when the batch is large against the table: every segment
+// is rewritten once (and, unless the table is known empty, read once).
+bool bulk_applies(const fqd_engine* e, uint64_t n)
+{
+    if (n < e->bulk_min || e->slots < (1ull << 13)) return false;
+    const bool empty = e->n_records == 0;
+    return empty || n * 8 >= e->slots;
+}
+
+int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes, uint32_t hash_stride,
+                       uint64_t n, uint64_t first_idx, uint8_t* keep)
+{
+    uint32_t t = 0; while ((1ull << t) < e->slots) ++t;
+    const uint32_t nb_bits = t - e->seg_bits;                // <= 16 by construction of seg_bits (t <= 30)
+    if (nb_bits > 16 || nb_bits == 0) return launch_insert(e, ks, hashes, hash_stride, n, first_idx, keep);
+    BulkGeom g;
+    g.slot_mask = e->slots - 1; g.seg_bits = e->seg_bits;
+    g.bits1 = nb_bits <= 8 ? nb_bits : (nb_bits + 1) / 2;
+    g.bits2 = nb_bits - g.bits1;
+    const uint32_t nd1 = 1u << g.bits1, n_buckets = 1u << nb_bits;
+    int rc;
+    const size_t rec_bytes = ((n * sizeof(ulonglong2)) + 255) & ~size_t(255);
+    if ((rc = reserve(e, e->bulk_recs, rec_bytes * (g.bits2 ? 2 : 1)))) return rc;
+    // meta: hist1[256] start1[257] cursor1[256] tile_start1[257] | hist2[nb] start2[nb+1] cursor2[nb]
+    const size_t meta_words = 1100 + 3 * size_t(n_buckets) + 8;
+    if ((rc = reserve(e, e->bulk_meta, meta_words * sizeof(uint32_t)))) return rc;
+    uint32_t* m = e->bulk_meta.as<uint32_t>();
+    uint32_t* hist1 = m; uint32_t* start1 = m + 256; uint32_t* cursor1 = m + 520; uint32_t* tile_start1 = m + 780;
+    uint32_t* hist2 = m + 1100; uint32_t* start2 = hist2 + n_buckets; uint32_t* cursor2 = start2 + n_buckets + 4;
+    ulonglong2* recA = e->bulk_recs.as<ulonglong2>();
+    ulonglong2* recB = reinterpret_cast<ulonglong2*>(e->bulk_recs.as<char>() + rec_bytes);
+    const bool fresh = e->n_records == 0 || e->table_clear || e->table_stale;
+    {
+        Bracket br(e, K_OTHER, 0);
+        HIP_TRY(e, hipMemsetAsync(keep, 1, n, e->stream));
+        HIP_TRY(e, hipMemsetAsync(m, 0, meta_words * sizeof(uint32_t), e->stream));
+    }
+    const ulonglong2* final_recs = recA; const uint32_t* bstart = start1;
+    {
+    Bracket part_br(e, K_PARTITION, n);
+    const uint32_t part_grid = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile, uint64_t(e->n_cu) * 2u));
+    hipLaunchKernelGGL(bulk_hist1_kernel, dim3(part_grid), dim3(kPartThreads), 0, e->stream, hashes, hash_stride, n, g, hist1);
+    hipLaunchKernelGGL(bulk_scan256_kernel, dim3(1), dim3(320), 0, e->stream,
+                       static_cast<const uint32_t*>(hist1), nd1, start1, cursor1, tile_start1);
+    hipLaunchKernelGGL(bulk_scatter_kernel<1>, dim3(part_grid), dim3(kPartThreads), 0, e->stream,
+                       hashes, hash_stride, uint32_t(first_idx), static_cast<const ulonglong2*>(nullptr), n, g,
+                       static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor1, recA);
+    if (g.bits2) {
+        const uint32_t grid2 = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile + nd1, uint64_t(e->n_cu) * 2u));
+        hipLaunchKernelGGL(bulk_hist2_kernel, dim3(grid2), dim3(kPartThreads), 0, e->stream,
+                           static_cast<const ulonglong2*>(recA), g, static_cast<const uint32_t*>(start1),
+                           static_cast<const uint32_t*>(tile_start1), hist2);
+        hipLaunchKernelGGL(bulk_scan_buckets_kernel, dim3(1), dim3(1024), 0, e->stream,
+                           static_cast<const uint32_t*>(hist2), n_buckets, start2, cursor2);
+        hipLaunchKernelGGL(bulk_scatter_kernel<2>, dim3(grid2), dim3(kPartThreads), 0, e->stream,
+                           static_cast<const uint64_t*>(nullptr), 0u, 0u, static_cast<const ulonglong2*>(recA), n, g,
+                           static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor2, recB);
+        final_recs = recB; bstart = start2;
+    }
+    }
+    Bracket br(e, K_DEDUP, n);
+    const size_t lds = (size_t(1) << e->seg_bits) * sizeof(uint64_t);
+    uint32_t dthreads = kPartThreads;
+    if (const char* v = std::getenv("FQD_DEDUP_THREADS")) dthreads = uint32_t(std::min(512, std::max(64, std::atoi(v))));
+    const uint32_t dgrid = std::min<uint32_t>(n_buckets, uint32_t(e->n_cu) * uint32_t(std::max<size_t>(1, (150 * 1024) / lds)));
+    unsigned long long* counters = reinterpret_cast<unsigned long long*>(e->d_state + 1);
+    if (fresh) {
+        if (lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_dedup_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        hipLaunchKernelGGL(bucket_dedup_kernel<true>, dim3(dgrid), dim3(dthreads), lds, e->stream,
+                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, ks, uint32_t(first_idx), keep, counters);
+    } else {
+        if (lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_dedup_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        hipLaunchKernelGGL(bucket_dedup_kernel<false>, dim3(dgrid), dim3(dthreads), lds, e->stream,
+                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, ks, uint32_t(first_idx), keep, counters);
+    }
+    HIP_TRY(e, hipGetLastError());
+    e->table_clear = false; e->table_stale = false;
     return FQD_OK;
 }
 
@@ -397,6 +507,7 @@ int fqd_engine_create(const fqd_config* cfg, fqd_engine** out)
     }
     if ((err = hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate(aux)", err);
     if (const char* v = std::getenv("FQD_CHUNK_READS")) { const long long x = std::atoll(v); e->chunk_reads = x > 0 ? uint64_t(x) : ~0ull; }
+    if (const char* v = std::getenv("FQD_BULK_MIN")) { const long long x = std::atoll(v); e->bulk_min = x >= 0 ? uint64_t(x) : ~0ull; }
     if (const char* v = std::getenv("FQD_ENC_BLOCKS_PER_CU")) e->enc_blocks_per_cu = uint32_t(std::max(1, std::atoi(v)));
     if (const char* v = std::getenv("FQD_INS_BLOCKS_PER_CU")) e->ins_blocks_per_cu = uint32_t(std::max(1, std::atoi(v)));
     if ((err = hipMalloc(reinterpret_cast<void**>(&e->d_state), 4 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc(state)", err);
@@ -425,7 +536,7 @@ int fqd_engine_destroy(fqd_engine* e)
     for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
     if (e->aux) (void)hipStreamDestroy(e->aux);
     release(e->table); release(e->keys); release(e->koff); release(e->hashes);
-    release(e->scan_scratch); release(e->part_scratch); release(e->st_keep);
+    release(e->scan_scratch); release(e->part_scratch); release(e->st_keep); release(e->bulk_recs); release(e->bulk_meta);
     for (int s = 0; s < 2; ++s) { release(e->st_bases[s]); release(e->st_off[s]); release(e->st_len[s]); }
     if (e->d_state) (void)hipFree(e->d_state);
     if (e->h_state) (void)hipHostFree(e->h_state);
@@ -438,10 +549,7 @@ int fqd_engine_reset(fqd_engine* e)
 {
     if (!e) return FQD_ERR_ARG;
     HIP_TRY(e, hipSetDevice(e->device));
-    if (e->table.p) {
-        Bracket br(e, K_OTHER, 0);
-        HIP_TRY(e, hipMemsetAsync(e->table.p, 0xFF, e->slots * sizeof(uint64_t), e->stream));
-    }
+    if (e->table.p && !e->table_clear) e->table_stale = true;     // cleared (or rebuilt by the bulk path) on first use
     e->h_state[0] = kNoError; e->h_state[1] = 0; e->h_state[2] = 0; e->h_state[3] = 0;
     HIP_TRY(e, hipMemcpyAsync(e->d_state, e->h_state, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -542,7 +650,10 @@ int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint
     }
 
     KeyStore ks{e->keys.as<uint64_t>(), e->ragged ? e->koff.as<uint64_t>() : nullptr, e->W0, e->W0, 0};
-    if (n >= 2 * e->chunk_reads && e->aux) {
+    if (bulk_applies(e, n)) {
+        if ((rc = launch_encode(e, sv, uniform, seg, n, first, ks, e->hashes.as<uint64_t>()))) return rc;
+        if ((rc = launch_bulk_insert(e, ks, e->hashes.as<uint64_t>(), 1, n, first, d_keep))) return rc;
+    } else if (n >= 2 * e->chunk_reads && e->aux) {
         // Overlap: the encoder streams HBM, the insert is bound by memory-side atomics, so the
         // two run side by side on two streams, sub-batch k+1 being encoded while k is inserted.
         // Each kernel is launched on half of the wave slots so the other one can be resident.
@@ -697,7 +808,8 @@ int fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n, uint3
                            records, n, e->W0, e->keys.as<uint64_t>() + first * uint64_t(e->W0));
     }
     KeyStore ks{e->keys.as<uint64_t>(), nullptr, e->W0, e->W0, 0};
-    if ((rc = launch_insert(e, ks, records, e->W0 + 1, n, first, keep))) return rc;
+    if (bulk_applies(e, n)) { if ((rc = launch_bulk_insert(e, ks, records, e->W0 + 1, n, first, keep))) return rc; }
+    else if ((rc = launch_insert(e, ks, records, e->W0 + 1, n, first, keep))) return rc;
     e->n_records += n; e->keys_used += new_words;
     return FQD_OK;
 }

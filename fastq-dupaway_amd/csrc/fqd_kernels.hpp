@@ -218,6 +218,11 @@ __device__ __forceinline__ bool keys_equal(const KeyStore& ks, uint32_t a, uint3
     return d == 0;
 }
 
+// The table is cut into segments of 2^seg_bits slots (4096..16384, or the whole table when it
+// is smaller); a key's probe sequence wraps inside the segment its hash selects.  That keeps the
+// incremental (atomic) path below and the bulk path (bucket_dedup_kernel, one segment per
+// workgroup in LDS) on one and the same table layout.
+//
 // insert: one record per lane.  Slot = (tag:32 | record index:32), EMPTY = all ones.
 //   * atomicCAS(EMPTY -> mine) claims a free slot: the record is (so far) the first of its key.
 //   * a slot whose tag matches is verified word-for-word against the owner's stored key;
@@ -227,7 +232,7 @@ __device__ __forceinline__ bool keys_equal(const KeyStore& ks, uint32_t a, uint3
 // Records of earlier batches have smaller indices and can never be displaced, so a batch's
 // flags are final when its launch retires.
 __global__ __launch_bounds__(kBlock)
-void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, KeyStore ks,
+void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, uint64_t seg_mask, KeyStore ks,
                    const uint64_t* __restrict__ hashes, uint32_t hash_stride,
                    uint64_t n, uint32_t first_idx, uint8_t* __restrict__ keep,
                    unsigned long long* __restrict__ counters /* [0]=dups [1]=table-full */)
@@ -241,7 +246,7 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, KeyStore ks
         const unsigned long long mine = (tag << 32) | idx;
         uint64_t pos = h & slot_mask;
         bool placed = false;
-        for (uint64_t probe = 0; probe <= slot_mask; ++probe) {
+        for (uint64_t probe = 0; probe <= seg_mask; ++probe) {
             const unsigned long long old = atomicCAS(&tab[pos], kEmptySlot, mine);
             if (old == kEmptySlot) { placed = true; break; }
             if ((old >> 32) == tag && keys_equal(ks, idx, uint32_t(old))) {
@@ -255,7 +260,7 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, KeyStore ks
                 placed = true;
                 break;
             }
-            pos = (pos + 1) & slot_mask;
+            pos = (pos & ~seg_mask) | ((pos + 1) & seg_mask);       // probing never leaves the key's segment
         }
         if (!placed) ++lost;
     }
@@ -271,7 +276,8 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, KeyStore ks
 // rehash: move every owner into a larger table (keys are distinct: no verification).
 __global__ __launch_bounds__(kBlock)
 void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
-                   uint64_t* __restrict__ new_table, uint64_t new_mask, KeyStore ks, uint32_t len0, uint32_t len1)
+                   uint64_t* __restrict__ new_table, uint64_t new_mask, uint64_t new_seg_mask, KeyStore ks,
+                   uint32_t len0, uint32_t len1)
 {
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(new_table);
     for (uint64_t s = blockIdx.x * uint64_t(kBlock) + threadIdx.x; s < old_slots; s += uint64_t(gridDim.x) * kBlock) {
@@ -286,7 +292,241 @@ void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
         h = hash_end(h);
         const unsigned long long mine = ((h >> 32) << 32) | idx;
         uint64_t pos = h & new_mask;
-        while (atomicCAS(&tab[pos], kEmptySlot, mine) != kEmptySlot) pos = (pos + 1) & new_mask;
+        while (atomicCAS(&tab[pos], kEmptySlot, mine) != kEmptySlot)
+            pos = (pos & ~new_seg_mask) | ((pos + 1) & new_seg_mask);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Bulk insert: no global atomics on the table.
+//   records (hash, index) are radix-partitioned by table segment (one or two passes of up to
+//   256 ways, LDS counting sort per 4096-record tile so the scatter leaves the CU as runs of
+//   whole lines), then one workgroup per segment replays the same probe/verify/first-wins logic
+//   as insert_kernel on an LDS-resident copy of the segment and writes it back once.
+// Measured motive (tools/atomic_probe.hip): device-scope atomics cap at 18-27 G/s on this chip
+// wherever the table lives, LDS atomics do not.
+struct BulkGeom {
+    uint64_t slot_mask;
+    uint32_t seg_bits;     // log2(slots per segment)
+    uint32_t bits1, bits2; // partition digits: bucket = pos >> seg_bits = (d1 << bits2) | d2
+};
+__device__ __forceinline__ uint32_t bucket_of(uint64_t hash, const BulkGeom& g) { return uint32_t((hash & g.slot_mask) >> g.seg_bits); }
+
+constexpr int kPartThreads = 512;
+constexpr int kPartPer = 8;
+constexpr int kPartTile = kPartThreads * kPartPer;      // 4096 records per tile
+
+// level-1 histogram straight from the batch's hashes
+__global__ __launch_bounds__(kPartThreads)
+void bulk_hist1_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stride, uint64_t n, BulkGeom g,
+                       uint32_t* __restrict__ hist1)
+{
+    __shared__ uint32_t h[256];
+    for (int k = threadIdx.x; k < 256; k += kPartThreads) h[k] = 0;
+    __syncthreads();
+    for (uint64_t i = blockIdx.x * uint64_t(kPartThreads) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kPartThreads)
+        atomicAdd(&h[bucket_of(hashes[i * uint64_t(hash_stride)], g) >> g.bits2], 1u);
+    __syncthreads();
+    for (int k = threadIdx.x; k < 256; k += kPartThreads) if (h[k]) atomicAdd(&hist1[k], h[k]);
+}
+
+// One block: start[d] = exclusive prefix of count[d] for d < nd (nd <= 256), start[nd] = total;
+// cursor = copy of start; tile_start[d] = prefix of ceil(count[d] / tile) (tiles never straddle digits).
+__global__ void bulk_scan256_kernel(const uint32_t* __restrict__ count, uint32_t nd, uint32_t* __restrict__ start,
+                                    uint32_t* __restrict__ cursor, uint32_t* __restrict__ tile_start)
+{
+    __shared__ uint32_t a[257], t[257];
+    const uint32_t d = threadIdx.x;
+    if (d <= 256) {
+        a[d] = d < nd ? count[d] : 0u;
+        t[d] = d < nd ? (count[d] + kPartTile - 1) / kPartTile : 0u;
+    }
+    __syncthreads();
+    if (d == 0) {
+        uint32_t s = 0, ts = 0;
+        for (uint32_t k = 0; k <= nd; ++k) { const uint32_t c = k < nd ? a[k] : 0, tc = k < nd ? t[k] : 0; a[k] = s; t[k] = ts; s += c; ts += tc; }
+    }
+    __syncthreads();
+    if (d <= nd) { start[d] = a[d]; tile_start[d] = t[d]; if (d < nd) cursor[d] = a[d]; }
+}
+
+// Scatter pass shared by both levels.  LEVEL 1 reads the batch's hashes (index implicit),
+// LEVEL 2 reads level-1 records; the tile's records are counting-sorted by digit in LDS, each
+// digit's run reserves its place with ONE atomicAdd on that digit's cursor, and the runs are
+// copied out contiguously.
+template <int LEVEL>
+__global__ __launch_bounds__(kPartThreads)
+void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stride, uint32_t first_idx,
+                         const ulonglong2* __restrict__ in, uint64_t n, BulkGeom g,
+                         const uint32_t* __restrict__ start1, const uint32_t* __restrict__ tile_start1,
+                         uint32_t* __restrict__ cursor, ulonglong2* __restrict__ out)
+{
+    __shared__ ulonglong2 stage[kPartTile];
+    __shared__ uint32_t cnt[256], lstart[256], gbase[256];
+    const uint32_t nd1 = 1u << g.bits1;
+    const uint64_t n_tiles = (LEVEL == 1) ? (n + kPartTile - 1) / kPartTile : tile_start1[nd1];
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        uint64_t lo, hi; uint32_t d1 = 0;
+        if (LEVEL == 1) { lo = tile * kPartTile; hi = lo + kPartTile < n ? lo + kPartTile : n; }
+        else {
+            // which level-1 digit does this tile belong to?  (binary search over <= 256 entries)
+            uint32_t a = 0, b = nd1;
+            while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (tile_start1[m] <= tile) a = m; else b = m; }
+            d1 = a;
+            lo = start1[d1] + (tile - tile_start1[d1]) * uint64_t(kPartTile);
+            hi = lo + kPartTile < start1[d1 + 1] ? lo + kPartTile : start1[d1 + 1];
+        }
+        const uint32_t count = uint32_t(hi - lo);
+        for (int k = threadIdx.x; k < 256; k += kPartThreads) cnt[k] = 0;
+        __syncthreads();
+        ulonglong2 rec[kPartPer]; uint32_t dig[kPartPer], rank[kPartPer];
+#pragma unroll
+        for (int k = 0; k < kPartPer; ++k) {
+            const uint32_t r = threadIdx.x + k * kPartThreads;
+            if (r < count) {
+                if (LEVEL == 1) { rec[k].x = hashes[(lo + r) * uint64_t(hash_stride)]; rec[k].y = first_idx + uint32_t(lo + r); }
+                else rec[k] = in[lo + r];
+                const uint32_t bkt = bucket_of(rec[k].x, g);
+                dig[k] = (LEVEL == 1) ? (bkt >> g.bits2) : (bkt & ((1u << g.bits2) - 1u));
+                rank[k] = atomicAdd(&cnt[dig[k]], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {                               // exclusive scan of 256 counts by one wave
+            uint32_t c[4], s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { c[k] = cnt[threadIdx.x * 4 + k]; s += c[k]; }
+            uint32_t inc = s;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(inc, d, 64); if (int(threadIdx.x) >= d) inc += up; }
+            uint32_t ex = inc - s;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { lstart[threadIdx.x * 4 + k] = ex; ex += c[k]; }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 256; k += kPartThreads)
+            gbase[k] = cnt[k] ? atomicAdd(&cursor[(LEVEL == 1 ? 0u : (d1 << g.bits2)) + k], cnt[k]) : 0u;
+#pragma unroll
+        for (int k = 0; k < kPartPer; ++k)
+            if (threadIdx.x + k * kPartThreads < count) stage[lstart[dig[k]] + rank[k]] = rec[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kPartPer; ++k) {
+            const uint32_t r = threadIdx.x + k * kPartThreads;
+            if (r < count) {
+                const ulonglong2 v = stage[r];
+                const uint32_t bkt = bucket_of(v.x, g);
+                const uint32_t d = (LEVEL == 1) ? (bkt >> g.bits2) : (bkt & ((1u << g.bits2) - 1u));
+                out[gbase[d] + (r - lstart[d])] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Level-2 histogram over the level-1 output: a tile lies inside one level-1 digit, so its
+// counts go to 256 consecutive buckets; LDS-aggregated, one global add per non-empty bin.
+__global__ __launch_bounds__(kPartThreads)
+void bulk_hist2_kernel(const ulonglong2* __restrict__ in, BulkGeom g, const uint32_t* __restrict__ start1,
+                       const uint32_t* __restrict__ tile_start1, uint32_t* __restrict__ hist2)
+{
+    __shared__ uint32_t h[256];
+    const uint32_t nd1 = 1u << g.bits1, nd2 = 1u << g.bits2;
+    const uint64_t n_tiles = tile_start1[nd1];
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        uint32_t a = 0, b = nd1;
+        while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (tile_start1[m] <= tile) a = m; else b = m; }
+        const uint32_t d1 = a;
+        const uint64_t lo = start1[d1] + (tile - tile_start1[d1]) * uint64_t(kPartTile);
+        const uint64_t hi = lo + kPartTile < start1[d1 + 1] ? lo + kPartTile : start1[d1 + 1];
+        for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) h[k] = 0;
+        __syncthreads();
+        for (uint64_t r = lo + threadIdx.x; r < hi; r += kPartThreads)
+            atomicAdd(&h[bucket_of(in[r].x, g) & (nd2 - 1u)], 1u);
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) if (h[k]) atomicAdd(&hist2[(d1 << g.bits2) + k], h[k]);
+        __syncthreads();
+    }
+}
+
+// One block of 1024 threads: start[b] = exclusive prefix of count[b], b < nb (nb <= 65536);
+// start[nb] = total; cursor = start.
+__global__ __launch_bounds__(1024)
+void bulk_scan_buckets_kernel(const uint32_t* __restrict__ count, uint32_t nb, uint32_t* __restrict__ start,
+                              uint32_t* __restrict__ cursor)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nb + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+    uint32_t s = 0;
+    for (uint32_t k = lo; k < hi; ++k) s += count[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {                                  // scan the 1024 partial sums with one wave
+        uint32_t c[16], t = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { c[k] = part[threadIdx.x * 16 + k]; t += c[k]; }
+        uint32_t inc = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(inc, d, 64); if (int(threadIdx.x) >= d) inc += up; }
+        uint32_t ex = inc - t;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { part[threadIdx.x * 16 + k] = ex; ex += c[k]; }
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t k = lo; k < hi; ++k) { start[k] = run; cursor[k] = run; run += count[k]; }
+    if (threadIdx.x == 1023) start[nb] = run;
+}
+
+// One workgroup per table segment.  FRESH: the segment is known to be empty (engine just reset):
+// it is built in LDS from scratch and written out, so the table needs no clearing pass.
+template <bool FRESH>
+__global__ __launch_bounds__(kPartThreads)
+void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __restrict__ bstart, uint32_t n_buckets,
+                         uint64_t* __restrict__ table, uint32_t seg_bits, KeyStore ks, uint32_t first_idx,
+                         uint8_t* __restrict__ keep, unsigned long long* __restrict__ counters)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long seg[];
+    const uint32_t seg_slots = 1u << seg_bits, seg_mask = seg_slots - 1u;
+    uint32_t dups = 0, lost = 0;
+    for (uint32_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
+        unsigned long long* gseg = reinterpret_cast<unsigned long long*>(table) + uint64_t(b) * seg_slots;
+        const uint32_t lo = bstart[b], hi = bstart[b + 1];
+        if (!FRESH && lo == hi) continue;                     // nothing to add: leave the segment alone
+        for (uint32_t k = threadIdx.x; k < seg_slots; k += blockDim.x) seg[k] = FRESH ? kEmptySlot : gseg[k];
+        __syncthreads();
+        for (uint32_t r = lo + threadIdx.x; r < hi; r += blockDim.x) {
+            const ulonglong2 v = recs[r];
+            const uint32_t idx = uint32_t(v.y);
+            const uint64_t tag = v.x >> 32;
+            const unsigned long long mine = (tag << 32) | idx;
+            uint32_t pos = uint32_t(v.x) & seg_mask;
+            bool placed = false;
+            for (uint32_t probe = 0; probe < seg_slots; ++probe) {
+                const unsigned long long old = atomicCAS(&seg[pos], kEmptySlot, mine);
+                if (old == kEmptySlot) { placed = true; break; }
+                if ((old >> 32) == tag && keys_equal(ks, idx, uint32_t(old))) {
+                    uint32_t owner = uint32_t(old);
+                    if (owner > idx) owner = uint32_t(atomicMin(&seg[pos], mine));
+                    if (owner < idx) keep[idx - first_idx] = 0;
+                    else             keep[owner - first_idx] = 0;
+                    ++dups; placed = true;
+                    break;
+                }
+                pos = (pos + 1u) & seg_mask;
+            }
+            if (!placed) ++lost;
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < seg_slots; k += blockDim.x) gseg[k] = seg[k];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { dups += __shfl_down(dups, d, 64); lost += __shfl_down(lost, d, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (dups) atomicAdd(&counters[0], static_cast<unsigned long long>(dups));
+        if (lost) atomicAdd(&counters[1], static_cast<unsigned long long>(lost));
     }
 }
 

@@ -89,9 +89,11 @@ typedef struct fqd_stats {
 /* Average device time per launch, measured with HIP events on the engine's
  * stream when FQD_FLAG_PROFILE is set (bench.py's roofline uses these). */
 typedef struct fqd_profile {
-    double   encode_ms;   uint64_t encode_launches;   uint64_t encode_reads;
-    double   insert_ms;   uint64_t insert_launches;   uint64_t insert_reads;
-    double   other_ms;    uint64_t other_launches;    /* clears, scans, rehash */
+    double   encode_ms;    uint64_t encode_launches;    uint64_t encode_reads;     /* encode_*_kernel            */
+    double   insert_ms;    uint64_t insert_launches;    uint64_t insert_reads;     /* insert_kernel (atomic path) */
+    double   partition_ms; uint64_t partition_launches; uint64_t partition_reads;  /* bulk path: hist + scatter passes, timed as one group per batch */
+    double   dedup_ms;     uint64_t dedup_launches;     uint64_t dedup_reads;      /* bulk path: bucket_dedup_kernel */
+    double   other_ms;     uint64_t other_launches;                                /* clears, scans, rehash      */
 } fqd_profile;
 
 int  fqd_abi_version(void);

@@ -301,3 +301,28 @@ def test_full_size_100m_pe_properties(torch_cuda):
         e.submit([Reads(b1, uniform_len=L, uniform_stride=L), Reads(b2, uniform_len=L, uniform_stride=L)], n, keep=keep)
         e.sync()
         assert torch.equal(keep, expect)
+
+
+# ---- the two insert paths (device atomics vs radix partition + LDS segments) agree -----------------
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_bulk_and_atomic_insert_paths_agree(oracle, monkeypatch, paired):
+    rng = np.random.default_rng(123)
+    n, L = 300_000, 100
+    S = 2 if paired else 1
+    pools = [rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=(n // (4 if m == 0 else 400), L), p=[.24, .24, .24, .24, .04]) for m in range(S)]
+    mates = [np.concatenate([pools[m][rng.integers(0, len(pools[m]), n)].reshape(-1), np.zeros(16, np.uint8)]) for m in range(S)]
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(L); lens = np.full(n, L, np.uint32)
+    exp = (oracle.dedup_paired(mates[0], offs, lens, mates[1], offs, lens) if paired
+           else oracle.dedup_single(mates[0], offs, lens))
+    for bulk_min in ("0", "999999999999"):
+        monkeypatch.setenv("FQD_BULK_MIN", bulk_min)
+        # one shot, and streamed in uneven batches into a growing table (fresh and non-fresh segments)
+        for cuts in ([0, n], [0, 1000, 60_000, 61_000, 200_000, n]):
+            got = []
+            with Engine(segments=S) as e:
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    segs = [Reads(mates[m][a * L:], uniform_len=L, uniform_stride=L) for m in range(S)]
+                    got.append(e.submit(segs, b - a))
+                assert e.stats()["duplicates"] == int((exp == 0).sum())
+            assert np.array_equal(np.concatenate(got), exp), (bulk_min, cuts)

@@ -39,11 +39,13 @@ def test_abi_version_and_key_words(lib):
 
 
 def test_library_holds_gfx950_code_only():
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-S", str(fqd.LIB_PATH)], capture_output=True, text=True).stdout
-    assert ".hip_fatbin" in out
-    strings = subprocess.run(["strings", "-a", str(fqd.LIB_PATH)], capture_output=True, text=True).stdout
-    assert "gfx950" in strings
-    assert "gfx942" not in strings and "sm_" not in strings
+    # every device code object bundled into the library targets gfx950 and nothing else
+    import re
+    data = fqd.LIB_PATH.read_bytes()
+    assert b"__CLANG_OFFLOAD_BUNDLE__" in data
+    targets = set(re.findall(rb"hipv4-amdgcn-amd-amdhsa--([a-z0-9:+-]+)", data))
+    assert targets == {b"gfx950"}, targets
+    assert b"nvptx" not in data and b"sm_90" not in data
 
 
 def test_bad_config_is_rejected_without_touching_a_gpu(lib):

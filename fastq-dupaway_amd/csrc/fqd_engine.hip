@@ -58,6 +58,7 @@ struct fqd_engine {
     DevBuf   keys;     uint64_t keys_used = 0;       // words
     DevBuf   koff;                                   // ragged only: word offset per record
     bool     ragged = false, have_shape = false;
+    bool     rec_layout = false;                     // keys kept as whole records [hash | key] (sharded engines)
     uint32_t L0 = 0, L1 = 0, W0 = 0;
     uint64_t n_records = 0;
     uint64_t cap_hint_reads = 0, cap_hint_bases = 0;
@@ -200,6 +201,12 @@ int scan_exclusive(fqd_engine* e, uint64_t* data, uint64_t n, uint64_t add, cons
     return FQD_OK;
 }
 
+KeyStore key_store(const fqd_engine* e)
+{
+    if (e->rec_layout) return KeyStore{e->keys.as<uint64_t>(), nullptr, e->W0, e->W0 + 1, 1};
+    return KeyStore{e->keys.as<uint64_t>(), e->ragged ? e->koff.as<uint64_t>() : nullptr, e->W0, e->W0, 0};
+}
+
 // Probing segments: 4096..16384 slots so that (slots / segment) <= 65536 buckets, or the whole
 // table when it is smaller than one segment.
 uint32_t seg_bits_for(uint64_t slots)
@@ -223,7 +230,7 @@ int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
     if (e->slots && e->n_records) {
         Bracket br(e, K_OTHER, 0);
         HIP_TRY(e, hipMemsetAsync(nt, 0xFF, want * sizeof(uint64_t), e->stream));
-        KeyStore ks{e->keys.as<uint64_t>(), e->ragged ? e->koff.as<uint64_t>() : nullptr, e->W0, e->W0, 0};
+        const KeyStore ks = key_store(e);
         hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(e, e->slots)), dim3(kBlock), 0, e->stream,
                            e->table.as<uint64_t>(), e->slots, static_cast<uint64_t*>(nt), want - 1,
                            (1ull << new_seg_bits) - 1, ks, e->L0, e->L1);
@@ -553,7 +560,7 @@ int fqd_engine_reset(fqd_engine* e)
     e->h_state[0] = kNoError; e->h_state[1] = 0; e->h_state[2] = 0; e->h_state[3] = 0;
     HIP_TRY(e, hipMemcpyAsync(e->d_state, e->h_state, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    e->n_records = 0; e->keys_used = 0; e->ragged = false; e->have_shape = false;
+    e->n_records = 0; e->keys_used = 0; e->ragged = false; e->have_shape = false; e->rec_layout = false;
     e->L0 = e->L1 = e->W0 = 0; e->has_bad = false; e->last_error.clear();
     return FQD_OK;
 }
@@ -565,6 +572,7 @@ int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint
         return e->fail(FQD_ERR_ARG, "fqd_submit: bad arguments");
     if (n == 0) return FQD_OK;
     if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
+    if (e->rec_layout) return e->fail(FQD_ERR_ARG, "fqd_submit: this engine holds pre-encoded records (fqd_insert_records)");
     HIP_TRY(e, hipSetDevice(e->device));
     int rc;
 
@@ -785,32 +793,53 @@ int fqd_partition_records(fqd_engine* e, const uint64_t* records, uint64_t n, ui
     return FQD_OK;
 }
 
+// Common front of the two record entry points: shape, table and key-store capacity.
+static int prepare_records(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1)
+{
+    if (e->S == 1 && len1 != 0) return e->fail(FQD_ERR_ARG, "records: single-end engine given a mate-2 length");
+    if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (!e->have_shape) {
+        e->have_shape = true; e->ragged = false; e->rec_layout = true;
+        e->L0 = len0; e->L1 = len1; e->W0 = seg_words(len0) + seg_words(len1);
+    } else if (!e->rec_layout || e->L0 != len0 || e->L1 != len1)
+        return e->fail(FQD_ERR_ARG, "records: engine holds keys of another shape or layout");
+    int rc;
+    if ((rc = ensure_table(e, e->n_records + n))) return rc;
+    const uint64_t need = e->keys_used + n * uint64_t(e->W0 + 1);
+    return reserve(e, e->keys, std::max<uint64_t>(need, 64) * sizeof(uint64_t), e->keys_used * sizeof(uint64_t));
+}
+
+int fqd_reserve_records(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1, uint64_t** slot)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!slot) return e->fail(FQD_ERR_ARG, "fqd_reserve_records: bad arguments");
+    const int rc = prepare_records(e, n, len0, len1);
+    if (rc) return rc;
+    *slot = e->keys.as<uint64_t>() + e->keys_used;
+    return FQD_OK;
+}
+
 int fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep)
 {
     if (!e) return FQD_ERR_ARG;
     if (n && (!records || !keep)) return e->fail(FQD_ERR_ARG, "fqd_insert_records: bad arguments");
-    if (e->S == 1 && len1 != 0) return e->fail(FQD_ERR_ARG, "fqd_insert_records: single-end engine given a mate-2 length");
     if (n == 0) return FQD_OK;
-    if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
-    HIP_TRY(e, hipSetDevice(e->device));
-    if (!e->have_shape) { e->have_shape = true; e->ragged = false; e->L0 = len0; e->L1 = len1; e->W0 = seg_words(len0) + seg_words(len1); }
-    else if (e->ragged || e->L0 != len0 || e->L1 != len1)
-        return e->fail(FQD_ERR_ARG, "fqd_insert_records: engine holds keys of another shape");
     int rc;
+    if ((rc = prepare_records(e, n, len0, len1))) return rc;
     const uint64_t first = e->n_records;
-    if ((rc = ensure_table(e, first + n))) return rc;
-    const uint64_t new_words = n * uint64_t(e->W0);
-    if ((rc = reserve(e, e->keys, std::max<uint64_t>(e->keys_used + new_words, 64) * sizeof(uint64_t),
-                      e->keys_used * sizeof(uint64_t)))) return rc;
-    if (e->W0) {
+    const uint64_t words = n * uint64_t(e->W0 + 1);
+    uint64_t* tail = e->keys.as<uint64_t>() + e->keys_used;
+    if (records != tail) {                                   // not received in place: one contiguous copy
         Bracket br(e, K_OTHER, 0);
-        hipLaunchKernelGGL(unpack_records_kernel, dim3(grid_for(e, new_words)), dim3(kBlock), 0, e->stream,
-                           records, n, e->W0, e->keys.as<uint64_t>() + first * uint64_t(e->W0));
+        HIP_TRY(e, hipMemcpyAsync(tail, records, words * sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream));
     }
-    KeyStore ks{e->keys.as<uint64_t>(), nullptr, e->W0, e->W0, 0};
-    if (bulk_applies(e, n)) { if ((rc = launch_bulk_insert(e, ks, records, e->W0 + 1, n, first, keep))) return rc; }
-    else if ((rc = launch_insert(e, ks, records, e->W0 + 1, n, first, keep))) return rc;
-    e->n_records += n; e->keys_used += new_words;
+    const KeyStore ks = key_store(e);
+    // the hash of record j is word 0 of its slot: hashes = first slot of the batch, stride W0+1
+    const uint64_t* hashes = tail;
+    if (bulk_applies(e, n)) { if ((rc = launch_bulk_insert(e, ks, hashes, e->W0 + 1, n, first, keep))) return rc; }
+    else if ((rc = launch_insert(e, ks, hashes, e->W0 + 1, n, first, keep))) return rc;
+    e->n_records += n; e->keys_used += words;
     return FQD_OK;
 }
 

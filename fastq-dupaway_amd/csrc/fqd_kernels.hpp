@@ -595,18 +595,6 @@ void relayout_ragged_kernel(const uint64_t* __restrict__ src, uint64_t* __restri
     }
 }
 
-// Records [hash, words...] -> uniform arena slots (multi-GPU insert path).
-__global__ __launch_bounds__(kBlock)
-void unpack_records_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t W0, uint64_t* __restrict__ arena_at_first)
-{
-    const uint64_t total = n * uint64_t(W0);
-    for (uint64_t x = blockIdx.x * uint64_t(kBlock) + threadIdx.x; x < total; x += uint64_t(gridDim.x) * kBlock) {
-        const uint64_t j = x / W0;
-        const uint32_t k = uint32_t(x - j * W0);
-        arena_at_first[x] = rec[j * (W0 + 1u) + 1u + k];
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Stable partition of records by owner = (hash >> 40) % n_parts  (SURVEY §8e step 2).
 // counts2d is part-major: counts2d[p * n_blocks + b]; an exclusive scan of it is

@@ -144,6 +144,12 @@ class Engine:
         self._check(self._L.fqd_partition_records(self._h, _addr(records), n, key_words, n_parts,
                                                   _addr(out), _addr(counts), _addr(origin)))
 
+    def reserve_records(self, n: int, len0: int, len1: int) -> int:
+        """Device address of room for n records at the tail of the key store (receive in place)."""
+        slot = C.c_void_p()
+        self._check(self._L.fqd_reserve_records(self._h, n, len0, len1, C.byref(slot)))
+        return slot.value
+
     def insert_records(self, records, n: int, len0: int, len1: int, keep):
         self._check(self._L.fqd_insert_records(self._h, _addr(records), n, len0, len1, _addr(keep)))
 

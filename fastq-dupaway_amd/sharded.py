@@ -17,6 +17,14 @@ from typing import Sequence
 import torch
 
 
+class _DeviceWords:
+    """Exposes raw device memory through __cuda_array_interface__ so torch can alias it."""
+
+    def __init__(self, ptr: int, n_words: int):
+        self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i8", "data": (ptr, False),
+                                         "version": 3, "strides": None}
+
+
 class HipOps:
     """The sharding halves of include/fqdupaway.h on one GPU."""
 
@@ -31,6 +39,13 @@ class HipOps:
 
     def partition(self, records, n, key_words, parts, out, counts, origin):
         self.e.partition_records(records, n, key_words, parts, out, counts, origin)
+
+    def recv_buffer(self, n, len0, len1, device):
+        """Room for n records at the tail of the engine's key store, as a tensor the all-to-all can
+        write into: the records are then inserted where they lie (fqd_reserve_records)."""
+        rw = self.key_words(len0, len1) + 1
+        ptr = self.e.reserve_records(n, len0, len1)
+        return torch.as_tensor(_DeviceWords(ptr, max(1, n * rw)), device=device)
 
     def insert(self, records, n, len0, len1, keep):
         self.e.insert_records(records, n, len0, len1, keep)
@@ -61,7 +76,10 @@ class ShardedDedup:
         self.counts = torch.zeros(self.world, dtype=i64, device=device)
         self.recv_counts = torch.zeros(self.world, dtype=i64, device=device)
         self.cap_recv = int(n_max * slack) + 4096
-        self.recv = torch.empty(self.cap_recv * self.rw, dtype=i64, device=device)
+        import os
+        # receive straight into the owner's key store (FQD_SHARDED_INPLACE=0: through a staging buffer)
+        self.in_place = hasattr(ops, "recv_buffer") and os.environ.get("FQD_SHARDED_INPLACE", "1") != "0"
+        self.recv = None if self.in_place else torch.empty(self.cap_recv * self.rw, dtype=i64, device=device)
         self.keep_recv = torch.empty(self.cap_recv, dtype=torch.uint8, device=device)
         self.keep_back = torch.empty(n_max, dtype=torch.uint8, device=device)
 
@@ -78,12 +96,14 @@ class ShardedDedup:
         n_recv = sum(recv)
         if n_recv > self.cap_recv:                   # a skewed step: grow once, keep going
             self.cap_recv = int(n_recv * 1.1) + 4096
-            self.recv = torch.empty(self.cap_recv * rw, dtype=torch.int64, device=self.device)
+            if not self.in_place:
+                self.recv = torch.empty(self.cap_recv * rw, dtype=torch.int64, device=self.device)
             self.keep_recv = torch.empty(self.cap_recv, dtype=torch.uint8, device=self.device)
-        dist.all_to_all_single(self.recv[: n_recv * rw], self.grouped[: n * rw],
+        recv_buf = ops.recv_buffer(n_recv, self.len0, self.len1, self.device) if self.in_place else self.recv
+        dist.all_to_all_single(recv_buf[: n_recv * rw], self.grouped[: n * rw],
                                output_split_sizes=[c * rw for c in recv], input_split_sizes=[c * rw for c in send])
         self._sync_comm()
-        ops.insert(self.recv, n_recv, self.len0, self.len1, self.keep_recv)
+        ops.insert(recv_buf, n_recv, self.len0, self.len1, self.keep_recv)
         ops.sync()
         dist.all_to_all_single(self.keep_back[:n], self.keep_recv[:n_recv],
                                output_split_sizes=send, input_split_sizes=recv)

@@ -148,9 +148,17 @@ int  fqd_partition_records(fqd_engine* e, const uint64_t* records, uint64_t n, u
                            uint32_t n_parts, uint64_t* out, uint64_t* counts, uint32_t* origin);
 
 /* Inserts n pre-encoded records (as produced by fqd_encode_uniform, in
- * global input order) for mate lengths (len0,len1) and writes their keep flags. */
+ * global input order) for mate lengths (len0,len1) and writes their keep flags.
+ * An engine fed this way keeps whole records ([hash | key]) in its key store and cannot
+ * also take fqd_submit batches. */
 int  fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n,
                         uint32_t len0, uint32_t len1, uint8_t* keep);
+
+/* Receive without a copy: *slot (device) is room for n records at the tail of the engine's
+ * key store.  Let the all-to-all write the records there, then pass *slot to
+ * fqd_insert_records, which inserts them where they lie.  No other engine call may come
+ * in between. */
+int  fqd_reserve_records(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1, uint64_t** slot);
 
 /* ---- the `--unordered` read-ID join (hash_dup_remover.hpp:150-192,257-347) ------------
  * ID tags of one file (FastqViewWithId::read_new, fastqview.cpp:190-204): the tag bytes of

@@ -226,3 +226,39 @@ def test_partition_is_stable_and_complete():
     assert np.array_equal(counts.cpu().numpy(), np.bincount(owner, minlength=parts))
     assert np.array_equal(origin.cpu().numpy(), order.astype(np.int32))
     assert np.array_equal(o, r[order])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_place", [False, True])
+@pytest.mark.parametrize("bulk_min", ["0", "-1", None])
+def test_insert_records_over_several_rounds(oracle, monkeypatch, in_place, bulk_min):
+    """The owner-side half on its own: records arrive round after round (copied in, or received
+    in place at the tail of the key store) and first-occurrence-wins holds across rounds."""
+    from fastq_dupaway_amd import Engine, Reads
+    from fastq_dupaway_amd.sharded import HipOps
+    if bulk_min is not None:
+        monkeypatch.setenv("FQD_BULK_MIN", bulk_min)
+    n_per, rounds, LL = 1_200_000, 3, 150
+    dev = torch.device("cuda", 0)
+    with Engine(segments=1) as e:
+        ops = HipOps(e)
+        W = e.key_words(LL); rw = W + 1
+        bases = torch.empty(rounds * n_per * LL + 16, dtype=torch.uint8, device=dev)
+        expect = torch.empty(rounds * n_per, dtype=torch.uint8, device=dev)
+        e.synth_reads(77, 0, rounds * n_per, LL, 250, 0, bases, expect)
+        keep = torch.zeros(rounds * n_per, dtype=torch.uint8, device=dev)
+        staging = torch.empty(n_per * rw, dtype=torch.int64, device=dev)
+        for k in range(rounds):
+            seg = [Reads(bases[k * n_per * LL:], uniform_len=LL, uniform_stride=LL)]
+            e.encode_uniform(seg, n_per, staging)
+            e.sync()
+            if in_place:
+                buf = ops.recv_buffer(n_per, LL, 0, dev)
+                buf[: n_per * rw].copy_(staging)             # stands in for the all-to-all writing the records
+                torch.cuda.synchronize()
+            else:
+                buf = staging
+            e.insert_records(buf, n_per, LL, 0, keep[k * n_per:])
+            e.sync()
+        assert torch.equal(keep, expect)
+        assert e.stats()["duplicates"] == int((expect == 0).sum().item())

@@ -165,8 +165,17 @@ def main():
                 kernels[k] = {"avg_ms": round(avg_ms, 4), "launches": prof[f"{k}_launches"],
                               "GBps": round(per_launch * bytes_per_unit / (avg_ms * 1e-3) / 1e9, 1)}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (two separate
+        # rocprofv3 --pmc runs of this same command, corrected per MI355X_MICROARCH.md §HBM:
+        # tools/summarize_pmc.py).  Only valid for the workload those passes were taken on.
+        traffic = None
+        pmc = sorted((ROOT / "profiles").glob("*_pmc_summary.json"))
+        if pmc and world == 1 and n == 100_000_000 and L == 150 and not a.paired:
+            for name, rec in json.loads(pmc[-1].read_text())["kernels"].items():
+                if name.split("<")[0] == names[dom].split("<")[0].split(" ")[0]:
+                    traffic = rec["hbm_traffic"]
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_unit": bytes_per_unit, "kernels": kernels,
                     "whole_step_frac": round(value * 1e6 / world * bytes_per_unit / 1e9 / HBM_PEAK_GBS, 4)}
         out = {"metric": "Mreads/s dedup, 150 bp %s FASTQ" % ("PE" if a.paired else "SE"),

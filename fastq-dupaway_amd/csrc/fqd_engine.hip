@@ -233,7 +233,8 @@ int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
         const KeyStore ks = key_store(e);
         hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(e, e->slots)), dim3(kBlock), 0, e->stream,
                            e->table.as<uint64_t>(), e->slots, static_cast<uint64_t*>(nt), want - 1,
-                           (1ull << new_seg_bits) - 1, ks, e->L0, e->L1);
+                           (1ull << new_seg_bits) - 1, ks, e->L0, e->L1,
+                           reinterpret_cast<unsigned long long*>(e->d_state + 1));
         e->table_clear = false; e->table_stale = false;
     } else {
         e->table_clear = false; e->table_stale = true;       // cleared lazily by whoever uses it first

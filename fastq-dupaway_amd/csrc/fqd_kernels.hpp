@@ -277,7 +277,7 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, uint64_t se
 __global__ __launch_bounds__(kBlock)
 void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
                    uint64_t* __restrict__ new_table, uint64_t new_mask, uint64_t new_seg_mask, KeyStore ks,
-                   uint32_t len0, uint32_t len1)
+                   uint32_t len0, uint32_t len1, unsigned long long* __restrict__ counters /* [1] = table-full */)
 {
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(new_table);
     for (uint64_t s = blockIdx.x * uint64_t(kBlock) + threadIdx.x; s < old_slots; s += uint64_t(gridDim.x) * kBlock) {
@@ -292,8 +292,11 @@ void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
         h = hash_end(h);
         const unsigned long long mine = ((h >> 32) << 32) | idx;
         uint64_t pos = h & new_mask;
-        while (atomicCAS(&tab[pos], kEmptySlot, mine) != kEmptySlot)
+        uint64_t probe = 0;                                  // bounded: a full segment is reported, never spun on
+        while (atomicCAS(&tab[pos], kEmptySlot, mine) != kEmptySlot) {
+            if (++probe > new_seg_mask) { atomicAdd(&counters[1], 1ull); break; }
             pos = (pos & ~new_seg_mask) | ((pos + 1) & new_seg_mask);
+        }
     }
 }
 

@@ -6,9 +6,10 @@ they do not fit one pass: MI355X_MICROARCH.md §rocprofv3 PMC slots).
   python tools/summarize_pmc.py <round-tag> <stats_dir> <fetch_dir> <write_dir>
 
 Corrections applied (MI355X_MICROARCH.md §HBM): counter unit = KiB; on gfx950 FETCH_SIZE
-reports exactly half of a wide coalesced streaming read, so the encode kernel's fetch is
-doubled; the insert kernel's fetch is random 8/64-byte traffic for which the factor is
-uncalibrated: it is reported raw and the doubled value is given as an upper bound.
+reports exactly half of a wide coalesced streaming read, so the fetch of the streaming kernels
+(encode, partition histogram/scatter passes) is doubled; the dedup/insert kernels mix streaming
+with random 8/64-byte traffic for which the factor is uncalibrated: their fetch is reported raw
+and the doubled value is given as an upper bound.
 """
 import collections
 import csv
@@ -41,7 +42,7 @@ def main():
     write = counter_avgs(write_dir, "WRITE_SIZE")
     summary = {"tag": tag, "unit": "bytes per launch", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
-        streaming = "encode" in k
+        streaming = any(t in k for t in ("encode", "bulk_hist", "bulk_scatter"))     # wide coalesced readers
         f_raw = fetch.get(k, 0.0) * 1024
         w = write.get(k, 0.0) * 1024
         f_corr = f_raw * 2 if streaming else f_raw

@@ -42,11 +42,20 @@ __host__ __device__ inline uint64_t hash_word(uint64_t h, uint64_t w)
     h = (h ^ w) * kHashMul;
     return h ^ (h >> 32);
 }
+// A record's hash = hash_end of its mate-1 chain (single-end), or of mate-1's chain fed with
+// mate-2's chain (paired): each mate is hashed on its own from hash_begin(len, 0), so the two
+// mates of a pair can be encoded by two lanes.
+__host__ __device__ inline uint64_t hash_pair(uint64_t mate0_chain, uint64_t mate1_chain);
 __host__ __device__ inline uint64_t hash_end(uint64_t h)
 {
     h ^= h >> 33; h *= 0xff51afd7ed558ccdull;
     h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull;
     return h ^ (h >> 33);
+}
+
+__host__ __device__ inline uint64_t hash_pair(uint64_t mate0_chain, uint64_t mate1_chain)
+{
+    return hash_end(hash_word(mate0_chain, mate1_chain));
 }
 
 // ---- error word ---------------------------------------------------------------

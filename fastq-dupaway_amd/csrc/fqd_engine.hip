@@ -233,7 +233,7 @@ int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
         const KeyStore ks = key_store(e);
         hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(e, e->slots)), dim3(kBlock), 0, e->stream,
                            e->table.as<uint64_t>(), e->slots, static_cast<uint64_t*>(nt), want - 1,
-                           (1ull << new_seg_bits) - 1, ks, e->L0, e->L1,
+                           (1ull << new_seg_bits) - 1, ks, e->L0, e->L1, uint32_t(e->S == 2),
                            reinterpret_cast<unsigned long long*>(e->d_state + 1));
         e->table_clear = false; e->table_stale = false;
     } else {
@@ -282,14 +282,17 @@ StagedChoice choose_staged(const fqd_engine* e, const fqd_reads* seg, bool unifo
     StagedChoice c{false, 0, 0, 0, 0};
     if (!uniform || (e->flags & FQD_FLAG_NO_STAGE)) return c;
     for (uint32_t R = 256; R >= 64; R -= 64) {
-        uint64_t t0 = (uint64_t(R) * seg[0].uniform_stride + 32 + 15) & ~15ull;
-        uint64_t t1 = (e->S == 2) ? ((uint64_t(R) * seg[1].uniform_stride + 32 + 15) & ~15ull) : 0;
+        const uint32_t per_tile = e->S == 2 ? R / 2 : R;     // paired: one lane per mate, R/2 pairs per tile
+        uint64_t t0 = (uint64_t(per_tile) * seg[0].uniform_stride + 32 + 15) & ~15ull;
+        uint64_t t1 = (e->S == 2) ? ((uint64_t(per_tile) * seg[1].uniform_stride + 32 + 15) & ~15ull) : 0;
         if (t0 + t1 <= 64 * 1024) {
-            // keys parked in LDS and streamed out as whole lines: see encode_staged_kernel
+            // keys parked in LDS over the lane's own consumed bytes and streamed out as whole lines
             const uint32_t row_words = ks.W0 + ks.lead;
-            const uint32_t lds_out = (!ks.koff && ks.stride == row_words && row_words > 1 &&
-                                      seg[0].uniform_stride >= 8u * row_words + 15u) ? 1u : 0u;
-            c = {true, R, uint32_t(t0), uint32_t(t1), lds_out};
+            const uint32_t row0 = ks.lead + seg_words(seg[0].uniform_len);
+            const uint32_t row1 = e->S == 2 ? seg_words(seg[1].uniform_len) : 0;
+            bool fits = !ks.koff && ks.stride == row_words && row_words > 1 && seg[0].uniform_stride >= 8u * row0 + 15u;
+            if (e->S == 2) fits = fits && seg[1].uniform_stride >= 8u * row1 + 15u;
+            c = {true, R, uint32_t(t0), uint32_t(t1), fits ? 1u : 0u};
             return c;
         }
     }
@@ -305,16 +308,23 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
     const StagedChoice c = choose_staged(e, seg, uniform, ks);
     uint64_t* err = e->d_state;
     if (c.staged) {
-        const uint32_t grid = uint32_t(std::min<uint64_t>((n + c.R - 1) / c.R, uint64_t(e->n_cu) * blocks_per_cu));
+        const uint32_t per_tile = e->S == 2 ? c.R / 2 : c.R;
+        const uint32_t grid = uint32_t(std::min<uint64_t>((n + per_tile - 1) / per_tile, uint64_t(e->n_cu) * blocks_per_cu));
         const size_t lds = size_t(c.tile0) + c.tile1;
         const uint32_t rw = ks.W0 + ks.lead;
         const uint32_t magic = rw > 1 ? uint32_t(((1ull << 32) + rw - 1) / rw) : 0xFFFFFFFFu;   // x/rw for x < 2^16
-        auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream,
-                               sv[0], sv[1], n, first_idx, ks, hash_out, err, c.tile0, magic);
-        };
-        if (e->S == 1) { if (c.lds_out) launch(encode_staged_kernel<1, true>); else launch(encode_staged_kernel<1, false>); }
-        else           { if (c.lds_out) launch(encode_staged_kernel<2, true>); else launch(encode_staged_kernel<2, false>); }
+        if (e->S == 1) {
+            auto launch = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream, sv[0], n, first_idx, ks, hash_out, err, magic);
+            };
+            if (c.lds_out) launch(encode_staged_kernel<true>); else launch(encode_staged_kernel<false>);
+        } else {
+            auto launch = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream,
+                                   sv[0], sv[1], n, first_idx, ks, hash_out, err, c.tile0, magic);
+            };
+            if (c.lds_out) launch(encode_staged_pe_kernel<true>); else launch(encode_staged_pe_kernel<false>);
+        }
     } else {
         const uint32_t grid = uint32_t(std::min<uint64_t>(grid_for(e, n), uint64_t(e->n_cu) * blocks_per_cu));
         if (e->S == 1)

@@ -70,7 +70,7 @@ void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_id
         const uint32_t l0 = s0.len(i);
         const uint32_t l1 = (S == 2) ? s1.len(i) : 0u;
         uint64_t* out = ks.slot(first_idx + i);
-        uint64_t h = hash_begin(l0, l1);
+        uint64_t h = hash_begin(l0, 0);
         if (ks.koff) *out++ = uint64_t(l0) | (uint64_t(l1) << 32);
         auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
         const uint8_t* p0 = s0.ptr(i);
@@ -78,10 +78,14 @@ void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_id
         const uintptr_t a0 = reinterpret_cast<uintptr_t>(p0);
         uint32_t diff = pack_mate(reinterpret_cast<const uint32_t*>(a0 & ~uintptr_t(3)), uint32_t(a0 & 3u), l0, sink);
         if (S == 2) {
+            const uint64_t m0 = h;
+            h = hash_begin(l1, 0);
             const uintptr_t a1 = reinterpret_cast<uintptr_t>(p1);
             diff |= pack_mate(reinterpret_cast<const uint32_t*>(a1 & ~uintptr_t(3)), uint32_t(a1 & 3u), l1, sink);
+            h = hash_pair(m0, h);
+        } else {
+            h = hash_end(h);
         }
-        h = hash_end(h);
         if (hash_out) hash_out[i] = h;
         else          ks.slot(first_idx + i)[-1] = h;
         if (diff) {
@@ -106,11 +110,10 @@ void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_id
 // only when  stride0 >= 8*row_words + 15  (row_words = W0 + lead) and the batch's key
 // slots are contiguous (no koff).  rw_magic = ceil(2^32 / row_words).
 //   tile_reads R = blockDim.x (multiple of 64); LDS = round16(R*stride + 32) per mate
-template <int S, bool LDS_OUT>
+template <bool LDS_OUT>
 __global__ __launch_bounds__(kBlock)
-void encode_staged_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx,
-                          KeyStore ks, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err,
-                          uint32_t tile_bytes0, uint32_t rw_magic)
+void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
+                          KeyStore ks, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err, uint32_t rw_magic)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint64_t* lds64 = reinterpret_cast<uint64_t*>(lds);
@@ -120,28 +123,22 @@ void encode_staged_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t r0 = tile * R;
         const uint32_t nr = uint32_t(n - r0 < R ? n - r0 : R);
-        uint32_t lds_off[2] = {0u, 0u};
-        uint32_t head[2] = {0u, 0u};
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const SegView& sv = s ? s1 : s0;
-            const uint8_t* g0 = sv.bases + r0 * uint64_t(sv.ustride);
-            const uint32_t bytes = (nr - 1u) * sv.ustride + sv.ulen;
-            const uintptr_t ga = reinterpret_cast<uintptr_t>(g0);
-            head[s] = uint32_t(ga & 15u);                           // bytes before g0 in its 16-B chunk
-            const uint4* src = reinterpret_cast<const uint4*>(ga - head[s]);
-            const uint32_t n16 = (head[s] + bytes + 15u) >> 4;
-            lds_off[s] = s ? tile_bytes0 : 0u;
-            uint4* dst = reinterpret_cast<uint4*>(lds + (lds_off[s] >> 2));
+        const uint8_t* g0 = s0.bases + r0 * uint64_t(s0.ustride);
+        const uint32_t bytes = (nr - 1u) * s0.ustride + s0.ulen;
+        const uintptr_t ga = reinterpret_cast<uintptr_t>(g0);
+        const uint32_t in0 = uint32_t(ga & 15u);                    // bytes before g0 in its 16-B chunk
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(ga - in0);
+            const uint32_t n16 = (in0 + bytes + 15u) >> 4;
+            uint4* dst = reinterpret_cast<uint4*>(lds);
             for (uint32_t c = threadIdx.x; c < n16; c += R) dst[c] = src[c];
         }
         __syncthreads();
         const uint32_t t = threadIdx.x;
         const uint64_t i = r0 + t;
-        const uint32_t l0 = s0.ulen, l1 = (S == 2) ? s1.ulen : 0u;
-        const uint32_t in0 = lds_off[0] + head[0];                  // byte offset of the tile's first read
+        const uint32_t l0 = s0.ulen;
         if (t < nr) {
-            uint64_t h = hash_begin(l0, l1);
+            uint64_t h = hash_begin(l0, 0);
             const uint32_t b0 = in0 + t * s0.ustride;
             uint32_t diff;
             if (LDS_OUT) {
@@ -149,27 +146,18 @@ void encode_staged_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx
                 uint64_t* out = row;
                 auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
                 diff = pack_mate(lds + (b0 >> 2), b0 & 3u, l0, sink);
-                if (S == 2) {
-                    const uint32_t b1 = lds_off[1] + head[1] + t * s1.ustride;
-                    diff |= pack_mate(lds + (b1 >> 2), b1 & 3u, l1, sink);
-                }
                 h = hash_end(h);
                 if (hash_out) hash_out[i] = h; else row[-1] = h;
             } else {
                 uint64_t* out = ks.slot(first_idx + i);
-                if (ks.koff) *out++ = uint64_t(l0) | (uint64_t(l1) << 32);
+                if (ks.koff) *out++ = uint64_t(l0);
                 auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
                 diff = pack_mate(lds + (b0 >> 2), b0 & 3u, l0, sink);
-                if (S == 2) {
-                    const uint32_t b1 = lds_off[1] + head[1] + t * s1.ustride;
-                    diff |= pack_mate(lds + (b1 >> 2), b1 & 3u, l1, sink);
-                }
                 h = hash_end(h);
                 if (hash_out) hash_out[i] = h; else ks.slot(first_idx + i)[-1] = h;
             }
             if (diff) {
-                const uint64_t e = locate_bad_base(s0.bases + i * uint64_t(s0.ustride), l0,
-                                                   (S == 2) ? s1.bases + i * uint64_t(s1.ustride) : nullptr, l1, first_idx + i);
+                const uint64_t e = locate_bad_base(s0.bases + i * uint64_t(s0.ustride), l0, nullptr, 0, first_idx + i);
                 if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
             }
         }
@@ -182,6 +170,97 @@ void encode_staged_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx
             for (uint32_t x = lane; x < total; x += 64u) {
                 const uint32_t rr = __umulhi(x, rw_magic), kk = x - rr * row_words;
                 gout[x] = lds64[((in0 + (wave * 64u + rr) * s0.ustride + 4u + 7u) >> 3) + kk];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Paired variant: ONE LANE PER MATE (lane 2p = mate 1 of pair p, lane 2p+1 = mate 2), so a
+// 256-lane workgroup stages 128 pairs (2 x 19 KiB) and runs at the same wave occupancy as the
+// single-end encoder.  Each lane hashes and parks its own mate (same in-place rule, per mate:
+// stride_m >= 8*row_m + 15 with row_0 = lead + W_0, row_1 = W_1); the pair's hash is combined
+// across the two lanes with one DPP exchange (hash_pair).  A wave streams out its 32 pair keys.
+template <bool LDS_OUT>
+__global__ __launch_bounds__(kBlock)
+void encode_staged_pe_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx,
+                             KeyStore ks, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err,
+                             uint32_t tile_bytes0, uint32_t rw_magic)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint64_t* lds64 = reinterpret_cast<uint64_t*>(lds);
+    const uint32_t R = blockDim.x, P = R >> 1;
+    const uint32_t W_0 = seg_words(s0.ulen);
+    const uint32_t row_words = ks.W0 + ks.lead;
+    const uint64_t n_tiles = (n + P - 1) / P;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t r0 = tile * P;
+        const uint32_t np = uint32_t(n - r0 < P ? n - r0 : P);
+        uint32_t in_base[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const SegView& sv = s ? s1 : s0;
+            const uint8_t* g0 = sv.bases + r0 * uint64_t(sv.ustride);
+            const uint32_t bytes = (np - 1u) * sv.ustride + sv.ulen;
+            const uintptr_t ga = reinterpret_cast<uintptr_t>(g0);
+            const uint32_t head = uint32_t(ga & 15u);
+            const uint4* src = reinterpret_cast<const uint4*>(ga - head);
+            const uint32_t n16 = (head + bytes + 15u) >> 4;
+            const uint32_t off = s ? tile_bytes0 : 0u;
+            in_base[s] = off + head;
+            uint4* dst = reinterpret_cast<uint4*>(lds + (off >> 2));
+            for (uint32_t c = threadIdx.x; c < n16; c += R) dst[c] = src[c];
+        }
+        __syncthreads();
+        const uint32_t t = threadIdx.x, pair = t >> 1, mate = t & 1u;
+        const bool live = pair < np;
+        const uint64_t i = r0 + pair;
+        const uint32_t len = mate ? s1.ulen : s0.ulen;
+        const uint32_t stride = mate ? s1.ustride : s0.ustride;
+        const uint32_t b = in_base[mate] + pair * stride;
+        uint64_t h = hash_begin(len, 0);
+        uint32_t diff = 0;
+        uint64_t* row = nullptr;
+        if (live) {
+            if (LDS_OUT) {
+                row = lds64 + ((b + 4u + 7u) >> 3) + (mate ? 0u : ks.lead);
+                uint64_t* out = row;
+                auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
+                diff = pack_mate(lds + (b >> 2), b & 3u, len, sink);
+            } else {
+                uint64_t* out = ks.slot(first_idx + i);
+                if (ks.koff) { if (!mate) *out = uint64_t(s0.ulen) | (uint64_t(s1.ulen) << 32); ++out; }
+                out += mate ? W_0 : 0u;
+                auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
+                diff = pack_mate(lds + (b >> 2), b & 3u, len, sink);
+            }
+        }
+        const uint64_t other = __shfl_xor(h, 1, 64);               // the partner lane's chain
+        if (live && !mate) {
+            const uint64_t hh = hash_pair(h, other);
+            if (hash_out) hash_out[i] = hh;
+            else if (LDS_OUT) row[-1] = hh;
+            else ks.slot(first_idx + i)[-1] = hh;
+        }
+        if (live && diff) {
+            uint32_t byte = 0;
+            const uint8_t* gp = (mate ? s1.bases : s0.bases) + i * uint64_t(stride);
+            const uint32_t pos = first_bad_base(gp, len, &byte);
+            if (pos != 0xFFFFFFFFu)
+                atomicMin(reinterpret_cast<unsigned long long*>(err),
+                          static_cast<unsigned long long>(make_error(first_idx + i, mate, pos, byte)));
+        }
+        if (LDS_OUT) {
+            const uint32_t wave = t >> 6, lane = t & 63u;
+            const uint32_t wave_pairs = (np > wave * 32u) ? ((np - wave * 32u < 32u) ? np - wave * 32u : 32u) : 0u;
+            uint64_t* __restrict__ gout = ks.keys + (first_idx + r0 + wave * 32u) * uint64_t(ks.stride);
+            const uint32_t total = wave_pairs * row_words, split = ks.lead + W_0;
+            for (uint32_t x = lane; x < total; x += 64u) {
+                const uint32_t rr = __umulhi(x, rw_magic), kk = x - rr * row_words;
+                const uint32_t m = kk >= split ? 1u : 0u;
+                const uint32_t kw = m ? kk - split : kk;
+                const uint32_t pb = in_base[m] + (wave * 32u + rr) * (m ? s1.ustride : s0.ustride);
+                gout[x] = lds64[((pb + 4u + 7u) >> 3) + kw];
             }
         }
         __syncthreads();
@@ -277,7 +356,7 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, uint64_t se
 __global__ __launch_bounds__(kBlock)
 void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
                    uint64_t* __restrict__ new_table, uint64_t new_mask, uint64_t new_seg_mask, KeyStore ks,
-                   uint32_t len0, uint32_t len1, unsigned long long* __restrict__ counters /* [1] = table-full */)
+                   uint32_t len0, uint32_t len1, uint32_t paired, unsigned long long* __restrict__ counters /* [1] = table-full */)
 {
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(new_table);
     for (uint64_t s = blockIdx.x * uint64_t(kBlock) + threadIdx.x; s < old_slots; s += uint64_t(gridDim.x) * kBlock) {
@@ -287,9 +366,16 @@ void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
         const uint64_t* p = ks.slot(idx);
         uint32_t l0 = len0, l1 = len1, W = ks.W0;
         if (ks.koff) { l0 = uint32_t(p[0]); l1 = uint32_t(p[0] >> 32); W = seg_words(l0) + seg_words(l1); ++p; }
-        uint64_t h = hash_begin(l0, l1);
-        for (uint32_t k = 0; k < W; ++k) h = hash_word(h, p[k]);
-        h = hash_end(h);
+        const uint32_t w0 = seg_words(l0);
+        uint64_t h = hash_begin(l0, 0);
+        for (uint32_t k = 0; k < w0; ++k) h = hash_word(h, p[k]);
+        if (paired) {                                         // second chain, then combine
+            uint64_t h1 = hash_begin(l1, 0);
+            for (uint32_t k = w0; k < W; ++k) h1 = hash_word(h1, p[k]);
+            h = hash_pair(h, h1);
+        } else {
+            h = hash_end(h);
+        }
         const unsigned long long mine = ((h >> 32) << 32) | idx;
         uint64_t pos = h & new_mask;
         uint64_t probe = 0;                                  // bounded: a full segment is reported, never spun on

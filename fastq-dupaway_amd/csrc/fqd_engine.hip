@@ -301,9 +301,11 @@ StagedChoice choose_staged(const fqd_engine* e, const fqd_reads* seg, bool unifo
 
 int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_reads* seg, uint64_t n,
                   uint64_t first_idx, const KeyStore& ks, uint64_t* hash_out,
-                  hipStream_t stream = nullptr, uint32_t blocks_per_cu = 8)
+                  hipStream_t stream = nullptr, uint32_t blocks_per_cu = 8, const Hist1* fold = nullptr)
 {
     if (!stream) stream = e->stream;
+    Hist1 h1{nullptr, BulkGeom{0, 0, 0, 0}};
+    if (fold) h1 = *fold;
     Bracket br(e, K_ENCODE, n, stream);
     const StagedChoice c = choose_staged(e, seg, uniform, ks);
     uint64_t* err = e->d_state;
@@ -315,13 +317,13 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
         const uint32_t magic = rw > 1 ? uint32_t(((1ull << 32) + rw - 1) / rw) : 0xFFFFFFFFu;   // x/rw for x < 2^16
         if (e->S == 1) {
             auto launch = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream, sv[0], n, first_idx, ks, hash_out, err, magic);
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream, sv[0], n, first_idx, ks, hash_out, err, magic, h1);
             };
             if (c.lds_out) launch(encode_staged_kernel<true>); else launch(encode_staged_kernel<false>);
         } else {
             auto launch = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream,
-                                   sv[0], sv[1], n, first_idx, ks, hash_out, err, c.tile0, magic);
+                                   sv[0], sv[1], n, first_idx, ks, hash_out, err, c.tile0, magic, h1);
             };
             if (c.lds_out) launch(encode_staged_pe_kernel<true>); else launch(encode_staged_pe_kernel<false>);
         }
@@ -329,10 +331,10 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
         const uint32_t grid = uint32_t(std::min<uint64_t>(grid_for(e, n), uint64_t(e->n_cu) * blocks_per_cu));
         if (e->S == 1)
             hipLaunchKernelGGL(encode_general_kernel<1>, dim3(grid), dim3(kBlock), 0, stream,
-                               sv[0], sv[1], n, first_idx, ks, hash_out, err);
+                               sv[0], sv[1], n, first_idx, ks, hash_out, err, h1);
         else
             hipLaunchKernelGGL(encode_general_kernel<2>, dim3(grid), dim3(kBlock), 0, stream,
-                               sv[0], sv[1], n, first_idx, ks, hash_out, err);
+                               sv[0], sv[1], n, first_idx, ks, hash_out, err, h1);
     }
     HIP_TRY(e, hipGetLastError());
     return FQD_OK;
@@ -370,54 +372,84 @@ bool bulk_applies(const fqd_engine* e, uint64_t n)
     return empty || n * 8 >= e->slots;
 }
 
-int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes, uint32_t hash_stride,
-                       uint64_t n, uint64_t first_idx, uint8_t* keep)
+struct BulkPlan {
+    bool ok = false;
+    BulkGeom g{0, 0, 0, 0};
+    uint32_t nd1 = 0, n_buckets = 0;
+    uint32_t *hist1 = nullptr, *start1 = nullptr, *cursor1 = nullptr, *tile_start1 = nullptr;
+    uint32_t *hist2 = nullptr, *start2 = nullptr, *cursor2 = nullptr;
+    ulonglong2 *recA = nullptr, *recB = nullptr;
+    uint16_t *bucket16 = nullptr;
+};
+
+// Geometry + scratch of one bulk insert; zeroes the counters on the engine's stream.
+int bulk_plan(fqd_engine* e, uint64_t n, BulkPlan& p)
 {
     uint32_t t = 0; while ((1ull << t) < e->slots) ++t;
     const uint32_t nb_bits = t - e->seg_bits;                // <= 16 by construction of seg_bits (t <= 30)
-    if (nb_bits > 16 || nb_bits == 0) return launch_insert(e, ks, hashes, hash_stride, n, first_idx, keep);
-    BulkGeom g;
-    g.slot_mask = e->slots - 1; g.seg_bits = e->seg_bits;
-    g.bits1 = nb_bits <= 8 ? nb_bits : (nb_bits + 1) / 2;
-    g.bits2 = nb_bits - g.bits1;
-    const uint32_t nd1 = 1u << g.bits1, n_buckets = 1u << nb_bits;
+    p.ok = false;
+    if (nb_bits > 16 || nb_bits == 0) return FQD_OK;
+    p.g.slot_mask = e->slots - 1; p.g.seg_bits = e->seg_bits;
+    p.g.bits1 = nb_bits <= 8 ? nb_bits : (nb_bits + 1) / 2;
+    p.g.bits2 = nb_bits - p.g.bits1;
+    p.nd1 = 1u << p.g.bits1; p.n_buckets = 1u << nb_bits;
     int rc;
     const size_t rec_bytes = ((n * sizeof(ulonglong2)) + 255) & ~size_t(255);
-    if ((rc = reserve(e, e->bulk_recs, rec_bytes * (g.bits2 ? 2 : 1)))) return rc;
+    const size_t b16_bytes = p.g.bits2 ? ((n * sizeof(uint16_t)) + 255) & ~size_t(255) : 0;
+    if ((rc = reserve(e, e->bulk_recs, rec_bytes * (p.g.bits2 ? 2 : 1) + b16_bytes))) return rc;
     // meta: hist1[256] start1[257] cursor1[256] tile_start1[257] | hist2[nb] start2[nb+1] cursor2[nb]
-    const size_t meta_words = 1100 + 3 * size_t(n_buckets) + 8;
+    const size_t meta_words = 1100 + 3 * size_t(p.n_buckets) + 8;
     if ((rc = reserve(e, e->bulk_meta, meta_words * sizeof(uint32_t)))) return rc;
     uint32_t* m = e->bulk_meta.as<uint32_t>();
-    uint32_t* hist1 = m; uint32_t* start1 = m + 256; uint32_t* cursor1 = m + 520; uint32_t* tile_start1 = m + 780;
-    uint32_t* hist2 = m + 1100; uint32_t* start2 = hist2 + n_buckets; uint32_t* cursor2 = start2 + n_buckets + 4;
-    ulonglong2* recA = e->bulk_recs.as<ulonglong2>();
-    ulonglong2* recB = reinterpret_cast<ulonglong2*>(e->bulk_recs.as<char>() + rec_bytes);
+    p.hist1 = m; p.start1 = m + 256; p.cursor1 = m + 520; p.tile_start1 = m + 780;
+    p.hist2 = m + 1100; p.start2 = p.hist2 + p.n_buckets; p.cursor2 = p.start2 + p.n_buckets + 4;
+    p.recA = e->bulk_recs.as<ulonglong2>();
+    p.recB = reinterpret_cast<ulonglong2*>(e->bulk_recs.as<char>() + rec_bytes);
+    p.bucket16 = p.g.bits2 ? reinterpret_cast<uint16_t*>(e->bulk_recs.as<char>() + 2 * rec_bytes) : nullptr;
+    {
+        Bracket br(e, K_OTHER, 0);
+        HIP_TRY(e, hipMemsetAsync(m, 0, meta_words * sizeof(uint32_t), e->stream));
+    }
+    p.ok = true;
+    return FQD_OK;
+}
+
+// hist1_done: the encoder already folded the level-1 histogram into its own pass.
+int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes, uint32_t hash_stride,
+                       uint64_t n, uint64_t first_idx, uint8_t* keep, const BulkPlan& p, bool hist1_done)
+{
+    const BulkGeom g = p.g;
+    const uint32_t nd1 = p.nd1, n_buckets = p.n_buckets;
+    uint32_t *hist1 = p.hist1, *start1 = p.start1, *cursor1 = p.cursor1, *tile_start1 = p.tile_start1;
+    uint32_t *hist2 = p.hist2, *start2 = p.start2, *cursor2 = p.cursor2;
+    ulonglong2 *recA = p.recA, *recB = p.recB;
     const bool fresh = e->n_records == 0 || e->table_clear || e->table_stale;
     {
         Bracket br(e, K_OTHER, 0);
         HIP_TRY(e, hipMemsetAsync(keep, 1, n, e->stream));
-        HIP_TRY(e, hipMemsetAsync(m, 0, meta_words * sizeof(uint32_t), e->stream));
     }
     const ulonglong2* final_recs = recA; const uint32_t* bstart = start1;
     {
     Bracket part_br(e, K_PARTITION, n);
     const uint32_t part_grid = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile, uint64_t(e->n_cu) * 2u));
-    hipLaunchKernelGGL(bulk_hist1_kernel, dim3(part_grid), dim3(kPartThreads), 0, e->stream, hashes, hash_stride, n, g, hist1);
+    if (!hist1_done)
+        hipLaunchKernelGGL(bulk_hist1_kernel, dim3(part_grid), dim3(kPartThreads), 0, e->stream, hashes, hash_stride, n, g, hist1);
     hipLaunchKernelGGL(bulk_scan256_kernel, dim3(1), dim3(320), 0, e->stream,
                        static_cast<const uint32_t*>(hist1), nd1, start1, cursor1, tile_start1);
     hipLaunchKernelGGL(bulk_scatter_kernel<1>, dim3(part_grid), dim3(kPartThreads), 0, e->stream,
                        hashes, hash_stride, uint32_t(first_idx), static_cast<const ulonglong2*>(nullptr), n, g,
-                       static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor1, recA);
+                       static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor1, recA, p.bucket16);
     if (g.bits2) {
         const uint32_t grid2 = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile + nd1, uint64_t(e->n_cu) * 2u));
         hipLaunchKernelGGL(bulk_hist2_kernel, dim3(grid2), dim3(kPartThreads), 0, e->stream,
-                           static_cast<const ulonglong2*>(recA), g, static_cast<const uint32_t*>(start1),
+                           static_cast<const uint16_t*>(p.bucket16), g, static_cast<const uint32_t*>(start1),
                            static_cast<const uint32_t*>(tile_start1), hist2);
         hipLaunchKernelGGL(bulk_scan_buckets_kernel, dim3(1), dim3(1024), 0, e->stream,
                            static_cast<const uint32_t*>(hist2), n_buckets, start2, cursor2);
         hipLaunchKernelGGL(bulk_scatter_kernel<2>, dim3(grid2), dim3(kPartThreads), 0, e->stream,
                            static_cast<const uint64_t*>(nullptr), 0u, 0u, static_cast<const ulonglong2*>(recA), n, g,
-                           static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor2, recB);
+                           static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor2, recB,
+                           static_cast<uint16_t*>(nullptr));
         final_recs = recB; bstart = start2;
     }
     }
@@ -669,9 +701,13 @@ int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint
     }
 
     KeyStore ks{e->keys.as<uint64_t>(), e->ragged ? e->koff.as<uint64_t>() : nullptr, e->W0, e->W0, 0};
-    if (bulk_applies(e, n)) {
-        if ((rc = launch_encode(e, sv, uniform, seg, n, first, ks, e->hashes.as<uint64_t>()))) return rc;
-        if ((rc = launch_bulk_insert(e, ks, e->hashes.as<uint64_t>(), 1, n, first, d_keep))) return rc;
+    BulkPlan plan;
+    if (bulk_applies(e, n) && (rc = bulk_plan(e, n, plan))) return rc;
+    if (plan.ok) {
+        const Hist1 fold{plan.hist1, plan.g};
+        static const bool fold_on = [] { const char* v = std::getenv("FQD_FOLD_HIST1"); return !(v && v[0] == '0'); }();
+        if ((rc = launch_encode(e, sv, uniform, seg, n, first, ks, e->hashes.as<uint64_t>(), nullptr, 8, fold_on ? &fold : nullptr))) return rc;
+        if ((rc = launch_bulk_insert(e, ks, e->hashes.as<uint64_t>(), 1, n, first, d_keep, plan, fold_on))) return rc;
     } else if (n >= 2 * e->chunk_reads && e->aux) {
         // Overlap: the encoder streams HBM, the insert is bound by memory-side atomics, so the
         // two run side by side on two streams, sub-batch k+1 being encoded while k is inserted.
@@ -848,7 +884,9 @@ int fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n, uint3
     const KeyStore ks = key_store(e);
     // the hash of record j is word 0 of its slot: hashes = first slot of the batch, stride W0+1
     const uint64_t* hashes = tail;
-    if (bulk_applies(e, n)) { if ((rc = launch_bulk_insert(e, ks, hashes, e->W0 + 1, n, first, keep))) return rc; }
+    BulkPlan plan;
+    if (bulk_applies(e, n) && (rc = bulk_plan(e, n, plan))) return rc;
+    if (plan.ok) { if ((rc = launch_bulk_insert(e, ks, hashes, e->W0 + 1, n, first, keep, plan, false))) return rc; }
     else if ((rc = launch_insert(e, ks, hashes, e->W0 + 1, n, first, keep))) return rc;
     e->n_records += n; e->keys_used += words;
     return FQD_OK;

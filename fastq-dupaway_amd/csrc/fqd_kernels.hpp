@@ -39,6 +39,26 @@ struct KeyStore {
     { return keys + (koff ? koff[j] : j * uint64_t(stride) + lead); }
 };
 
+// Geometry of the bulk (partitioned) insert, see bulk_* kernels below.  The encoders can fold
+// the level-1 histogram of that path into their own pass (Hist1: hist == nullptr -> off).
+struct BulkGeom {
+    uint64_t slot_mask;
+    uint32_t seg_bits;     // log2(slots per segment)
+    uint32_t bits1, bits2; // partition digits: bucket = pos >> seg_bits = (d1 << bits2) | d2
+};
+__device__ __forceinline__ uint32_t bucket_of(uint64_t hash, const BulkGeom& g) { return uint32_t((hash & g.slot_mask) >> g.seg_bits); }
+struct Hist1 {
+    uint32_t* hist;        // 256 global counters, or nullptr
+    BulkGeom  g;
+};
+// Per-block LDS histogram helpers shared by the three encoders.
+__device__ __forceinline__ void hist1_clear(uint32_t* lh) { for (uint32_t k = threadIdx.x; k < 256u; k += blockDim.x) lh[k] = 0; __syncthreads(); }
+__device__ __forceinline__ void hist1_flush(const uint32_t* lh, uint32_t* gh)
+{
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 256u; k += blockDim.x) if (lh[k]) atomicAdd(&gh[k], lh[k]);
+}
+
 // ---------------------------------------------------------------------------
 // Shared tail of both encoders: error word for a record whose packing saw a bad byte.
 // Rare path: rescans the mate(s) byte by byte in global memory for the FIRST offender,
@@ -64,8 +84,10 @@ __device__ __noinline__ uint64_t locate_bad_base(const uint8_t* p0, uint32_t l0,
 template <int S>
 __global__ __launch_bounds__(kBlock)
 void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx,
-                           KeyStore ks, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err)
+                           KeyStore ks, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err, Hist1 h1)
 {
+    __shared__ uint32_t lhist[256];
+    if (h1.hist) hist1_clear(lhist);
     for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
         const uint32_t l0 = s0.len(i);
         const uint32_t l1 = (S == 2) ? s1.len(i) : 0u;
@@ -88,11 +110,13 @@ void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_id
         }
         if (hash_out) hash_out[i] = h;
         else          ks.slot(first_idx + i)[-1] = h;
+        if (h1.hist) atomicAdd(&lhist[bucket_of(h, h1.g) >> h1.g.bits2], 1u);
         if (diff) {
             const uint64_t e = locate_bad_base(p0, l0, p1, l1, first_idx + i);
             if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
         }
     }
+    if (h1.hist) hist1_flush(lhist, h1.hist);
 }
 
 // ---------------------------------------------------------------------------
@@ -113,9 +137,11 @@ void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_id
 template <bool LDS_OUT>
 __global__ __launch_bounds__(kBlock)
 void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
-                          KeyStore ks, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err, uint32_t rw_magic)
+                          KeyStore ks, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err, uint32_t rw_magic, Hist1 h1)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ __attribute__((aligned(16))) uint32_t lhist[256];
+    if (h1.hist) hist1_clear(lhist);
     uint64_t* lds64 = reinterpret_cast<uint64_t*>(lds);
     const uint32_t R = blockDim.x;
     const uint32_t row_words = ks.W0 + ks.lead;
@@ -156,6 +182,7 @@ void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
                 h = hash_end(h);
                 if (hash_out) hash_out[i] = h; else ks.slot(first_idx + i)[-1] = h;
             }
+            if (h1.hist) atomicAdd(&lhist[bucket_of(h, h1.g) >> h1.g.bits2], 1u);
             if (diff) {
                 const uint64_t e = locate_bad_base(s0.bases + i * uint64_t(s0.ustride), l0, nullptr, 0, first_idx + i);
                 if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
@@ -174,6 +201,7 @@ void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
         }
         __syncthreads();
     }
+    if (h1.hist) hist1_flush(lhist, h1.hist);
 }
 
 // Paired variant: ONE LANE PER MATE (lane 2p = mate 1 of pair p, lane 2p+1 = mate 2), so a
@@ -185,9 +213,11 @@ template <bool LDS_OUT>
 __global__ __launch_bounds__(kBlock)
 void encode_staged_pe_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx,
                              KeyStore ks, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err,
-                             uint32_t tile_bytes0, uint32_t rw_magic)
+                             uint32_t tile_bytes0, uint32_t rw_magic, Hist1 h1)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ __attribute__((aligned(16))) uint32_t lhist[256];
+    if (h1.hist) hist1_clear(lhist);
     uint64_t* lds64 = reinterpret_cast<uint64_t*>(lds);
     const uint32_t R = blockDim.x, P = R >> 1;
     const uint32_t W_0 = seg_words(s0.ulen);
@@ -241,6 +271,7 @@ void encode_staged_pe_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_
             if (hash_out) hash_out[i] = hh;
             else if (LDS_OUT) row[-1] = hh;
             else ks.slot(first_idx + i)[-1] = hh;
+            if (h1.hist) atomicAdd(&lhist[bucket_of(hh, h1.g) >> h1.g.bits2], 1u);
         }
         if (live && diff) {
             uint32_t byte = 0;
@@ -265,6 +296,7 @@ void encode_staged_pe_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_
         }
         __syncthreads();
     }
+    if (h1.hist) hist1_flush(lhist, h1.hist);
 }
 
 // ---------------------------------------------------------------------------
@@ -394,12 +426,6 @@ void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
 //   as insert_kernel on an LDS-resident copy of the segment and writes it back once.
 // Measured motive (tools/atomic_probe.hip): device-scope atomics cap at 18-27 G/s on this chip
 // wherever the table lives, LDS atomics do not.
-struct BulkGeom {
-    uint64_t slot_mask;
-    uint32_t seg_bits;     // log2(slots per segment)
-    uint32_t bits1, bits2; // partition digits: bucket = pos >> seg_bits = (d1 << bits2) | d2
-};
-__device__ __forceinline__ uint32_t bucket_of(uint64_t hash, const BulkGeom& g) { return uint32_t((hash & g.slot_mask) >> g.seg_bits); }
 
 constexpr int kPartThreads = 512;
 constexpr int kPartPer = 8;
@@ -448,7 +474,8 @@ __global__ __launch_bounds__(kPartThreads)
 void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stride, uint32_t first_idx,
                          const ulonglong2* __restrict__ in, uint64_t n, BulkGeom g,
                          const uint32_t* __restrict__ start1, const uint32_t* __restrict__ tile_start1,
-                         uint32_t* __restrict__ cursor, ulonglong2* __restrict__ out)
+                         uint32_t* __restrict__ cursor, ulonglong2* __restrict__ out,
+                         uint16_t* __restrict__ bucket_out /* LEVEL 1: bucket number per output record, for the level-2 count */)
 {
     __shared__ ulonglong2 stage[kPartTile];
     __shared__ uint32_t cnt[256], lstart[256], gbase[256];
@@ -507,16 +534,18 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
                 const uint32_t bkt = bucket_of(v.x, g);
                 const uint32_t d = (LEVEL == 1) ? (bkt >> g.bits2) : (bkt & ((1u << g.bits2) - 1u));
                 out[gbase[d] + (r - lstart[d])] = v;
+                if (LEVEL == 1 && bucket_out) bucket_out[gbase[d] + (r - lstart[d])] = uint16_t(bkt);
             }
         }
         __syncthreads();
     }
 }
 
-// Level-2 histogram over the level-1 output: a tile lies inside one level-1 digit, so its
-// counts go to 256 consecutive buckets; LDS-aggregated, one global add per non-empty bin.
+// Level-2 histogram over the level-1 output (read through the 2-byte bucket numbers the
+// level-1 scatter leaves beside the records: an eighth of the bytes).  A tile lies inside one
+// level-1 digit, so its counts go to consecutive buckets; LDS-aggregated, one global add per bin.
 __global__ __launch_bounds__(kPartThreads)
-void bulk_hist2_kernel(const ulonglong2* __restrict__ in, BulkGeom g, const uint32_t* __restrict__ start1,
+void bulk_hist2_kernel(const uint16_t* __restrict__ bucket_in, BulkGeom g, const uint32_t* __restrict__ start1,
                        const uint32_t* __restrict__ tile_start1, uint32_t* __restrict__ hist2)
 {
     __shared__ uint32_t h[256];
@@ -531,7 +560,7 @@ void bulk_hist2_kernel(const ulonglong2* __restrict__ in, BulkGeom g, const uint
         for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) h[k] = 0;
         __syncthreads();
         for (uint64_t r = lo + threadIdx.x; r < hi; r += kPartThreads)
-            atomicAdd(&h[bucket_of(in[r].x, g) & (nd2 - 1u)], 1u);
+            atomicAdd(&h[bucket_in[r] & (nd2 - 1u)], 1u);
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) if (h[k]) atomicAdd(&hist2[(d1 << g.bits2) + k], h[k]);
         __syncthreads();

@@ -600,7 +600,7 @@ void bulk_scan_buckets_kernel(const uint32_t* __restrict__ count, uint32_t nb, u
 // One workgroup per table segment.  FRESH: the segment is known to be empty (engine just reset):
 // it is built in LDS from scratch and written out, so the table needs no clearing pass.
 template <bool FRESH>
-__global__ __launch_bounds__(kPartThreads)
+__global__ __launch_bounds__(1024)
 void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __restrict__ bstart, uint32_t n_buckets,
                          uint64_t* __restrict__ table, uint32_t seg_bits, KeyStore ks, uint32_t first_idx,
                          uint8_t* __restrict__ keep, unsigned long long* __restrict__ counters)

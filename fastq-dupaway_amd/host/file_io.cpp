@@ -21,8 +21,7 @@ bool has_gz_extension(const std::string& name)
 
 void throw_cannot_open(const std::string& name)
 {
-    std::cerr << "Cannot open file " << name << std::endl;
-    throw std::runtime_error("File does not exist or cannot be opened!");
+    throw DiagnosedError("Cannot open file " + name + "\n", "File does not exist or cannot be opened!");
 }
 
 InputFile::InputFile(const std::string& name) : gz_(has_gz_extension(name))

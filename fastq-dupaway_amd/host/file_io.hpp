@@ -13,7 +13,15 @@ namespace fqdhost {
 
 bool has_gz_extension(const std::string& name);               // file_utils.cpp:42-48
 
-// Prints "Cannot open file <name>" to stderr and throws, as check_fstream_ok does
+// An error that comes with a line for stderr ahead of the exception text, the way the reference
+// prints a diagnostic and then throws.  Whoever lets it reach main() prints `diag` first, so
+// work done on helper threads never prints out of order.
+struct DiagnosedError : std::runtime_error {
+    std::string diag;
+    DiagnosedError(std::string d, const std::string& what) : std::runtime_error(what), diag(std::move(d)) {}
+};
+
+// "Cannot open file <name>" + "File does not exist or cannot be opened!", as check_fstream_ok
 // (file_utils.hpp:111-121).
 [[noreturn]] void throw_cannot_open(const std::string& name);
 

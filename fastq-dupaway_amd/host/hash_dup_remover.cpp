@@ -108,32 +108,59 @@ private:
 struct PooledBlock : Block {
     Channel<PooledBlock>* home = nullptr;
     std::atomic<int> users{0};
+    std::exception_ptr error;        // the reader thread's fill() threw: rethrown by the consumer
+    bool stream_end = false;         // no block: the stream had already ended
     void acquire() { users.fetch_add(1); }
     void release() { if (users.fetch_sub(1) == 1) home->push(this); }
 };
 
-// One side (file) of an ordered run: a cursor over scanned blocks.
+// One side (file) of an ordered run: a reader thread fills pinned blocks (file read + record
+// scan) ahead of the consumer, which walks them with a cursor.
 struct Side {
     std::unique_ptr<RecordStream> stream;
-    Channel<PooledBlock> pool;
+    Channel<PooledBlock> pool, ready;
     std::vector<std::unique_ptr<PooledBlock>> storage;
+    std::thread reader;
+    std::atomic<bool> stop{false};
+    int device = 0;
     PooledBlock* cur = nullptr;      // block being consumed (holds one "feeder" reference)
     size_t pos = 0;                  // next record of cur
     bool ended = false;              // no further records will come
     bool failed = false; ParseFailure failure; bool held_back = false;
 
+    ~Side() { shutdown(); }
     void open_file(const std::string& name, Format f, bool want_tag, size_t block_bytes)
     {
         stream = std::make_unique<RecordStream>(name, f, want_tag, block_bytes);
     }
-    void prime(int n_blocks)
+    void prime(int n_blocks, int dev)
     {
+        device = dev;
         for (int k = 0; k < n_blocks; ++k) {
             storage.emplace_back(new PooledBlock());
             storage.back()->home = &pool;
             pool.push(storage.back().get());
         }
+        reader = std::thread([this] {
+            (void)hipSetDevice(device);
+            for (;;) {
+                PooledBlock* b = pool.pop();
+                if (!b || stop.load()) break;
+                b->error = nullptr; b->stream_end = false;
+                bool more = false;
+                try { more = stream->fill(*b); }
+                catch (...) { b->error = std::current_exception(); ready.push(b); break; }
+                if (!more) { b->stream_end = true; ready.push(b); break; }
+                const bool last = b->last;
+                ready.push(b);
+                if (last) break;
+            }
+        });
         advance();                   // the reference parses the first record when the file is set (bufferedinput.hpp:38-42)
+    }
+    void shutdown()
+    {
+        if (reader.joinable()) { stop.store(true); pool.push(nullptr); reader.join(); }
     }
     // Makes `cur` a block with unread records, or marks the side ended.
     void advance()
@@ -145,8 +172,9 @@ struct Side {
                 cur->release(); cur = nullptr;
                 if (was_last) { ended = true; break; }
             }
-            PooledBlock* b = pool.pop();
-            if (!stream->fill(*b)) { pool.push(b); ended = true; break; }
+            PooledBlock* b = ready.pop();
+            if (b->error) { std::exception_ptr err = b->error; b->error = nullptr; pool.push(b); ended = true; std::rethrow_exception(err); }
+            if (b->stream_end) { pool.push(b); ended = true; break; }
             b->users.store(1);       // the feeder's reference
             cur = b; pos = 0;
         }
@@ -164,7 +192,8 @@ struct Work {
     size_t n = 0;
     uint64_t first_index = 0;        // pair index of the batch's first record
     uint64_t emit_below = ~0ull;     // records at or beyond this pair index are not written
-    bool stop = false;               // tells the writer to finish
+    bool stop = false;               // tells the writers to finish
+    std::atomic<int> writers_left{0}; // one writer thread per output file
     Pinned<uint64_t> off[2]; Pinned<uint32_t> len[2]; Pinned<uint8_t> keep;
     Device<char> d_text[2]; Device<uint64_t> d_off[2]; Device<uint32_t> d_len[2]; Device<uint8_t> d_keep;
 };
@@ -184,7 +213,7 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
     for (int s = 0; s < S; ++s) {
         side[s].open_file(in[s], format_, S == 2, tuning_.block_bytes);      // "Cannot open file" comes first
         HIP_OK(hipSetDevice(tuning_.device));
-        side[s].prime(4);
+        side[s].prime(4, tuning_.device);
         // A malformed FIRST record fails at open, before anything is processed and before the
         // next file is touched (bufferedinput.hpp:38-42,81-84; hpp:211-212).
         if (side[s].available() == 0 && side[s].failed && !side[s].held_back) {
@@ -200,17 +229,20 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
 
     constexpr int kWorks = 3;
     std::vector<std::unique_ptr<Work>> works;
-    Channel<Work> free_works, to_write;
+    Channel<Work> free_works;
     for (int k = 0; k < kWorks; ++k) { works.emplace_back(new Work()); works.back()->S = S; free_works.push(works.back().get()); }
 
-    // ---- writer thread: survivors, verbatim, in input order ----------------------------
-    std::exception_ptr writer_error;
-    std::thread writer([&] {
-        try {
-            for (;;) {
-                Work* w = to_write.pop();
-                if (w->stop) { free_works.push(w); break; }
-                for (int s = 0; s < S; ++s) {
+    // ---- writer threads (one per output file: gzip outputs deflate in parallel): survivors,
+    //      verbatim, in input order ----------------------------------------------------------
+    Channel<Work> to_write[2];
+    std::exception_ptr writer_error[2];
+    auto writer_body = [&](int s) {
+        bool failed_already = false;
+        for (;;) {
+            Work* w = to_write[s].pop();
+            const bool stop = w->stop;
+            if (!stop && !failed_already) {
+                try {
                     const Block& b = *w->blk[s];
                     const char* run_from = nullptr; size_t run_len = 0;
                     for (size_t k = 0; k < w->n; ++k) {
@@ -223,15 +255,20 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
                         }
                     }
                     if (run_len) sink[s]->write(run_from, run_len);
-                }
-                for (int s = 0; s < S; ++s) w->blk[s]->release();
-                free_works.push(w);
+                } catch (...) { writer_error[s] = std::current_exception(); failed_already = true; }
             }
-        } catch (...) { writer_error = std::current_exception(); for (;;) { Work* w = to_write.pop(); bool stop = w->stop; if (!stop) for (int s = 0; s < S; ++s) w->blk[s]->release(); free_works.push(w); if (stop) break; } }
-    });
+            if (!stop) w->blk[s]->release();
+            if (w->writers_left.fetch_sub(1) == 1) free_works.push(w);
+            if (stop) break;
+        }
+    };
+    std::thread writers[2];
+    for (int s = 0; s < S; ++s) writers[s] = std::thread(writer_body, s);
+    auto hand_to_writers = [&](Work* w) { w->writers_left.store(S); for (int s = 0; s < S; ++s) to_write[s].push(w); };
     auto stop_writer = [&] {
-        Work* w = free_works.pop(); w->stop = true; to_write.push(w);
-        writer.join();
+        Work* w = free_works.pop(); w->stop = true;
+        hand_to_writers(w);
+        for (int s = 0; s < S; ++s) writers[s].join();
     };
 
     uint64_t next_index = 0;
@@ -252,7 +289,7 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
             free_works.push(w);
             throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng.e));
         }
-        to_write.push(w);
+        hand_to_writers(w);
     };
 
     try {
@@ -309,7 +346,7 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
         throw;
     }
     stop_writer();
-    if (writer_error) std::rethrow_exception(writer_error);
+    for (int s = 0; s < S; ++s) if (writer_error[s]) std::rethrow_exception(writer_error[s]);
     for (int s = 0; s < S; ++s) sink[s]->close();
 
     fqd_stats st{};
@@ -336,15 +373,18 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
 
 void HashDupRemover::filterSE(const std::string& infile, const std::string& outfile)
 {
-    run_ordered(1, &infile, &outfile);
+    try { run_ordered(1, &infile, &outfile); }
+    catch (const DiagnosedError& e) { std::cerr << e.diag; throw; }
 }
 
 void HashDupRemover::filterPE(const std::string& infile1, const std::string& infile2,
                               const std::string& outfile1, const std::string& outfile2, bool unordered)
 {
     const std::string in[2] = {infile1, infile2}, out[2] = {outfile1, outfile2};
-    if (unordered) run_unordered(in, out);
-    else           run_ordered(2, in, out);
+    try {
+        if (unordered) run_unordered(in, out);
+        else           run_ordered(2, in, out);
+    } catch (const DiagnosedError& e) { std::cerr << e.diag; throw; }
 }
 
 namespace {
@@ -411,9 +451,21 @@ void HashDupRemover::run_unordered(const std::string* in, const std::string* out
     HIP_OK(hipSetDevice(tuning_.device));
     // 1. load + index both files (the reference's ExternalSorter reads them fully too, hpp:161-173)
     LoadedFile file[2];
-    for (int s = 0; s < 2; ++s) {
-        load_whole_file(in[s], format_, tuning_.block_bytes, file[s]);
-        if (file[s].failure.set) { std::cerr << file[s].failure.diag; throw std::runtime_error(file[s].failure.what); }
+    {
+        // both files are read (and, for .gz, inflated) at the same time; problems are still
+        // reported in the reference's order: everything about file 1 before anything about file 2
+        std::exception_ptr err[2];
+        auto load = [&](int s) {
+            try { load_whole_file(in[s], format_, tuning_.block_bytes, file[s]); }
+            catch (...) { err[s] = std::current_exception(); }
+        };
+        std::thread second(load, 1);
+        load(0);
+        second.join();
+        for (int s = 0; s < 2; ++s) {
+            if (err[s]) std::rethrow_exception(err[s]);
+            if (file[s].failure.set) { std::cerr << file[s].failure.diag; throw std::runtime_error(file[s].failure.what); }
+        }
     }
 
     // 2. outputs are opened after the sort phase (hpp:265-266)

@@ -832,8 +832,11 @@ int fqd_partition_records(fqd_engine* e, const uint64_t* records, uint64_t n, ui
     hipLaunchKernelGGL(part_count_kernel, dim3(n_blocks), dim3(kBlock), n_parts * sizeof(uint32_t), e->stream,
                        records, n, rec_words, n_parts, c2, n_blocks);
     if ((rc = scan_exclusive(e, c2, cells, 0, nullptr))) return rc;
-    hipLaunchKernelGGL(part_scatter_kernel, dim3(n_blocks), dim3(kBlock), n_parts * 4 * sizeof(uint32_t), e->stream,
-                       records, n, rec_words, n_parts, static_cast<const uint64_t*>(c2), n_blocks, out, origin);
+    const size_t scatter_lds = size_t(kBlock) * rec_words * sizeof(uint64_t) + kBlock * sizeof(uint64_t) + size_t(n_parts) * 4 * sizeof(uint32_t);
+    if (scatter_lds > 64 * 1024) return e->fail(FQD_ERR_ARG, "fqd_partition_records: records too long for the staged partition");
+    const uint32_t rw_magic = rec_words > 1 ? uint32_t(((1ull << 32) + rec_words - 1) / rec_words) : 0xFFFFFFFFu;
+    hipLaunchKernelGGL(part_scatter_kernel, dim3(n_blocks), dim3(kBlock), scatter_lds, e->stream,
+                       records, n, rec_words, n_parts, static_cast<const uint64_t*>(c2), n_blocks, out, origin, rw_magic);
     hipLaunchKernelGGL(part_totals_kernel, dim3((n_parts + 63) / 64), dim3(64), 0, e->stream,
                        static_cast<const uint64_t*>(c2), n_parts, n_blocks, n, counts);
     HIP_TRY(e, hipGetLastError());

@@ -732,15 +732,27 @@ void part_count_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t re
     for (uint32_t p = threadIdx.x; p < n_parts; p += kBlock) counts2d[uint64_t(p) * n_blocks + blockIdx.x] = hist[p];
 }
 
+// The 256 records of a block are staged in LDS with coalesced loads, ranked per owner in input
+// order (wave ballots, so the partition is stable), and copied out word by word: consecutive
+// lanes write consecutive words, and records bound for one owner are neighbours in the output,
+// so the stores leave as runs instead of one scattered 8-byte store per lane.
+// LDS: 256*rec_words uint64 + 256 uint64 (destinations) + n_parts*4 uint32.  rw_magic = ceil(2^32/rec_words).
 __global__ __launch_bounds__(kBlock)
 void part_scatter_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t rec_words, uint32_t n_parts,
                          const uint64_t* __restrict__ starts2d, uint32_t n_blocks,
-                         uint64_t* __restrict__ out, uint32_t* __restrict__ origin)
+                         uint64_t* __restrict__ out, uint32_t* __restrict__ origin, uint32_t rw_magic)
 {
-    extern __shared__ uint32_t wave_cnt[];             // [n_parts][4 waves]
-    const uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x;
-    const bool live = i < n;
-    const uint32_t mine = live ? owner_of(rec[i * uint64_t(rec_words)], n_parts) : 0xFFFFFFFFu;
+    extern __shared__ __attribute__((aligned(16))) uint64_t ptile[];
+    uint64_t* dst_of = ptile + size_t(kBlock) * rec_words;
+    uint32_t* wave_cnt = reinterpret_cast<uint32_t*>(dst_of + kBlock);            // [n_parts][4 waves]
+    const uint64_t base = blockIdx.x * uint64_t(kBlock);
+    const uint32_t cnt = uint32_t(n - base < kBlock ? n - base : kBlock);
+    const uint32_t words = cnt * rec_words;
+    const uint64_t* src = rec + base * rec_words;
+    for (uint32_t w = threadIdx.x; w < words; w += kBlock) ptile[w] = src[w];
+    __syncthreads();
+    const bool live = threadIdx.x < cnt;
+    const uint32_t mine = live ? owner_of(ptile[threadIdx.x * rec_words], n_parts) : 0xFFFFFFFFu;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t rank_in_wave = 0;
     for (uint32_t p = 0; p < n_parts; ++p) {
@@ -753,10 +765,13 @@ void part_scatter_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t 
         uint32_t before = 0;
         for (int w = 0; w < wave; ++w) before += wave_cnt[mine * 4 + w];
         const uint64_t dst = starts2d[uint64_t(mine) * n_blocks + blockIdx.x] + before + rank_in_wave;
-        const uint64_t* s = rec + i * uint64_t(rec_words);
-        uint64_t* d = out + dst * uint64_t(rec_words);
-        for (uint32_t k = 0; k < rec_words; ++k) d[k] = s[k];
-        origin[dst] = uint32_t(i);
+        dst_of[threadIdx.x] = dst;
+        origin[dst] = uint32_t(base + threadIdx.x);
+    }
+    __syncthreads();
+    for (uint32_t w = threadIdx.x; w < words; w += kBlock) {
+        const uint32_t r = rec_words == 1u ? w : __umulhi(w, rw_magic), k = w - r * rec_words;
+        out[dst_of[r] * rec_words + k] = ptile[w];
     }
 }
 

@@ -352,3 +352,28 @@ def test_bad_base_before_malformed_record_wins(exe, oracle, tmp_path, capfd):
     assert err == "Fastq record should start with @ symbol!"
     assert r.returncode == 1 and "Fastq record should start with @ symbol!" in r.stderr
     assert got == exp == fastq([(b"1", b"ACGT")])
+
+
+@pytest.mark.gpu
+def test_unordered_tail_rule_fuzz_against_oracle(exe, oracle, tmp_path):
+    """Many tiny --unordered inputs (1..9 records per file, random overlaps) through the CLI and
+    the oracle: the reference's end-of-file rule and the full join must both agree
+    byte for byte, including the -v counts."""
+    rnd = random.Random(20260101)
+    seqs = [b"ACGT", b"GGCC", b"TTAA", b"ACGT", b"NNAC"]
+    for case in range(45):
+        ids = rnd.sample(range(1, 13), rnd.randrange(1, 10))
+        ids2 = rnd.sample(range(1, 13), rnd.randrange(1, 10))
+        def fa(idlist, salt):
+            return b"".join(b">%02d x\n%s\n" % (i, seqs[(i * salt) % len(seqs)]) for i in idlist)
+        f1, f2 = tmp_path / f"a{case}.fa", tmp_path / f"b{case}.fa"
+        f1.write_bytes(fa(ids, 1)); f2.write_bytes(fa(ids2, 3))
+        for full in ("0", "1"):
+            e1, e2, g1, g2 = (tmp_path / f"{x}{case}{full}" for x in ("e1", "e2", "g1", "g2"))
+            tot, dup, un = oracle.filter_paired(f1, f2, e1, e2, FASTA, unordered=True, tail_rule=(full == "0"))
+            r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--format", "fasta", "--fast", "--unordered", "-v",
+                    env={"FQD_FULL_JOIN": full})
+            assert r.returncode == 0, r.stderr
+            assert g1.read_bytes() == e1.read_bytes() and g2.read_bytes() == e2.read_bytes(), (ids, ids2, full)
+            assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
+                                f"{un} Non-matching entries from both files were skipped.\n"), (ids, ids2, full)

@@ -111,11 +111,12 @@ def main():
         from fastq_dupaway_amd.sharded import HipOps, ShardedDedup
         sharded = ShardedDedup(HipOps(eng), dist, dev, n_max=m, len0=L, len1=(L if S == 2 else 0))
 
+        round_list = [([Reads(bases[mate][lo * L:], uniform_len=L, uniform_stride=L) for mate in range(S)], cnt, keep[lo:])
+                      for lo, cnt in spans]
+
         def step():
             eng.reset()
-            for lo, cnt in spans:
-                sub = [Reads(bases[mate][lo * L:], uniform_len=L, uniform_stride=L) for mate in range(S)]
-                sharded.dedup(sub, cnt, keep[lo:])
+            sharded.dedup_rounds(round_list)
             eng.sync()
     else:
         def step():

@@ -86,6 +86,8 @@ def load_library():
     L.fqd_engine_reset.argtypes = [vp]
     L.fqd_submit.argtypes = [vp, C.POINTER(ReadsDesc), u64, i32, vp]
     L.fqd_engine_sync.argtypes = [vp]
+    L.fqd_engine_stream.argtypes = [vp]
+    L.fqd_engine_stream.restype = vp
     L.fqd_bad_base.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint8)]
     L.fqd_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.fqd_get_profile.argtypes = [vp, C.POINTER(Profile)]
@@ -104,7 +106,7 @@ def load_library():
     L.fqd_synth_reads.argtypes = [vp, u64, u64, u64, u32, u32, i32, vp, vp]
     for name in declared_symbols():
         fn = getattr(L, name)          # AttributeError here = header and library disagree
-        if name not in ("fqd_last_error", "fqd_key_words"):
+        if name not in ("fqd_last_error", "fqd_key_words", "fqd_engine_stream"):
             fn.restype = i32
     _lib = L
     return L

@@ -750,6 +750,8 @@ int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint
     return FQD_OK;
 }
 
+void* fqd_engine_stream(fqd_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
+
 int fqd_engine_sync(fqd_engine* e)
 {
     if (!e) return FQD_ERR_ARG;

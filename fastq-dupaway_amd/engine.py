@@ -93,6 +93,10 @@ class Engine:
     def sync(self):
         self._check(self._L.fqd_engine_sync(self._h))
 
+    def stream_handle(self) -> int:
+        """The engine's hipStream_t as an integer (wrap with torch.cuda.ExternalStream)."""
+        return int(self._L.fqd_engine_stream(self._h) or 0)
+
     # -- the hot path ---------------------------------------------------------------
     def submit(self, segs: Sequence[Reads], n: int, keep=None):
         """Dedups n more records; returns their keep flags (numpy for host input,

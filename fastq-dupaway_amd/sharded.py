@@ -56,6 +56,24 @@ class HipOps:
     def sync(self):
         self.e.sync()
 
+    def stream_handle(self):
+        return self.e.stream_handle()
+
+
+class _Round:
+    """Buffers of one round in flight (the pipeline keeps two)."""
+
+    def __init__(self, n_max, rw, world, cap_recv, device):
+        i64 = torch.int64
+        self.records = torch.empty(n_max * rw, dtype=i64, device=device)
+        self.grouped = torch.empty(n_max * rw, dtype=i64, device=device)
+        self.origin = torch.empty(n_max, dtype=torch.int32, device=device)
+        self.counts = torch.zeros(world, dtype=i64, device=device)
+        self.recv_counts = torch.zeros(world, dtype=i64, device=device)
+        self.keep_recv = torch.empty(cap_recv, dtype=torch.uint8, device=device)
+        self.keep_back = torch.empty(n_max, dtype=torch.uint8, device=device)
+        self.cap_recv = cap_recv
+
 
 class ShardedDedup:
     """dedup(segs, n, keep): keep[i] = 1 iff read i of THIS rank's batch is the first with its
@@ -110,6 +128,91 @@ class ShardedDedup:
         self._sync_comm()
         ops.scatter(self.keep_back, self.origin, n, keep)
         return n_recv
+
+    # ------------------------------------------------------------------------------------
+    def dedup_rounds(self, rounds):
+        """Runs several rounds [(segs, n, keep), ...] of one step.  On a GPU the rounds are
+        software-pipelined: the all-to-all of round k travels over xGMI while round k+1 is
+        encoded and partitioned and round k-1 is inserted (HBM-bound), ordered by events between
+        the engine's stream and a communication stream — the host only waits for the split
+        sizes.  Elsewhere (CPU tests) the rounds simply run one after the other."""
+        pipelined = (getattr(self.device, "type", "cpu") == "cuda" and hasattr(self.ops, "stream_handle")
+                     and self.in_place and len(rounds) > 1)
+        if not pipelined:
+            return [self.dedup(segs, n, keep) for segs, n, keep in rounds]
+        import os
+        if os.environ.get("FQD_SHARDED_PIPELINE", "1") == "0":
+            return [self.dedup(segs, n, keep) for segs, n, keep in rounds]
+        ops, dist, rw, dev = self.ops, self.dist, self.rw, self.device
+        if not hasattr(self, "_pipe"):
+            try:
+                self._s_e = torch.cuda.ExternalStream(ops.stream_handle(), device=dev)
+                self._s_c = torch.cuda.Stream(device=dev)
+            except Exception:                                 # no stream interop: keep the simple order
+                self.in_place = self.in_place and False
+                return [self.dedup(segs, n, keep) for segs, n, keep in rounds]
+            self._pipe = [_Round(self.n_max, rw, self.world, self.cap_recv, dev) for _ in range(2)]
+        s_e, s_c = self._s_e, self._s_c
+        R = len(rounds)
+        st = [dict() for _ in range(R)]
+
+        def encode(k):
+            segs, n, _ = rounds[k]
+            b = self._pipe[k % 2]
+            ops.encode(segs, n, b.records)
+            ops.partition(b.records, n, self.W, self.world, b.grouped, b.counts, b.origin)
+            st[k]["ev_p"] = torch.cuda.Event(); st[k]["ev_p"].record(s_e)
+
+        def exchange(k):
+            _, n, _ = rounds[k]
+            b = self._pipe[k % 2]
+            st[k]["ev_p"].synchronize()                       # host: the split sizes of round k are ready
+            with torch.cuda.stream(s_c):                      # reads ordered behind the collective on s_c
+                dist.all_to_all_single(b.recv_counts, b.counts)
+                send = [int(c) for c in b.counts.tolist()]
+                recv = [int(c) for c in b.recv_counts.tolist()]
+            n_recv = sum(recv)
+            if n_recv > b.cap_recv:
+                b.cap_recv = int(n_recv * 1.1) + 4096
+                b.keep_recv = torch.empty(b.cap_recv, dtype=torch.uint8, device=dev)
+            buf = ops.recv_buffer(n_recv, self.len0, self.len1, dev)     # tail of the key store, after insert(k-1)
+            s_c.wait_event(st[k]["ev_p"])
+            with torch.cuda.stream(s_c):
+                work = dist.all_to_all_single(buf[: n_recv * rw], b.grouped[: n * rw],
+                                              output_split_sizes=[c * rw for c in recv],
+                                              input_split_sizes=[c * rw for c in send], async_op=True)
+            st[k].update(send=send, recv=recv, n_recv=n_recv, buf=buf, work=work)
+
+        def insert(k):
+            b = self._pipe[k % 2]
+            with torch.cuda.stream(s_c):
+                st[k]["work"].wait()
+                ev = torch.cuda.Event(); ev.record(s_c)
+            s_e.wait_event(ev)                                # the engine's stream waits for the records
+            ops.insert(st[k]["buf"], st[k]["n_recv"], self.len0, self.len1, b.keep_recv)
+            st[k]["ev_i"] = torch.cuda.Event(); st[k]["ev_i"].record(s_e)
+
+        def give_back(k):
+            _, n, keep = rounds[k]
+            b = self._pipe[k % 2]
+            s_c.wait_event(st[k]["ev_i"])
+            with torch.cuda.stream(s_c):
+                dist.all_to_all_single(b.keep_back[:n], b.keep_recv[: st[k]["n_recv"]],
+                                       output_split_sizes=st[k]["send"], input_split_sizes=st[k]["recv"])
+                ev = torch.cuda.Event(); ev.record(s_c)
+            s_e.wait_event(ev)
+            ops.scatter(b.keep_back, b.origin, n, keep)
+
+        encode(0)
+        exchange(0)
+        for k in range(R):
+            if k + 1 < R:
+                encode(k + 1)                                 # runs under the all-to-all of round k
+            insert(k)
+            if k + 1 < R:
+                exchange(k + 1)                               # its all-to-all runs under insert(k)
+            give_back(k)
+        return [st[k]["n_recv"] for k in range(R)]
 
     def _sync_comm(self):
         if self.device is not None and getattr(self.device, "type", "cpu") == "cuda":

@@ -114,6 +114,10 @@ int  fqd_engine_reset(fqd_engine* e);
  * it completes: later batches cannot change them. */
 int  fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep);
 
+/* The hipStream_t the engine launches on (its own, or the one given in fqd_config), so a caller
+ * can order its own work — copies, collectives — against the engine's with events. */
+void* fqd_engine_stream(fqd_engine* e);
+
 /* Waits for the stream and surfaces deferred errors (FQD_ERR_BAD_BASE). */
 int  fqd_engine_sync(fqd_engine* e);
 

@@ -262,3 +262,35 @@ def test_insert_records_over_several_rounds(oracle, monkeypatch, in_place, bulk_
             e.sync()
         assert torch.equal(keep, expect)
         assert e.stats()["duplicates"] == int((expect == 0).sum().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_pipelined_rounds_under_rccl_single_rank(monkeypatch, pipeline):
+    """dedup_rounds with real RCCL collectives (one rank: the all-to-all is a copy to self) and the
+    real stream/event ordering between the engine's stream and the communication stream."""
+    import torch.distributed as dist
+    from fastq_dupaway_amd import Engine, Reads
+    from fastq_dupaway_amd.sharded import HipOps
+    monkeypatch.setenv("FQD_SHARDED_PIPELINE", pipeline)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    try:
+        n_per, rounds, LL = 1_500_000, 5, 150
+        n = n_per * rounds
+        with Engine(segments=1, capacity_reads=n) as e:
+            bases = torch.empty(n * LL + 16, dtype=torch.uint8, device=dev)
+            expect = torch.empty(n, dtype=torch.uint8, device=dev)
+            e.synth_reads(31, 0, n, LL, 250, 0, bases, expect)
+            e.sync()
+            sd = ShardedDedup(HipOps(e), dist, dev, n_max=n_per, len0=LL)
+            keep = torch.zeros(n, dtype=torch.uint8, device=dev)
+            for step in range(2):                            # two steps: buffers and events are reused
+                e.reset(); keep.zero_()
+                sd.dedup_rounds([([Reads(bases[k * n_per * LL:], uniform_len=LL, uniform_stride=LL)], n_per, keep[k * n_per:])
+                                 for k in range(rounds)])
+                e.sync()
+                assert torch.equal(keep, expect), f"step {step}"
+    finally:
+        dist.destroy_process_group()

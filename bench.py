@@ -89,12 +89,13 @@ def main():
     eng = Engine(segments=S, device=local, capacity_reads=n, capacity_bases=S * n * L, profile=True)
     sharded_mode = dist is not None
     # Sharded runs move a step's reads in rounds sized so that no rank-to-rank message of the
-    # all-to-all exceeds 512 MiB (72-byte records for 150 bp).  Measured on this image (RCCL 2.26.6,
-    # torch 2.10): a single all_to_all_single message above 1 GiB arrives corrupted.  The
+    # all-to-all exceeds 256 MiB (72-byte records for 150 bp): 4 rounds per step on 8 GPUs, enough for
+    # the round pipeline to hide most of the exchange.  Measured on this image (RCCL 2.26.6, torch
+    # 2.10): a single all_to_all_single message above 1 GiB arrives corrupted.  The
     # job's input order is (round, rank, position) — file blocks dealt round-robin to the ranks —
     # so round k of rank r holds the global indices below.
     rec_bytes = 8 * (1 + S * ((L + 31) // 32 + (L + 63) // 64))
-    rounds = max(1, -(-(n * rec_bytes // world) // (512 << 20))) if sharded_mode else 1
+    rounds = max(1, -(-(n * rec_bytes // world) // (256 << 20))) if sharded_mode else 1
     if sharded_mode and os.environ.get("FQD_BENCH_ROUNDS"):
         rounds = int(os.environ["FQD_BENCH_ROUNDS"])
     m = -(-n // rounds)

@@ -12,7 +12,7 @@ HEADER = REPO_ROOT / "include" / "fqdupaway.h"
 
 OK, ERR_ARG, ERR_HIP, ERR_BAD_BASE, ERR_CAPACITY, ERR_NO_DEVICE = range(6)
 MEM_HOST, MEM_DEVICE = 0, 1
-FLAG_PROFILE, FLAG_NO_STAGE = 1, 2
+FLAG_PROFILE, FLAG_NO_STAGE, FLAG_WEAK_HASH = 1, 2, 4
 
 
 class FqdError(RuntimeError):

@@ -234,6 +234,7 @@ int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
         hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(e, e->slots)), dim3(kBlock), 0, e->stream,
                            e->table.as<uint64_t>(), e->slots, static_cast<uint64_t*>(nt), want - 1,
                            (1ull << new_seg_bits) - 1, ks, e->L0, e->L1, uint32_t(e->S == 2),
+                           (e->flags & FQD_FLAG_WEAK_HASH) ? 0x00000000FFFFFFC0ull : ~0ull,
                            reinterpret_cast<unsigned long long*>(e->d_state + 1));
         e->table_clear = false; e->table_stale = false;
     } else {
@@ -304,8 +305,9 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
                   hipStream_t stream = nullptr, uint32_t blocks_per_cu = 8, const Hist1* fold = nullptr)
 {
     if (!stream) stream = e->stream;
-    Hist1 h1{nullptr, BulkGeom{0, 0, 0, 0}};
-    if (fold) h1 = *fold;
+    const uint64_t hash_and = (e->flags & FQD_FLAG_WEAK_HASH) ? 0x00000000FFFFFFC0ull : ~0ull;
+    Hist1 h1{nullptr, BulkGeom{0, 0, 0, 0}, hash_and};
+    if (fold) { h1 = *fold; h1.hash_and = hash_and; }
     Bracket br(e, K_ENCODE, n, stream);
     const StagedChoice c = choose_staged(e, seg, uniform, ks);
     uint64_t* err = e->d_state;
@@ -704,7 +706,7 @@ int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint
     BulkPlan plan;
     if (bulk_applies(e, n) && (rc = bulk_plan(e, n, plan))) return rc;
     if (plan.ok) {
-        const Hist1 fold{plan.hist1, plan.g};
+        const Hist1 fold{plan.hist1, plan.g, ~0ull};
         static const bool fold_on = [] { const char* v = std::getenv("FQD_FOLD_HIST1"); return !(v && v[0] == '0'); }();
         if ((rc = launch_encode(e, sv, uniform, seg, n, first, ks, e->hashes.as<uint64_t>(), nullptr, 8, fold_on ? &fold : nullptr))) return rc;
         if ((rc = launch_bulk_insert(e, ks, e->hashes.as<uint64_t>(), 1, n, first, d_keep, plan, fold_on))) return rc;

@@ -50,6 +50,7 @@ __device__ __forceinline__ uint32_t bucket_of(uint64_t hash, const BulkGeom& g) 
 struct Hist1 {
     uint32_t* hist;        // 256 global counters, or nullptr
     BulkGeom  g;
+    uint64_t  hash_and;    // ANDed onto every hash: all ones, except under FQD_FLAG_TEST_WEAK_HASH
 };
 // Per-block LDS histogram helpers shared by the three encoders.
 __device__ __forceinline__ void hist1_clear(uint32_t* lh) { for (uint32_t k = threadIdx.x; k < 256u; k += blockDim.x) lh[k] = 0; __syncthreads(); }
@@ -108,6 +109,7 @@ void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_id
         } else {
             h = hash_end(h);
         }
+        h &= h1.hash_and;
         if (hash_out) hash_out[i] = h;
         else          ks.slot(first_idx + i)[-1] = h;
         if (h1.hist) atomicAdd(&lhist[bucket_of(h, h1.g) >> h1.g.bits2], 1u);
@@ -172,14 +174,14 @@ void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
                 uint64_t* out = row;
                 auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
                 diff = pack_mate(lds + (b0 >> 2), b0 & 3u, l0, sink);
-                h = hash_end(h);
+                h = hash_end(h) & h1.hash_and;
                 if (hash_out) hash_out[i] = h; else row[-1] = h;
             } else {
                 uint64_t* out = ks.slot(first_idx + i);
                 if (ks.koff) *out++ = uint64_t(l0);
                 auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
                 diff = pack_mate(lds + (b0 >> 2), b0 & 3u, l0, sink);
-                h = hash_end(h);
+                h = hash_end(h) & h1.hash_and;
                 if (hash_out) hash_out[i] = h; else ks.slot(first_idx + i)[-1] = h;
             }
             if (h1.hist) atomicAdd(&lhist[bucket_of(h, h1.g) >> h1.g.bits2], 1u);
@@ -267,7 +269,7 @@ void encode_staged_pe_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_
         }
         const uint64_t other = __shfl_xor(h, 1, 64);               // the partner lane's chain
         if (live && !mate) {
-            const uint64_t hh = hash_pair(h, other);
+            const uint64_t hh = hash_pair(h, other) & h1.hash_and;
             if (hash_out) hash_out[i] = hh;
             else if (LDS_OUT) row[-1] = hh;
             else ks.slot(first_idx + i)[-1] = hh;
@@ -388,7 +390,8 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, uint64_t se
 __global__ __launch_bounds__(kBlock)
 void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
                    uint64_t* __restrict__ new_table, uint64_t new_mask, uint64_t new_seg_mask, KeyStore ks,
-                   uint32_t len0, uint32_t len1, uint32_t paired, unsigned long long* __restrict__ counters /* [1] = table-full */)
+                   uint32_t len0, uint32_t len1, uint32_t paired, uint64_t hash_and,
+                   unsigned long long* __restrict__ counters /* [1] = table-full */)
 {
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(new_table);
     for (uint64_t s = blockIdx.x * uint64_t(kBlock) + threadIdx.x; s < old_slots; s += uint64_t(gridDim.x) * kBlock) {
@@ -408,6 +411,7 @@ void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
         } else {
             h = hash_end(h);
         }
+        h &= hash_and;
         const unsigned long long mine = ((h >> 32) << 32) | idx;
         uint64_t pos = h & new_mask;
         uint64_t probe = 0;                                  // bounded: a full segment is reported, never spun on

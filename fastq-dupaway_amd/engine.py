@@ -53,11 +53,12 @@ class Engine:
     """One HBM-resident exact sequence set on one MI355X (struct fqd_engine)."""
 
     def __init__(self, segments: int = 1, device: int = 0, capacity_reads: int = 0, capacity_bases: int = 0,
-                 stream: Optional[int] = None, profile: bool = False, no_stage: bool = False):
+                 stream: Optional[int] = None, profile: bool = False, no_stage: bool = False, weak_hash: bool = False):
         self._L = load_library()
         cfg = _lib.Config(device=device, segments=segments, capacity_reads=capacity_reads,
                           capacity_bases=capacity_bases, stream=stream,
-                          flags=(_lib.FLAG_PROFILE if profile else 0) | (_lib.FLAG_NO_STAGE if no_stage else 0))
+                          flags=(_lib.FLAG_PROFILE if profile else 0) | (_lib.FLAG_NO_STAGE if no_stage else 0)
+                          | (_lib.FLAG_WEAK_HASH if weak_hash else 0))
         h = C.c_void_p()
         rc = self._L.fqd_engine_create(C.byref(cfg), C.byref(h))
         if rc != _lib.OK:

@@ -49,6 +49,9 @@ extern "C" {
 /* fqd_config.flags */
 #define FQD_FLAG_PROFILE    1u  /* bracket every kernel with HIP events (fqd_profile) */
 #define FQD_FLAG_NO_STAGE   2u  /* testing: force the per-lane global-load encoder    */
+#define FQD_FLAG_WEAK_HASH  4u  /* testing: zero every hash's tag and its low 6 position bits,
+                                   so unequal keys keep meeting in the table and the
+                                   verify-then-probe-on branch runs on every insert    */
 
 typedef struct fqd_engine fqd_engine;
 

@@ -326,3 +326,30 @@ def test_bulk_and_atomic_insert_paths_agree(oracle, monkeypatch, paired):
                     got.append(e.submit(segs, b - a))
                 assert e.stats()["duplicates"] == int((exp == 0).sum())
             assert np.array_equal(np.concatenate(got), exp), (bulk_min, cuts)
+
+
+# ---- forced collisions: the verify-mismatch-then-probe-on branch -------------------------------------
+
+@pytest.mark.parametrize("bulk_min", ["0", "-1"])
+@pytest.mark.parametrize("paired", [False, True])
+def test_forced_tag_collisions_stay_exact(oracle, monkeypatch, bulk_min, paired):
+    """With FQD_FLAG_WEAK_HASH every hash loses its tag and its low position bits, so unequal keys
+    collide constantly: each insert meets occupied slots whose tag 'matches', must compare the
+    full keys, find them different and keep probing (and wrap inside its segment).  Results must
+    still be exact, on both insert paths, across batches and a table rehash."""
+    monkeypatch.setenv("FQD_BULK_MIN", bulk_min)
+    rng = np.random.default_rng(99)
+    n, L = 120_000, 75
+    S = 2 if paired else 1
+    pools = [rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=(n // 3, L)) for _ in range(S)]
+    mates = [np.concatenate([pools[m][rng.integers(0, len(pools[m]), n)].reshape(-1), np.zeros(16, np.uint8)]) for m in range(S)]
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(L); lens = np.full(n, L, np.uint32)
+    exp = (oracle.dedup_paired(mates[0], offs, lens, mates[1], offs, lens) if paired
+           else oracle.dedup_single(mates[0], offs, lens))
+    got = []
+    with Engine(segments=S, weak_hash=True) as e:            # no capacity hint: grows and rehashes with the weak hash too
+        for a, b in ((0, 20_000), (20_000, 21_000), (21_000, n)):
+            segs = [Reads(mates[m][a * L:], uniform_len=L, uniform_stride=L) for m in range(S)]
+            got.append(e.submit(segs, b - a))
+        assert e.stats()["duplicates"] == int((exp == 0).sum())
+    assert np.array_equal(np.concatenate(got), exp)

@@ -382,6 +382,7 @@ struct BulkPlan {
     uint32_t *hist2 = nullptr, *start2 = nullptr, *cursor2 = nullptr;
     ulonglong2 *recA = nullptr, *recB = nullptr;
     uint16_t *bucket16 = nullptr;
+    uint32_t *heavy_flag = nullptr;
 };
 
 // Geometry + scratch of one bulk insert; zeroes the counters on the engine's stream.
@@ -405,6 +406,7 @@ int bulk_plan(fqd_engine* e, uint64_t n, BulkPlan& p)
     uint32_t* m = e->bulk_meta.as<uint32_t>();
     p.hist1 = m; p.start1 = m + 256; p.cursor1 = m + 520; p.tile_start1 = m + 780;
     p.hist2 = m + 1100; p.start2 = p.hist2 + p.n_buckets; p.cursor2 = p.start2 + p.n_buckets + 4;
+    p.heavy_flag = m + 1090;                                   // zeroed with the rest of meta
     p.recA = e->bulk_recs.as<ulonglong2>();
     p.recB = reinterpret_cast<ulonglong2*>(e->bulk_recs.as<char>() + rec_bytes);
     p.bucket16 = p.g.bits2 ? reinterpret_cast<uint16_t*>(e->bulk_recs.as<char>() + 2 * rec_bytes) : nullptr;
@@ -461,15 +463,22 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
     if (const char* v = std::getenv("FQD_DEDUP_THREADS")) dthreads = uint32_t(std::min(1024, std::max(64, std::atoi(v))));
     const uint32_t dgrid = std::min<uint32_t>(n_buckets, uint32_t(e->n_cu) * uint32_t(std::max<size_t>(1, (150 * 1024) / lds)));
     unsigned long long* counters = reinterpret_cast<unsigned long long*>(e->d_state + 1);
+    uint32_t heavy_above = 4u << e->seg_bits;                   // far beyond what a segment can hold at <= 50 % load
+    if (const char* v = std::getenv("FQD_HEAVY_ABOVE")) heavy_above = uint32_t(std::max(0, std::atoi(v)));
     if (fresh) {
         if (lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_dedup_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         hipLaunchKernelGGL(bucket_dedup_kernel<true>, dim3(dgrid), dim3(dthreads), lds, e->stream,
-                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, ks, uint32_t(first_idx), keep, counters);
+                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, ks, uint32_t(first_idx), keep, counters,
+                           heavy_above, p.heavy_flag);
     } else {
         if (lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_dedup_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         hipLaunchKernelGGL(bucket_dedup_kernel<false>, dim3(dgrid), dim3(dthreads), lds, e->stream,
-                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, ks, uint32_t(first_idx), keep, counters);
+                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, ks, uint32_t(first_idx), keep, counters,
+                           heavy_above, p.heavy_flag);
     }
+    hipLaunchKernelGGL(heavy_bucket_insert_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
+                       final_recs, bstart, n, g, e->table.as<uint64_t>(), ks, uint32_t(first_idx), keep, counters,
+                       heavy_above, static_cast<const uint32_t*>(p.heavy_flag));
     HIP_TRY(e, hipGetLastError());
     e->table_clear = false; e->table_stale = false;
     return FQD_OK;

@@ -607,7 +607,8 @@ template <bool FRESH>
 __global__ __launch_bounds__(1024)
 void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __restrict__ bstart, uint32_t n_buckets,
                          uint64_t* __restrict__ table, uint32_t seg_bits, KeyStore ks, uint32_t first_idx,
-                         uint8_t* __restrict__ keep, unsigned long long* __restrict__ counters)
+                         uint8_t* __restrict__ keep, unsigned long long* __restrict__ counters,
+                         uint32_t heavy_above, uint32_t* __restrict__ heavy_flag)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long seg[];
     const uint32_t seg_slots = 1u << seg_bits, seg_mask = seg_slots - 1u;
@@ -616,6 +617,14 @@ void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __
         unsigned long long* gseg = reinterpret_cast<unsigned long long*>(table) + uint64_t(b) * seg_slots;
         const uint32_t lo = bstart[b], hi = bstart[b + 1];
         if (!FRESH && lo == hi) continue;                     // nothing to add: leave the segment alone
+        if (hi - lo > heavy_above) {
+            // A bucket swollen by one massively repeated key (poly-G reads, adapter dimers) would
+            // pin a single workgroup for the whole batch: leave it to heavy_bucket_insert_kernel,
+            // which spreads its records over the chip with the atomic path.
+            if (FRESH) for (uint32_t k = threadIdx.x; k < seg_slots; k += blockDim.x) gseg[k] = kEmptySlot;
+            if (threadIdx.x == 0) *heavy_flag = 1u;
+            continue;
+        }
         for (uint32_t k = threadIdx.x; k < seg_slots; k += blockDim.x) seg[k] = FRESH ? kEmptySlot : gseg[k];
         __syncthreads();
         for (uint32_t r = lo + threadIdx.x; r < hi; r += blockDim.x) {
@@ -643,6 +652,51 @@ void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < seg_slots; k += blockDim.x) gseg[k] = seg[k];
         __syncthreads();
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { dups += __shfl_down(dups, d, 64); lost += __shfl_down(lost, d, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (dups) atomicAdd(&counters[0], static_cast<unsigned long long>(dups));
+        if (lost) atomicAdd(&counters[1], static_cast<unsigned long long>(lost));
+    }
+}
+
+// Second half of the skew guard: records of buckets the LDS kernel skipped go through the
+// device-atomic protocol of insert_kernel.  Launched after every bulk dedup; when no bucket was
+// heavy every workgroup returns on its first instruction.
+__global__ __launch_bounds__(kBlock)
+void heavy_bucket_insert_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __restrict__ bstart, uint64_t n,
+                                BulkGeom g, uint64_t* __restrict__ table, KeyStore ks, uint32_t first_idx,
+                                uint8_t* __restrict__ keep, unsigned long long* __restrict__ counters,
+                                uint32_t heavy_above, const uint32_t* __restrict__ heavy_flag)
+{
+    if (*heavy_flag == 0u) return;
+    unsigned long long* tab = reinterpret_cast<unsigned long long*>(table);
+    const uint64_t seg_mask = (1ull << g.seg_bits) - 1ull;
+    uint32_t dups = 0, lost = 0;
+    for (uint64_t r = blockIdx.x * uint64_t(kBlock) + threadIdx.x; r < n; r += uint64_t(gridDim.x) * kBlock) {
+        const ulonglong2 v = recs[r];
+        const uint32_t b = bucket_of(v.x, g);
+        if (bstart[b + 1] - bstart[b] <= heavy_above) continue;
+        const uint32_t idx = uint32_t(v.y);
+        const uint64_t tag = v.x >> 32;
+        const unsigned long long mine = (tag << 32) | idx;
+        uint64_t pos = v.x & g.slot_mask;
+        bool placed = false;
+        for (uint64_t probe = 0; probe <= seg_mask; ++probe) {
+            const unsigned long long old = atomicCAS(&tab[pos], kEmptySlot, mine);
+            if (old == kEmptySlot) { placed = true; break; }
+            if ((old >> 32) == tag && keys_equal(ks, idx, uint32_t(old))) {
+                uint32_t owner = uint32_t(old);
+                if (owner > idx) owner = uint32_t(atomicMin(&tab[pos], mine));
+                if (owner < idx) keep[idx - first_idx] = 0;
+                else             keep[owner - first_idx] = 0;
+                ++dups; placed = true;
+                break;
+            }
+            pos = (pos & ~seg_mask) | ((pos + 1) & seg_mask);
+        }
+        if (!placed) ++lost;
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { dups += __shfl_down(dups, d, 64); lost += __shfl_down(lost, d, 64); }

@@ -353,3 +353,47 @@ def test_forced_tag_collisions_stay_exact(oracle, monkeypatch, bulk_min, paired)
             got.append(e.submit(segs, b - a))
         assert e.stats()["duplicates"] == int((exp == 0).sum())
     assert np.array_equal(np.concatenate(got), exp)
+
+
+# ---- skew: one key repeated massively, and very long reads ---------------------------------------
+
+@pytest.mark.parametrize("bulk_min", ["0", "-1", None])
+def test_massively_repeated_key(oracle, monkeypatch, torch_cuda, bulk_min):
+    """Poly-G style input: one sequence makes up most of the batch.  The bulk path must hand the
+    swollen bucket to the atomic protocol (heavy_bucket_insert_kernel) and stay exact."""
+    torch = torch_cuda
+    if bulk_min is not None:
+        monkeypatch.setenv("FQD_BULK_MIN", bulk_min)
+    rng = np.random.default_rng(4)
+    n, L = 1_500_000, 60
+    pool = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(5000, L))
+    pool[0, :] = ord("G")
+    pick = rng.integers(1, 5000, size=n)
+    pick[rng.random(n) < 0.7] = 0                              # 70 % of the reads are the same poly-G
+    data = np.concatenate([pool[pick].reshape(-1), np.zeros(16, np.uint8)])
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(L)
+    exp = oracle.dedup_single(data, offs, np.full(n, L, np.uint32))
+    with Engine(segments=1, capacity_reads=n) as e:
+        keep = e.submit([Reads(data, uniform_len=L, uniform_stride=L)], n)
+        assert e.stats()["duplicates"] == int((exp == 0).sum())
+    assert np.array_equal(keep, exp)
+
+
+def test_very_long_and_empty_reads(oracle):
+    rng = np.random.default_rng(12)
+    pool = [bytes(rng.choice(list(b"ACGTN"), size=int(L)).astype(np.uint8)) for L in (0, 1, 5000, 5001, 20000, 20000, 65, 3)]
+    reads = [pool[int(rng.integers(0, len(pool)))] for _ in range(400)]
+    reads[7] = reads[5][:-1] + (b"A" if reads[5][-1:] != b"A" else b"C") if len(reads[5]) else reads[7]
+    d, o, l = ragged_arrays(reads)
+    with Engine(segments=1) as e:
+        keep = e.submit([Reads(d, o, l)], len(reads))
+    assert np.array_equal(keep, oracle_keep(oracle, reads))
+    # uniform long reads: too long for the LDS tile -> per-lane encoder
+    L = 3000
+    block = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(50, L))
+    pick = rng.integers(0, 50, size=2000)
+    data = np.concatenate([block[pick].reshape(-1), np.zeros(16, np.uint8)])
+    with Engine(segments=1) as e:
+        keep = e.submit([Reads(data, uniform_len=L, uniform_stride=L)], 2000)
+    exp = oracle.dedup_single(data, np.arange(2000, dtype=np.uint64) * np.uint64(L), np.full(2000, L, np.uint32))
+    assert np.array_equal(keep, exp)

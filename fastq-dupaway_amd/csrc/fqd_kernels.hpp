@@ -603,6 +603,21 @@ void bulk_scan_buckets_kernel(const uint32_t* __restrict__ count, uint32_t nb, u
 
 // One workgroup per table segment.  FRESH: the segment is known to be empty (engine just reset):
 // it is built in LDS from scratch and written out, so the table needs no clearing pass.
+//
+// A chunk of the segment's records goes through three phases, so that the two random 64-byte
+// key gathers a duplicate needs are never waited for one record at a time (measured: with the
+// verification inline, every loop iteration of every wave paid a full gather round trip and
+// 20 M duplicates cost 1.6 ms of a 2.6 ms kernel):
+//   1. probe: every lane walks its records through the LDS table (CAS on EMPTY claims; a tag
+//      match is only QUEUED as a candidate (record, slot));
+//   2. verify: eight lanes per candidate load one key word each of the record and of the slot's
+//      current owner — whole lines, dozens of candidates in flight per wave — and lane 0 applies
+//      the verdict (atomicMin / keep flags) or queues a retry from the next slot;
+//   3. retry (rare: a tag matched an unequal key): per-lane probing with inline verification.
+// LDS: segment (2^seg_bits * 8 B) + 2 queues of kDedupChunk uint32 + 2 counters.
+constexpr uint32_t kDedupChunk = 1536;
+constexpr uint32_t kDedupFly = 4;
+
 template <bool FRESH>
 __global__ __launch_bounds__(1024)
 void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __restrict__ bstart, uint32_t n_buckets,
@@ -612,7 +627,36 @@ void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long seg[];
     const uint32_t seg_slots = 1u << seg_bits, seg_mask = seg_slots - 1u;
+    uint32_t* queue = reinterpret_cast<uint32_t*>(seg + seg_slots);      // (record in chunk << 16) | slot
+    uint32_t* retry = queue + kDedupChunk;
+    uint32_t* qn = retry + kDedupChunk;                                   // qn[0] candidates, qn[1] retries
     uint32_t dups = 0, lost = 0;
+
+    // One record's walk from `pos`: claims, or (inline == false) queues the first tag match,
+    // or (inline == true) verifies tag matches on the spot.
+    auto walk = [&](const ulonglong2 v, uint32_t c, uint32_t pos, bool verify_inline) {
+        const uint32_t idx = uint32_t(v.y);
+        const uint64_t tag = v.x >> 32;
+        const unsigned long long mine = (tag << 32) | idx;
+        for (uint32_t probe = 0; probe < seg_slots; ++probe) {
+            const unsigned long long old = atomicCAS(&seg[pos], kEmptySlot, mine);
+            if (old == kEmptySlot) return;
+            if ((old >> 32) == tag) {
+                if (!verify_inline) { queue[atomicAdd(&qn[0], 1u)] = (c << 16) | pos; return; }
+                if (keys_equal(ks, idx, uint32_t(old))) {
+                    uint32_t owner = uint32_t(old);
+                    if (owner > idx) owner = uint32_t(atomicMin(&seg[pos], mine));
+                    if (owner < idx) keep[idx - first_idx] = 0;
+                    else             keep[owner - first_idx] = 0;
+                    ++dups;
+                    return;
+                }
+            }
+            pos = (pos + 1u) & seg_mask;
+        }
+        ++lost;
+    };
+
     for (uint32_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
         unsigned long long* gseg = reinterpret_cast<unsigned long long*>(table) + uint64_t(b) * seg_slots;
         const uint32_t lo = bstart[b], hi = bstart[b + 1];
@@ -626,28 +670,73 @@ void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __
             continue;
         }
         for (uint32_t k = threadIdx.x; k < seg_slots; k += blockDim.x) seg[k] = FRESH ? kEmptySlot : gseg[k];
-        __syncthreads();
-        for (uint32_t r = lo + threadIdx.x; r < hi; r += blockDim.x) {
-            const ulonglong2 v = recs[r];
-            const uint32_t idx = uint32_t(v.y);
-            const uint64_t tag = v.x >> 32;
-            const unsigned long long mine = (tag << 32) | idx;
-            uint32_t pos = uint32_t(v.x) & seg_mask;
-            bool placed = false;
-            for (uint32_t probe = 0; probe < seg_slots; ++probe) {
-                const unsigned long long old = atomicCAS(&seg[pos], kEmptySlot, mine);
-                if (old == kEmptySlot) { placed = true; break; }
-                if ((old >> 32) == tag && keys_equal(ks, idx, uint32_t(old))) {
-                    uint32_t owner = uint32_t(old);
-                    if (owner > idx) owner = uint32_t(atomicMin(&seg[pos], mine));
-                    if (owner < idx) keep[idx - first_idx] = 0;
-                    else             keep[owner - first_idx] = 0;
-                    ++dups; placed = true;
-                    break;
-                }
-                pos = (pos + 1u) & seg_mask;
+        for (uint32_t chunk_lo = lo; chunk_lo < hi; chunk_lo += kDedupChunk) {
+            const uint32_t chunk_n = hi - chunk_lo < kDedupChunk ? hi - chunk_lo : kDedupChunk;
+            if (threadIdx.x == 0) { qn[0] = 0; qn[1] = 0; }
+            __syncthreads();
+            // 1. probe
+            for (uint32_t c = threadIdx.x; c < chunk_n; c += blockDim.x) {
+                const ulonglong2 v = recs[chunk_lo + c];
+                walk(v, c, uint32_t(v.x) & seg_mask, false);
             }
-            if (!placed) ++lost;
+            __syncthreads();
+            // 2. verify, eight lanes per candidate, kDedupFly candidates per group in flight
+            const uint32_t n_cand = qn[0];
+            const uint32_t grp = threadIdx.x >> 3, n_grp = blockDim.x >> 3, sub = threadIdx.x & 7u;
+            for (uint32_t q0 = grp; q0 < n_cand; q0 += n_grp * kDedupFly) {
+                uint32_t pos[kDedupFly], idx[kDedupFly], seen[kDedupFly], tag[kDedupFly];
+                uint64_t diff[kDedupFly];
+                uint32_t cc[kDedupFly];
+                bool live[kDedupFly];
+#pragma unroll
+                for (uint32_t u = 0; u < kDedupFly; ++u) {        // issue every load of the batch first
+                    const uint32_t q = q0 + u * n_grp;
+                    live[u] = q < n_cand;
+                    diff[u] = 0; pos[u] = 0; idx[u] = 0; seen[u] = 0; tag[u] = 0; cc[u] = 0;
+                    if (live[u]) {
+                        const uint32_t ent = queue[q];
+                        cc[u] = ent >> 16; pos[u] = ent & 0xFFFFu;
+                        const ulonglong2 v = recs[chunk_lo + cc[u]];
+                        idx[u] = uint32_t(v.y); tag[u] = uint32_t(v.x >> 32);
+                        seen[u] = uint32_t(seg[pos[u]]);      // the slot's owner right now: same key class for good
+                        const uint64_t* __restrict__ pa = ks.slot(idx[u]);
+                        const uint64_t* __restrict__ pb = ks.slot(seen[u]);
+                        uint32_t W = ks.W0;
+                        if (ks.koff) {
+                            const uint64_t ha = pa[0];
+                            diff[u] = ha ^ pb[0];             // mate lengths
+                            W = seg_words(uint32_t(ha)) + seg_words(uint32_t(ha >> 32));
+                            ++pa; ++pb;
+                        }
+                        if (!diff[u]) for (uint32_t w = sub; w < W; w += 8u) diff[u] |= pa[w] ^ pb[w];
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kDedupFly; ++u) {
+                    uint64_t d = diff[u];
+                    d |= __shfl_xor(d, 1, 64); d |= __shfl_xor(d, 2, 64); d |= __shfl_xor(d, 4, 64);
+                    if (live[u] && sub == 0u) {
+                        if (d == 0) {
+                            const unsigned long long mine = (uint64_t(tag[u]) << 32) | idx[u];
+                            uint32_t owner = seen[u];
+                            if (owner > idx[u]) owner = uint32_t(atomicMin(&seg[pos[u]], mine));
+                            if (owner < idx[u]) keep[idx[u] - first_idx] = 0;
+                            else                keep[owner - first_idx] = 0;
+                            ++dups;
+                        } else {
+                            retry[atomicAdd(&qn[1], 1u)] = (cc[u] << 16) | ((pos[u] + 1u) & seg_mask);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // 3. retry the few whose tag matched an unequal key
+            const uint32_t n_retry = qn[1];
+            for (uint32_t q = threadIdx.x; q < n_retry; q += blockDim.x) {
+                const uint32_t ent = retry[q];
+                walk(recs[chunk_lo + (ent >> 16)], ent >> 16, ent & 0xFFFFu, true);
+            }
+            __syncthreads();
         }
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < seg_slots; k += blockDim.x) gseg[k] = seg[k];

@@ -3,7 +3,9 @@
 #include <cerrno>
 #include <cstring>
 #include <fcntl.h>
+#include <algorithm>
 #include <iostream>
+#include <thread>
 #include <unistd.h>
 
 namespace fqdhost {
@@ -65,40 +67,100 @@ size_t InputFile::read(char* dst, size_t n)
     return got;
 }
 
+namespace {
+
+constexpr size_t kGzMember = 1u << 20;                   // uncompressed bytes per gzip member
+
+// One complete gzip member (header + deflate stream + CRC/length trailer) for `raw`.
+std::string deflate_member(std::string raw)
+{
+    z_stream zs{};
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK)
+        throw std::runtime_error("zlib: deflateInit2 failed");
+    std::string out(deflateBound(&zs, static_cast<uLong>(raw.size())) + 64, '\0');
+    zs.next_in = reinterpret_cast<Bytef*>(raw.data());
+    zs.avail_in = static_cast<uInt>(raw.size());
+    zs.next_out = reinterpret_cast<Bytef*>(out.data());
+    zs.avail_out = static_cast<uInt>(out.size());
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t produced = out.size() - zs.avail_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) throw std::runtime_error("zlib: deflate failed");
+    out.resize(produced);
+    return out;
+}
+
+} // namespace
+
 OutputFile::OutputFile(const std::string& name) : gz_(has_gz_extension(name)), name_(name)
 {
+    f_ = std::fopen(name.c_str(), "wb");
+    if (!f_) throw_cannot_open(name);
+    std::setvbuf(f_, nullptr, _IOFBF, 256 * 1024);
     if (gz_) {
-        g_ = gzopen(name.c_str(), "wb");                       // file_utils.cpp:87-88 (64 KiB buffers)
-        if (!g_) throw_cannot_open(name);
-        gzbuffer(g_, 64 * 1024);
-    } else {
-        f_ = std::fopen(name.c_str(), "wb");                   // file_utils.cpp:90 (256 KiB buffer)
-        if (!f_) throw_cannot_open(name);
-        std::setvbuf(f_, nullptr, _IOFBF, 256 * 1024);
+        block_.reserve(kGzMember + 65536);
+        const unsigned hw = std::thread::hardware_concurrency();
+        max_in_flight_ = hw >= 16 ? 8 : (hw >= 4 ? hw / 2 : 1);
     }
 }
 
-OutputFile::~OutputFile() { close(); }
+OutputFile::~OutputFile()
+{
+    try { close(); } catch (...) {}
+}
+
+void OutputFile::drain(size_t keep_in_flight)
+{
+    while (in_flight_.size() > keep_in_flight) {
+        const std::string member = in_flight_.front().get();
+        in_flight_.pop_front();
+        if (!member.empty() && std::fwrite(member.data(), 1, member.size(), f_) != member.size())
+            throw std::runtime_error("write failed: " + name_);
+    }
+}
+
+void OutputFile::submit_block()
+{
+    if (block_.empty()) return;
+    std::string raw;
+    raw.swap(block_);
+    block_.reserve(kGzMember + 65536);
+    in_flight_.push_back(std::async(std::launch::async, deflate_member, std::move(raw)));
+    drain(max_in_flight_);
+}
 
 void OutputFile::write(const char* p, size_t n)
 {
-    while (n) {
-        if (gz_) {
-            const unsigned chunk = static_cast<unsigned>(std::min<size_t>(n, 1u << 30));
-            if (gzwrite(g_, p, chunk) <= 0) throw std::runtime_error("write failed: " + name_);
-            p += chunk; n -= chunk;
-        } else {
+    if (!gz_) {
+        while (n) {
             const size_t k = std::fwrite(p, 1, n, f_);
             if (k == 0) throw std::runtime_error("write failed: " + name_);
             p += k; n -= k;
         }
+        return;
+    }
+    while (n) {
+        const size_t room = kGzMember > block_.size() ? kGzMember - block_.size() : 0;
+        const size_t k = std::min(n, std::max<size_t>(room, 1));
+        block_.append(p, k);
+        p += k; n -= k;
+        if (block_.size() >= kGzMember) submit_block();
     }
 }
 
 void OutputFile::close()
 {
-    if (g_) { gzclose(g_); g_ = nullptr; }
-    if (f_) { std::fclose(f_); f_ = nullptr; }
+    if (!f_) return;
+    if (gz_) {
+        submit_block();
+        drain(0);
+        if (std::ftell(f_) == 0) {                          // nothing was written: still a valid (empty) gzip file
+            const std::string member = deflate_member(std::string());
+            std::fwrite(member.data(), 1, member.size(), f_);
+        }
+    }
+    std::fclose(f_);
+    f_ = nullptr;
 }
 
 } // namespace fqdhost

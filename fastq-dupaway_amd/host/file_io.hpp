@@ -5,6 +5,8 @@
 #pragma once
 #include <cstddef>
 #include <cstdio>
+#include <deque>
+#include <future>
 #include <stdexcept>
 #include <string>
 #include <zlib.h>
@@ -38,6 +40,11 @@ private:
     bool gz_; gzFile g_ = nullptr; int fd_ = -1; bool eof_ = false;
 };
 
+// Plain files go through a 256 KiB stdio buffer (file_utils.cpp:90).  ".gz" files are written
+// as a sequence of independent gzip members, one per 1 MiB of output, deflated on worker threads
+// and written in order: the decompressed content is what the reference would have written
+// (file_utils.cpp:87-88; gzip readers concatenate members), the deflate work no longer runs on
+// one core.
 class OutputFile {
 public:
     explicit OutputFile(const std::string& name);
@@ -47,7 +54,12 @@ public:
     void write(const char* p, size_t n);
     void close();
 private:
-    bool gz_; gzFile g_ = nullptr; FILE* f_ = nullptr; std::string name_;
+    void submit_block();
+    void drain(size_t keep_in_flight);
+    bool gz_; FILE* f_ = nullptr; std::string name_;
+    std::string block_;                                   // gz: bytes of the member being filled
+    std::deque<std::future<std::string>> in_flight_;      // gz: members being deflated, oldest first
+    size_t max_in_flight_ = 8;
 };
 
 } // namespace fqdhost

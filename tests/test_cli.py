@@ -251,7 +251,8 @@ def test_unordered_fastq_matches_oracle_bytes(exe, oracle, tmp_path, style, full
 @pytest.mark.gpu
 def test_gz_in_and_out(exe, oracle, tmp_path):
     rnd = random.Random(61)
-    raw = fastq([(b"g%05d" % k, s) for k, s in enumerate(random_reads(rnd, 5000, 700, 30, 80))])
+    # > 4 MiB of output: several gzip members deflated on worker threads, written in order
+    raw = fastq([(b"g%05d" % k, s) for k, s in enumerate(random_reads(rnd, 60000, 30000, 30, 80))])
     src = tmp_path / "in.fq.gz"
     with gzip.open(src, "wb") as f:
         f.write(raw)
@@ -261,6 +262,11 @@ def test_gz_in_and_out(exe, oracle, tmp_path):
     r = run(exe, "-i", src, "-o", got, "--fast")
     assert r.returncode == 0, r.stderr
     assert gzip.open(got, "rb").read() == exp.read_bytes()
+    assert subprocess.run(["gzip", "-t", str(got)]).returncode == 0
+    # the oracle (zlib's gzread, as Boost's gzip_decompressor) reads the multi-member file back identically
+    again = tmp_path / "again.fq"
+    oracle.filter_single(got, again, FASTQ)
+    assert again.read_bytes() == exp.read_bytes()
 
 
 # ---------------------------------------------------------------- GPU: error behaviour

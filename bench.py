@@ -95,6 +95,9 @@ def main():
     # job's input order is (round, rank, position) — file blocks dealt round-robin to the ranks —
     # so round k of rank r holds the global indices below.
     rec_bytes = 8 * (1 + S * ((L + 31) // 32 + (L + 63) // 64))
+    lazy = sharded_mode and os.environ.get("FQD_SHARDED_LAZY") == "1"       # hashes first, keys only for candidates
+    if lazy:
+        rec_bytes = 16
     rounds = max(1, -(-(n * rec_bytes // world) // (256 << 20))) if sharded_mode else 1
     if sharded_mode and os.environ.get("FQD_BENCH_ROUNDS"):
         rounds = int(os.environ["FQD_BENCH_ROUNDS"])
@@ -108,7 +111,17 @@ def main():
     eng.sync()
     segs = [Reads(bases[mate], uniform_len=L, uniform_stride=L) for mate in range(S)]
 
-    if sharded_mode:
+    if lazy:
+        from fastq_dupaway_amd.sharded import LazyShardedDedup
+        owner = Engine(segments=1, device=local, capacity_reads=int(n * 1.1))
+        sharded = LazyShardedDedup(eng, owner, dist, dev, n_max=m, len0=L, len1=(L if S == 2 else 0))
+
+        def step():
+            eng.reset(); owner.reset(); sharded.reset()
+            for lo, cnt in spans:
+                sharded.dedup([Reads(bases[mate][lo * L:], uniform_len=L, uniform_stride=L) for mate in range(S)], cnt, keep[lo:])
+            eng.sync()
+    elif sharded_mode:
         from fastq_dupaway_amd.sharded import HipOps, ShardedDedup
         sharded = ShardedDedup(HipOps(eng), dist, dev, n_max=m, len0=L, len1=(L if S == 2 else 0))
 
@@ -141,6 +154,8 @@ def main():
             sys.exit(f"rank {rank}: keep flags differ from the generator's closed form — result invalid")
         parity = "keep flags == closed-form flags of the generator on every rank" if ok else "skipped (no warmup step)"
     eng.reset_profile()
+    if lazy and sharded.timing is not None:
+        sharded.timing.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -152,6 +167,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = eng.profile()
+    if lazy and rank == 0 and sharded.timing is not None:
+        print({k: round(v / a.steps, 3) for k, v in sharded.timing.items()}, file=sys.stderr)
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -189,7 +206,8 @@ def main():
                                        "100M single-end 150 bp FASTQ (~20% dups), --fast" if n == 100_000_000 else
                                        f"{n} {'pairs' if a.paired else 'reads'} x {L} bp per GPU"),
                           "reads_per_gpu": n, "read_len": L, "dup_fraction": a.dup_permille / 1000.0,
-                          "sharding": "none" if not sharded_mode else f"hash-prefix all-to-all over {world} GPU(s), {rounds} round(s) per step"},
+                          "sharding": "none" if not sharded_mode else f"hash-prefix all-to-all over {world} GPU(s), {rounds} round(s) per step"
+                                      + (", hashes first / keys for candidates only" if lazy else "")},
                "parity": parity, "roofline": roofline}
         if world == 1 and a.cpu_sample > 0:
             m = min(a.cpu_sample, n)

@@ -103,6 +103,15 @@ def load_library():
     L.fqd_sort_tags.argtypes = [vp, C.POINTER(TagsDesc), vp]
     L.fqd_match_sorted_tags.argtypes = [vp, C.POINTER(TagsDesc), vp, C.POINTER(TagsDesc), vp, vp]
     L.fqd_scatter_flags.argtypes = [vp, vp, vp, u64, vp]
+    L.fqd_encode_batch.argtypes = [vp, C.POINTER(ReadsDesc), u64, vp]
+    L.fqd_make_hash_records.argtypes = [vp, vp, u64, u64, vp]
+    L.fqd_reserve_hashes.argtypes = [vp, u64, C.POINTER(vp)]
+    L.fqd_insert_hashes.argtypes = [vp, vp, u64, vp, vp]
+    L.fqd_hash_replies.argtypes = [vp, u64, vp, vp, vp]
+    L.fqd_scatter_u64.argtypes = [vp, vp, vp, u64, vp]
+    L.fqd_build_requests.argtypes = [vp, vp, u64, u64, vp, u64, vp, C.POINTER(u64)]
+    L.fqd_verify_requests.argtypes = [vp, vp, u64, vp]
+    L.fqd_apply_replies.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
     L.fqd_synth_reads.argtypes = [vp, u64, u64, u64, u32, u32, i32, vp, vp]
     for name in declared_symbols():
         fn = getattr(L, name)          # AttributeError here = header and library disagree

@@ -59,6 +59,7 @@ struct fqd_engine {
     DevBuf   koff;                                   // ragged only: word offset per record
     bool     ragged = false, have_shape = false;
     bool     rec_layout = false;                     // keys kept as whole records [hash | key] (sharded engines)
+    bool     hash_layout = false;                    // hash engine: store of [hash | payload], keyed by the hash
     uint32_t L0 = 0, L1 = 0, W0 = 0;
     uint64_t n_records = 0;
     uint64_t cap_hint_reads = 0, cap_hint_bases = 0;
@@ -203,6 +204,7 @@ int scan_exclusive(fqd_engine* e, uint64_t* data, uint64_t n, uint64_t add, cons
 
 KeyStore key_store(const fqd_engine* e)
 {
+    if (e->hash_layout) return KeyStore{e->keys.as<uint64_t>(), nullptr, 1, 2, 0};
     if (e->rec_layout) return KeyStore{e->keys.as<uint64_t>(), nullptr, e->W0, e->W0 + 1, 1};
     return KeyStore{e->keys.as<uint64_t>(), e->ragged ? e->koff.as<uint64_t>() : nullptr, e->W0, e->W0, 0};
 }
@@ -233,8 +235,8 @@ int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
         const KeyStore ks = key_store(e);
         hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(e, e->slots)), dim3(kBlock), 0, e->stream,
                            e->table.as<uint64_t>(), e->slots, static_cast<uint64_t*>(nt), want - 1,
-                           (1ull << new_seg_bits) - 1, ks, e->L0, e->L1, uint32_t(e->S == 2),
-                           (e->flags & FQD_FLAG_WEAK_HASH) ? 0x00000000FFFFFFC0ull : ~0ull,
+                           (1ull << new_seg_bits) - 1, ks, e->L0, e->L1, uint32_t(e->S == 2), uint32_t(e->hash_layout),
+                           (e->hash_layout || !(e->flags & FQD_FLAG_WEAK_HASH)) ? ~0ull : 0x00000000FFFFFFC0ull,
                            reinterpret_cast<unsigned long long*>(e->d_state + 1));
         e->table_clear = false; e->table_stale = false;
     } else {
@@ -343,7 +345,8 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
 }
 
 int launch_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes, uint32_t hash_stride,
-                  uint64_t n, uint64_t first_idx, uint8_t* keep, bool preset_keep = true, uint32_t blocks_per_cu = 8)
+                  uint64_t n, uint64_t first_idx, uint8_t* keep, bool preset_keep = true, uint32_t blocks_per_cu = 8,
+                  uint32_t* first = nullptr)
 {
     if (e->table_stale) {
         Bracket br(e, K_OTHER, 0);
@@ -358,7 +361,8 @@ int launch_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes, uin
     Bracket br(e, K_INSERT, n);
     const uint32_t grid = uint32_t(std::min<uint64_t>(grid_for(e, n), uint64_t(e->n_cu) * blocks_per_cu));
     hipLaunchKernelGGL(insert_kernel, dim3(grid), dim3(kBlock), 0, e->stream,
-                       e->table.as<uint64_t>(), e->slots - 1, (1ull << e->seg_bits) - 1, ks, hashes, hash_stride, n, uint32_t(first_idx), keep,
+                       e->table.as<uint64_t>(), e->slots - 1, (1ull << e->seg_bits) - 1, ks, hashes, hash_stride, n,
+                       Verdicts{keep, first, uint32_t(first_idx)},
                        reinterpret_cast<unsigned long long*>(e->d_state + 1));
     HIP_TRY(e, hipGetLastError());
     return FQD_OK;
@@ -420,8 +424,10 @@ int bulk_plan(fqd_engine* e, uint64_t n, BulkPlan& p)
 
 // hist1_done: the encoder already folded the level-1 histogram into its own pass.
 int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes, uint32_t hash_stride,
-                       uint64_t n, uint64_t first_idx, uint8_t* keep, const BulkPlan& p, bool hist1_done)
+                       uint64_t n, uint64_t first_idx, uint8_t* keep, const BulkPlan& p, bool hist1_done,
+                       uint32_t* first = nullptr)
 {
+    const Verdicts verdicts{keep, first, uint32_t(first_idx)};
     const BulkGeom g = p.g;
     const uint32_t nd1 = p.nd1, n_buckets = p.n_buckets;
     uint32_t *hist1 = p.hist1, *start1 = p.start1, *cursor1 = p.cursor1, *tile_start1 = p.tile_start1;
@@ -468,16 +474,16 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
     if (fresh) {
         if (lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_dedup_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         hipLaunchKernelGGL(bucket_dedup_kernel<true>, dim3(dgrid), dim3(dthreads), lds, e->stream,
-                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, ks, uint32_t(first_idx), keep, counters,
+                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, ks, verdicts, counters,
                            heavy_above, p.heavy_flag);
     } else {
         if (lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_dedup_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         hipLaunchKernelGGL(bucket_dedup_kernel<false>, dim3(dgrid), dim3(dthreads), lds, e->stream,
-                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, ks, uint32_t(first_idx), keep, counters,
+                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, ks, verdicts, counters,
                            heavy_above, p.heavy_flag);
     }
     hipLaunchKernelGGL(heavy_bucket_insert_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
-                       final_recs, bstart, n, g, e->table.as<uint64_t>(), ks, uint32_t(first_idx), keep, counters,
+                       final_recs, bstart, n, g, e->table.as<uint64_t>(), ks, verdicts, counters,
                        heavy_above, static_cast<const uint32_t*>(p.heavy_flag));
     HIP_TRY(e, hipGetLastError());
     e->table_clear = false; e->table_stale = false;
@@ -614,19 +620,22 @@ int fqd_engine_reset(fqd_engine* e)
     e->h_state[0] = kNoError; e->h_state[1] = 0; e->h_state[2] = 0; e->h_state[3] = 0;
     HIP_TRY(e, hipMemcpyAsync(e->d_state, e->h_state, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    e->n_records = 0; e->keys_used = 0; e->ragged = false; e->have_shape = false; e->rec_layout = false;
+    e->n_records = 0; e->keys_used = 0; e->ragged = false; e->have_shape = false; e->rec_layout = false; e->hash_layout = false;
     e->L0 = e->L1 = e->W0 = 0; e->has_bad = false; e->last_error.clear();
     return FQD_OK;
 }
 
-int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep)
+// hashes_only != nullptr: encode-only mode (fqd_encode_batch): keys are stored, hashes go to the
+// caller, the set is not touched.
+static int submit_impl(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep, uint64_t* hashes_only)
 {
     if (!e) return FQD_ERR_ARG;
-    if (!seg || (n && !keep) || (memory != FQD_MEM_HOST && memory != FQD_MEM_DEVICE))
+    if (!seg || (n && !keep && !hashes_only) || (memory != FQD_MEM_HOST && memory != FQD_MEM_DEVICE))
         return e->fail(FQD_ERR_ARG, "fqd_submit: bad arguments");
     if (n == 0) return FQD_OK;
     if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
-    if (e->rec_layout) return e->fail(FQD_ERR_ARG, "fqd_submit: this engine holds pre-encoded records (fqd_insert_records)");
+    if (e->rec_layout || e->hash_layout)
+        return e->fail(FQD_ERR_ARG, "fqd_submit: this engine holds pre-encoded records (fqd_insert_records / fqd_insert_hashes)");
     HIP_TRY(e, hipSetDevice(e->device));
     int rc;
 
@@ -682,8 +691,8 @@ int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint
     }
 
     const uint64_t first = e->n_records;
-    if ((rc = ensure_table(e, first + n))) return rc;
-    if ((rc = reserve(e, e->hashes, n * sizeof(uint64_t)))) return rc;
+    if (!hashes_only && (rc = ensure_table(e, first + n))) return rc;
+    if (!hashes_only && (rc = reserve(e, e->hashes, n * sizeof(uint64_t)))) return rc;
 
     uint64_t new_words = 0;
     if (!e->ragged) {
@@ -712,6 +721,12 @@ int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint
     }
 
     KeyStore ks{e->keys.as<uint64_t>(), e->ragged ? e->koff.as<uint64_t>() : nullptr, e->W0, e->W0, 0};
+    if (hashes_only) {
+        if ((rc = launch_encode(e, sv, uniform, seg, n, first, ks, hashes_only))) return rc;
+        e->n_records += n;
+        e->keys_used += new_words;
+        return FQD_OK;
+    }
     BulkPlan plan;
     if (bulk_applies(e, n) && (rc = bulk_plan(e, n, plan))) return rc;
     if (plan.ok) {
@@ -762,6 +777,18 @@ int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint
 }
 
 void* fqd_engine_stream(fqd_engine* e) { return e ? static_cast<void*>(e->stream) : nullptr; }
+
+int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep)
+{
+    return submit_impl(e, seg, n, memory, keep, nullptr);
+}
+
+int fqd_encode_batch(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint64_t* hashes)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (n && !hashes) return e->fail(FQD_ERR_ARG, "fqd_encode_batch: bad arguments");
+    return submit_impl(e, seg, n, FQD_MEM_DEVICE, nullptr, hashes);
+}
 
 int fqd_engine_sync(fqd_engine* e)
 {
@@ -917,6 +944,159 @@ int fqd_scatter_flags(fqd_engine* e, const uint8_t* flags, const uint32_t* origi
     Bracket br(e, K_OTHER, 0);
     hipLaunchKernelGGL(scatter_flags_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream, flags, origin, n, keep_out);
     HIP_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+// ---- optimistic sharding --------------------------------------------------------------
+
+int fqd_make_hash_records(fqd_engine* e, const uint64_t* hashes, uint64_t n, uint64_t payload_base, uint64_t* out)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (n && (!hashes || !out)) return e->fail(FQD_ERR_ARG, "fqd_make_hash_records: bad arguments");
+    if (n == 0) return FQD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    Bracket br(e, K_OTHER, 0);
+    hipLaunchKernelGGL(make_hash_records_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
+                       hashes, n, payload_base, reinterpret_cast<ulonglong2*>(out));
+    HIP_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+// Shape, table and store capacity of a hash engine for n more records.
+static int prepare_hashes(fqd_engine* e, uint64_t n)
+{
+    if (e->S != 1) return e->fail(FQD_ERR_ARG, "hash engines are created with segments = 1");
+    if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (!e->have_shape) { e->have_shape = true; e->ragged = false; e->hash_layout = true; e->L0 = e->L1 = 0; e->W0 = 1; }
+    else if (!e->hash_layout) return e->fail(FQD_ERR_ARG, "fqd_insert_hashes: engine already holds sequence keys");
+    int rc;
+    if ((rc = ensure_table(e, e->n_records + n))) return rc;
+    const uint64_t need = e->keys_used + 2 * n;
+    return reserve(e, e->keys, std::max<uint64_t>(need, 64) * sizeof(uint64_t), e->keys_used * sizeof(uint64_t));
+}
+
+int fqd_reserve_hashes(fqd_engine* e, uint64_t n, uint64_t** slot)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!slot) return e->fail(FQD_ERR_ARG, "fqd_reserve_hashes: bad arguments");
+    const int rc = prepare_hashes(e, n);
+    if (rc) return rc;
+    *slot = e->keys.as<uint64_t>() + e->keys_used;
+    return FQD_OK;
+}
+
+int fqd_insert_hashes(fqd_engine* e, const uint64_t* records, uint64_t n, uint8_t* keep, uint32_t* first)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (n && (!records || !keep)) return e->fail(FQD_ERR_ARG, "fqd_insert_hashes: bad arguments");
+    if (n == 0) return FQD_OK;
+    int rc;
+    if ((rc = prepare_hashes(e, n))) return rc;
+    const uint64_t first_idx = e->n_records;
+    uint64_t* tail = e->keys.as<uint64_t>() + e->keys_used;
+    if (records != tail) {
+        Bracket br(e, K_OTHER, 0);
+        HIP_TRY(e, hipMemcpyAsync(tail, records, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream));
+    }
+    const KeyStore ks = key_store(e);                         // key word = the hash itself
+    BulkPlan plan;
+    if (bulk_applies(e, n) && (rc = bulk_plan(e, n, plan))) return rc;
+    if (plan.ok) { if ((rc = launch_bulk_insert(e, ks, tail, 2, n, first_idx, keep, plan, false, first))) return rc; }
+    else if ((rc = launch_insert(e, ks, tail, 2, n, first_idx, keep, true, 8, first))) return rc;
+    e->n_records += n; e->keys_used += 2 * n;
+    return FQD_OK;
+}
+
+int fqd_hash_replies(fqd_engine* e, uint64_t n, const uint8_t* keep, const uint32_t* first, uint64_t* reply)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!e->hash_layout || (n && (!keep || !first || !reply)) || n > e->n_records)
+        return e->fail(FQD_ERR_ARG, "fqd_hash_replies: bad arguments");
+    if (n == 0) return FQD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    Bracket br(e, K_OTHER, 0);
+    hipLaunchKernelGGL(hash_replies_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
+                       reinterpret_cast<const ulonglong2*>(e->keys.as<uint64_t>()), uint32_t(e->n_records - n), n, keep, first, reply);
+    HIP_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+int fqd_scatter_u64(fqd_engine* e, const uint64_t* vals, const uint32_t* origin, uint64_t n, uint64_t* out)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (n && (!vals || !origin || !out)) return e->fail(FQD_ERR_ARG, "fqd_scatter_u64: bad arguments");
+    if (n == 0) return FQD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    Bracket br(e, K_OTHER, 0);
+    hipLaunchKernelGGL(scatter_u64_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream, vals, origin, n, out);
+    HIP_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+int fqd_build_requests(fqd_engine* e, const uint64_t* reply, uint64_t n, uint64_t local_base,
+                       uint64_t* req, uint64_t req_capacity, uint32_t* req_local, uint64_t* count)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!count || (n && !reply) || e->ragged || e->rec_layout || e->hash_layout || !e->have_shape ||
+        local_base + n > e->n_records || n > 0xFFFFFFFFull)
+        return e->fail(FQD_ERR_ARG, "fqd_build_requests: needs a uniform engine filled by fqd_encode_batch");
+    *count = 0;
+    if (n == 0) return FQD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    const uint32_t n_blocks = uint32_t((n + kReqChunk - 1) / kReqChunk);
+    int rc = reserve(e, e->part_scratch, uint64_t(n_blocks) * sizeof(uint64_t));
+    if (rc) return rc;
+    uint64_t* blocks = e->part_scratch.as<uint64_t>();
+    const uint64_t* d_total = nullptr;
+    {
+        Bracket br(e, K_OTHER, 0);
+        hipLaunchKernelGGL(count_requests_kernel, dim3(n_blocks), dim3(kBlock), 0, e->stream, reply, n, blocks);
+        if ((rc = scan_exclusive(e, blocks, n_blocks, 0, &d_total))) return rc;
+    }
+    HIP_TRY(e, hipMemcpyAsync(&e->h_state[3], d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    *count = e->h_state[3];
+    if (*count > req_capacity) return e->fail(FQD_ERR_CAPACITY, "fqd_build_requests: more requests than req_capacity");
+    if (*count == 0) return FQD_OK;
+    if (!req || !req_local) return e->fail(FQD_ERR_ARG, "fqd_build_requests: bad arguments");
+    Bracket br(e, K_OTHER, 0);
+    hipLaunchKernelGGL(build_requests_kernel, dim3(n_blocks), dim3(kBlock), 0, e->stream,
+                       reply, n, uint32_t(local_base), key_store(e), static_cast<const uint64_t*>(blocks), req, req_local);
+    HIP_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+int fqd_verify_requests(fqd_engine* e, const uint64_t* req, uint64_t m, uint8_t* verdict)
+{
+    if (!e) return FQD_ERR_ARG;
+    if ((m && (!req || !verdict)) || e->ragged || e->rec_layout || e->hash_layout || !e->have_shape)
+        return e->fail(FQD_ERR_ARG, "fqd_verify_requests: needs a uniform engine filled by fqd_encode_batch");
+    if (m == 0) return FQD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    Bracket br(e, K_OTHER, 0);
+    hipLaunchKernelGGL(verify_requests_kernel, dim3(grid_for(e, m)), dim3(kBlock), 0, e->stream, req, m, key_store(e), verdict);
+    HIP_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+int fqd_apply_replies(fqd_engine* e, const uint64_t* reply, uint64_t n, uint8_t* keep,
+                      const uint8_t* verdict, uint64_t m, uint64_t* refuted)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!refuted || (n && (!reply || !keep)) || (m && !verdict)) return e->fail(FQD_ERR_ARG, "fqd_apply_replies: bad arguments");
+    if (n == 0 && m == 0) return FQD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    unsigned long long* d_count = reinterpret_cast<unsigned long long*>(e->d_state + 3);
+    {
+        Bracket br(e, K_OTHER, 0);
+        HIP_TRY(e, hipMemsetAsync(d_count, 0, sizeof(uint64_t), e->stream));
+        hipLaunchKernelGGL(apply_replies_kernel, dim3(grid_for(e, std::max(n, m))), dim3(kBlock), 0, e->stream,
+                           reply, n, keep, verdict, m, d_count);
+    }
+    HIP_TRY(e, hipMemcpyAsync(&e->h_state[3], d_count, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    *refuted += e->h_state[3];
     return FQD_OK;
 }
 

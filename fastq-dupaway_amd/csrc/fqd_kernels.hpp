@@ -39,6 +39,20 @@ struct KeyStore {
     { return keys + (koff ? koff[j] : j * uint64_t(stride) + lead); }
 };
 
+// Where a batch's verdicts go.  keep[] is preset to 1 and only ever cleared; `first`, when given
+// (hash engines of the optimistic sharded exchange), names an earlier record with the same key
+// for every cleared flag.
+struct Verdicts {
+    uint8_t*  keep;
+    uint32_t* first;       // may be nullptr
+    uint32_t  first_idx;   // engine index of keep[0]
+    __device__ __forceinline__ void lose(uint32_t loser, uint32_t winner) const
+    {
+        keep[loser - first_idx] = 0;
+        if (first) first[loser - first_idx] = winner;
+    }
+};
+
 // Geometry of the bulk (partitioned) insert, see bulk_* kernels below.  The encoders can fold
 // the level-1 histogram of that path into their own pass (Hist1: hist == nullptr -> off).
 struct BulkGeom {
@@ -347,14 +361,14 @@ __device__ __forceinline__ bool keys_equal(const KeyStore& ks, uint32_t a, uint3
 __global__ __launch_bounds__(kBlock)
 void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, uint64_t seg_mask, KeyStore ks,
                    const uint64_t* __restrict__ hashes, uint32_t hash_stride,
-                   uint64_t n, uint32_t first_idx, uint8_t* __restrict__ keep,
+                   uint64_t n, Verdicts out,
                    unsigned long long* __restrict__ counters /* [0]=dups [1]=table-full */)
 {
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(table);
     uint32_t dups = 0, lost = 0;
     for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
         const uint64_t h = hashes[i * uint64_t(hash_stride)];
-        const uint32_t idx = first_idx + uint32_t(i);
+        const uint32_t idx = out.first_idx + uint32_t(i);
         const uint64_t tag = h >> 32;
         const unsigned long long mine = (tag << 32) | idx;
         uint64_t pos = h & slot_mask;
@@ -367,8 +381,8 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, uint64_t se
                 // table needs no update; only an owner younger than me has to be displaced.
                 uint32_t owner = uint32_t(old);
                 if (owner > idx) owner = uint32_t(atomicMin(&tab[pos], mine));
-                if (owner < idx) keep[i] = 0;                       // an earlier record holds this key
-                else             keep[owner - first_idx] = 0;       // I am earlier: the displaced one loses
+                if (owner < idx) out.lose(idx, owner);              // an earlier record holds this key
+                else             out.lose(owner, idx);              // I am earlier: the displaced one loses
                 ++dups;
                 placed = true;
                 break;
@@ -390,7 +404,7 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, uint64_t se
 __global__ __launch_bounds__(kBlock)
 void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
                    uint64_t* __restrict__ new_table, uint64_t new_mask, uint64_t new_seg_mask, KeyStore ks,
-                   uint32_t len0, uint32_t len1, uint32_t paired, uint64_t hash_and,
+                   uint32_t len0, uint32_t len1, uint32_t paired, uint32_t key_is_hash, uint64_t hash_and,
                    unsigned long long* __restrict__ counters /* [1] = table-full */)
 {
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(new_table);
@@ -404,7 +418,9 @@ void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
         const uint32_t w0 = seg_words(l0);
         uint64_t h = hash_begin(l0, 0);
         for (uint32_t k = 0; k < w0; ++k) h = hash_word(h, p[k]);
-        if (paired) {                                         // second chain, then combine
+        if (key_is_hash) {                                    // hash engines: the stored key IS the placement hash
+            h = p[0];
+        } else if (paired) {                                         // second chain, then combine
             uint64_t h1 = hash_begin(l1, 0);
             for (uint32_t k = w0; k < W; ++k) h1 = hash_word(h1, p[k]);
             h = hash_pair(h, h1);
@@ -621,8 +637,8 @@ constexpr uint32_t kDedupFly = 4;
 template <bool FRESH>
 __global__ __launch_bounds__(1024)
 void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __restrict__ bstart, uint32_t n_buckets,
-                         uint64_t* __restrict__ table, uint32_t seg_bits, KeyStore ks, uint32_t first_idx,
-                         uint8_t* __restrict__ keep, unsigned long long* __restrict__ counters,
+                         uint64_t* __restrict__ table, uint32_t seg_bits, KeyStore ks, Verdicts out,
+                         unsigned long long* __restrict__ counters,
                          uint32_t heavy_above, uint32_t* __restrict__ heavy_flag)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long seg[];
@@ -646,8 +662,8 @@ void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __
                 if (keys_equal(ks, idx, uint32_t(old))) {
                     uint32_t owner = uint32_t(old);
                     if (owner > idx) owner = uint32_t(atomicMin(&seg[pos], mine));
-                    if (owner < idx) keep[idx - first_idx] = 0;
-                    else             keep[owner - first_idx] = 0;
+                    if (owner < idx) out.lose(idx, owner);
+                    else             out.lose(owner, idx);
                     ++dups;
                     return;
                 }
@@ -720,8 +736,8 @@ void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __
                             const unsigned long long mine = (uint64_t(tag[u]) << 32) | idx[u];
                             uint32_t owner = seen[u];
                             if (owner > idx[u]) owner = uint32_t(atomicMin(&seg[pos[u]], mine));
-                            if (owner < idx[u]) keep[idx[u] - first_idx] = 0;
-                            else                keep[owner - first_idx] = 0;
+                            if (owner < idx[u]) out.lose(idx[u], owner);
+                            else                out.lose(owner, idx[u]);
                             ++dups;
                         } else {
                             retry[atomicAdd(&qn[1], 1u)] = (cc[u] << 16) | ((pos[u] + 1u) & seg_mask);
@@ -755,8 +771,8 @@ void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __
 // heavy every workgroup returns on its first instruction.
 __global__ __launch_bounds__(kBlock)
 void heavy_bucket_insert_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __restrict__ bstart, uint64_t n,
-                                BulkGeom g, uint64_t* __restrict__ table, KeyStore ks, uint32_t first_idx,
-                                uint8_t* __restrict__ keep, unsigned long long* __restrict__ counters,
+                                BulkGeom g, uint64_t* __restrict__ table, KeyStore ks, Verdicts out,
+                                unsigned long long* __restrict__ counters,
                                 uint32_t heavy_above, const uint32_t* __restrict__ heavy_flag)
 {
     if (*heavy_flag == 0u) return;
@@ -778,8 +794,8 @@ void heavy_bucket_insert_kernel(const ulonglong2* __restrict__ recs, const uint3
             if ((old >> 32) == tag && keys_equal(ks, idx, uint32_t(old))) {
                 uint32_t owner = uint32_t(old);
                 if (owner > idx) owner = uint32_t(atomicMin(&tab[pos], mine));
-                if (owner < idx) keep[idx - first_idx] = 0;
-                else             keep[owner - first_idx] = 0;
+                if (owner < idx) out.lose(idx, owner);
+                else             out.lose(owner, idx);
                 ++dups; placed = true;
                 break;
             }
@@ -939,6 +955,130 @@ void scatter_flags_kernel(const uint8_t* __restrict__ flags, const uint32_t* __r
 {
     for (uint64_t k = blockIdx.x * uint64_t(kBlock) + threadIdx.x; k < n; k += uint64_t(gridDim.x) * kBlock)
         keep_out[origin[k]] = flags[k];
+}
+
+// ---------------------------------------------------------------------------
+// Optimistic sharded exchange ("hashes first, keys only for candidate duplicates").
+constexpr uint64_t kNoReply = 0xFFFFFFFFFFFFFFFFull;
+
+// records[i] = [hashes[i] | payload_base + i]
+__global__ __launch_bounds__(kBlock)
+void make_hash_records_kernel(const uint64_t* __restrict__ hashes, uint64_t n, uint64_t payload_base, ulonglong2* __restrict__ out)
+{
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock)
+        out[i] = ulonglong2{hashes[i], payload_base + i};
+}
+
+// Owner: reply[j] = kNoReply when record first_idx+j was the first with its hash, else the payload
+// of THE first record with that hash.  first[j] names the record that beat j in the table; that
+// one may have been displaced later in the same batch by a still earlier record, so the chain is
+// followed (indices strictly fall) to the record that kept its flag or came with an earlier batch.
+__global__ __launch_bounds__(kBlock)
+void hash_replies_kernel(const ulonglong2* __restrict__ store, uint32_t first_idx, uint64_t n, const uint8_t* __restrict__ keep,
+                         const uint32_t* __restrict__ first, uint64_t* __restrict__ reply)
+{
+    for (uint64_t j = blockIdx.x * uint64_t(kBlock) + threadIdx.x; j < n; j += uint64_t(gridDim.x) * kBlock) {
+        if (keep[j]) { reply[j] = kNoReply; continue; }
+        uint32_t f = first[j];
+        while (f >= first_idx && !keep[f - first_idx]) f = first[f - first_idx];
+        reply[j] = store[f].y;
+    }
+}
+
+__global__ __launch_bounds__(kBlock)
+void scatter_u64_kernel(const uint64_t* __restrict__ vals, const uint32_t* __restrict__ origin, uint64_t n, uint64_t* __restrict__ out)
+{
+    for (uint64_t k = blockIdx.x * uint64_t(kBlock) + threadIdx.x; k < n; k += uint64_t(gridDim.x) * kBlock)
+        out[origin[k]] = vals[k];
+}
+
+// Source: every local read whose reply names an earlier holder becomes a request
+// [reply | its own key words]; req_local remembers which read asked.  Requests keep the order of
+// the reads: a block owns kReqChunk consecutive reads, count_requests_kernel leaves the number of
+// candidates per block (scanned by the host code into block offsets), build_requests_kernel
+// ranks the candidates inside the block with wave ballots.
+constexpr uint32_t kReqChunk = kBlock * 16;
+
+__global__ __launch_bounds__(kBlock)
+void count_requests_kernel(const uint64_t* __restrict__ reply, uint64_t n, uint64_t* __restrict__ block_counts)
+{
+    __shared__ uint32_t wave_sum[kBlock / 64];
+    const uint64_t lo = blockIdx.x * uint64_t(kReqChunk);
+    uint32_t c = 0;
+    for (uint32_t t = threadIdx.x; t < kReqChunk; t += kBlock) {
+        const uint64_t i = lo + t;
+        c += (i < n && reply[i] != kNoReply) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < kBlock / 64; ++w) tot += wave_sum[w];
+        block_counts[blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(kBlock)
+void build_requests_kernel(const uint64_t* __restrict__ reply, uint64_t n, uint32_t local_base, KeyStore ks,
+                           const uint64_t* __restrict__ block_offsets, uint64_t* __restrict__ req, uint32_t* __restrict__ req_local)
+{
+    __shared__ uint32_t wave_cnt[kBlock / 64];
+    const uint32_t rw = ks.W0 + 1u;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lo = blockIdx.x * uint64_t(kReqChunk);
+    uint64_t at = block_offsets[blockIdx.x];
+    for (uint32_t t = 0; t < kReqChunk; t += kBlock) {
+        const uint64_t i = lo + t + threadIdx.x;
+        const uint64_t r = i < n ? reply[i] : kNoReply;
+        const bool cand = r != kNoReply;
+        const uint64_t mask = __ballot(cand);
+        if (lane == 0) wave_cnt[wave] = uint32_t(__popcll(mask));
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < kBlock / 64; ++w) { const uint32_t c = wave_cnt[w]; before += w < wave ? c : 0u; total += c; }
+        if (cand) {
+            const uint64_t k = at + before + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+            uint64_t* dst = req + k * rw;
+            const uint64_t* key = ks.slot(local_base + uint32_t(i));
+            dst[0] = r;
+            for (uint32_t q = 0; q < ks.W0; ++q) dst[1u + q] = key[q];
+            req_local[k] = uint32_t(i);
+        }
+        at += total;
+        __syncthreads();
+    }
+}
+
+// Holder: verdict[j] = 1 iff the carried key equals the local key the request names.
+__global__ __launch_bounds__(kBlock)
+void verify_requests_kernel(const uint64_t* __restrict__ req, uint64_t m, KeyStore ks, uint8_t* __restrict__ verdict)
+{
+    const uint32_t rw = ks.W0 + 1u;
+    for (uint64_t j = blockIdx.x * uint64_t(kBlock) + threadIdx.x; j < m; j += uint64_t(gridDim.x) * kBlock) {
+        const uint64_t* r = req + j * rw;
+        const uint64_t* key = ks.slot(uint32_t(r[0] & 0xFFFFFFFFFFull));
+        uint64_t d = 0;
+        for (uint32_t k = 0; k < ks.W0; ++k) d |= key[k] ^ r[1u + k];
+        verdict[j] = d == 0 ? 1 : 0;
+    }
+}
+
+// Source: keep[i] = 1 iff no earlier record had read i's hash; every refuted verdict (two unequal
+// keys with one 64-bit hash) is counted: the caller must then redo the step with full keys.
+__global__ __launch_bounds__(kBlock)
+void apply_replies_kernel(const uint64_t* __restrict__ reply, uint64_t n, uint8_t* __restrict__ keep,
+                          const uint8_t* __restrict__ verdict, uint64_t m, unsigned long long* __restrict__ refuted)
+{
+    uint32_t bad = 0;
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < (n > m ? n : m); i += uint64_t(gridDim.x) * kBlock) {
+        if (i < n) keep[i] = reply[i] == kNoReply ? 1 : 0;
+        if (i < m && !verdict[i]) ++bad;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) bad += __shfl_down(bad, d, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(refuted, static_cast<unsigned long long>(bad));
 }
 
 // ---------------------------------------------------------------------------

@@ -217,3 +217,201 @@ class ShardedDedup:
     def _sync_comm(self):
         if self.device is not None and getattr(self.device, "type", "cpu") == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
+
+
+
+class LazyShardedDedup:
+    """Optimistic exchange (include/fqdupaway.h, "optimistic sharding"): every rank keeps its
+    keys, owners dedup by the 64-bit hash alone, and only candidate duplicates are checked key
+    against key at the rank that holds the earlier record.  Per read this moves 16 B (hash +
+    payload) out and 8 B (reply) back, plus key + 8 B out and 1 B back per candidate, instead of
+    hash + key out and 1 B back for every read.
+
+    `local` is an Engine used as this rank's key store (fqd_encode_batch), `owner` a second Engine
+    (segments = 1) used as hash engine.  Results are exact: a candidate whose key differs from
+    the earlier record's (two keys, one hash) goes to a small replicated side set that holds
+    every such key in global order, so it is still compared with all earlier keys it could equal.
+    Global order is (call, rank, position), as in ShardedDedup."""
+
+    MAX_MESSAGE = 256 << 20                                  # bytes per peer in one all-to-all (see DESIGN §5)
+
+    def __init__(self, local, owner, dist, device, n_max: int, len0: int, len1: int = 0, slack: float = 1.15):
+        self.local, self.owner, self.dist, self.device = local, owner, dist, device
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.len0, self.len1 = len0, len1
+        self.W = local.key_words(len0, len1)
+        self.rw = self.W + 1
+        self.n_max = n_max
+        i64, i32, u8 = torch.int64, torch.int32, torch.uint8
+        dev = device
+        self.hashes = torch.empty(n_max, dtype=i64, device=dev)
+        self.rec16 = torch.empty(2 * n_max, dtype=i64, device=dev)
+        self.grouped16 = torch.empty(2 * n_max, dtype=i64, device=dev)
+        self.origin = torch.empty(n_max, dtype=i32, device=dev)
+        self.counts = torch.zeros(self.world, dtype=i64, device=dev)
+        self.recv_counts = torch.zeros(self.world, dtype=i64, device=dev)
+        self.reply_back = torch.empty(n_max, dtype=i64, device=dev)
+        self.reply_orig = torch.empty(n_max, dtype=i64, device=dev)
+        self.req_local = torch.empty(n_max, dtype=i32, device=dev)
+        self.verdict_back = torch.empty(n_max, dtype=u8, device=dev)
+        self._owner_side(int(n_max * slack) + 4096)
+        self.req = self.greq = self.origin2 = self.recv_req = self.verdict = None
+        self.local_base = 0                                  # records this rank has encoded so far
+        import os
+        self.timing = {} if os.environ.get("FQD_LAZY_TIMING") == "1" else None   # host-side ms per phase
+        self.side = set()                                    # keys that lost their hash slot to another key
+        self.stats = {"reads": 0, "requests": 0, "refuted": 0, "bytes_out": 0}
+
+    def _t(self, name):
+        if self.timing is not None:
+            import time
+            now = time.perf_counter()
+            self.timing[name] = self.timing.get(name, 0.0) + (now - self._t0) * 1e3
+            self._t0 = now
+
+    def reset(self):
+        """Forget everything (the caller resets the two engines)."""
+        self.local_base = 0
+        self.side.clear()
+        self.stats = dict.fromkeys(self.stats, 0)
+
+    def _owner_side(self, cap):
+        self.cap_recv = cap
+        self.keep_o = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        self.first_o = torch.empty(cap, dtype=torch.int32, device=self.device)
+        self.reply_o = torch.empty(cap, dtype=torch.int64, device=self.device)
+
+    def _request_side(self, cnt):
+        if self.req is None or self.req.numel() < cnt * self.rw:
+            cap = int(cnt * 1.25) + 1024
+            self.req = torch.empty(cap * self.rw, dtype=torch.int64, device=self.device)
+            self.greq = torch.empty(cap * self.rw, dtype=torch.int64, device=self.device)
+            self.origin2 = torch.empty(cap, dtype=torch.int32, device=self.device)
+            self.verdict_grouped = torch.empty(cap, dtype=torch.uint8, device=self.device)
+
+    def _holder_side(self, m):
+        if self.recv_req is None or self.recv_req.numel() < m * self.rw:
+            cap = int(m * 1.25) + 1024
+            self.recv_req = torch.empty(cap * self.rw, dtype=torch.int64, device=self.device)
+            self.verdict = torch.empty(cap, dtype=torch.uint8, device=self.device)
+
+    def _sync(self):
+        if getattr(self.device, "type", "cpu") == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def _exchange_counts(self):
+        self.dist.all_to_all_single(self.recv_counts, self.counts)
+        return [int(c) for c in self.counts.tolist()], [int(c) for c in self.recv_counts.tolist()]
+
+    def dedup(self, segs: Sequence, n: int, keep) -> int:
+        """One round: keep[i] (device uint8, n) for this rank's batch.  Returns the number of
+        candidate duplicates this rank had checked."""
+        L, O, dist, rw = self.local, self.owner, self.dist, self.rw
+        if n > self.n_max:
+            raise ValueError("batch larger than the buffers this LazyShardedDedup was built for")
+        if self.local_base + n >= 1 << 32:
+            raise ValueError("more than 2^32 records on one rank")
+        base = self.local_base
+        if self.timing is not None:
+            import time
+            self._t0 = time.perf_counter()
+        # 1. keys stay here; [hash | (rank, index)] travels to the owner of the hash
+        L.encode_batch(segs, n, self.hashes)
+        L.make_hash_records(self.hashes, n, (self.rank << 40) | base, self.rec16)
+        L.partition_records(self.rec16, n, 1, self.world, self.grouped16, self.counts, self.origin)
+        L.sync(); self._t("encode+part16")
+        send, recv = self._exchange_counts()
+        n_recv = sum(recv)
+        if n_recv > self.cap_recv:
+            self._owner_side(int(n_recv * 1.1) + 4096)
+        buf = torch.as_tensor(_DeviceWords(O.reserve_hashes(n_recv), max(1, 2 * n_recv)), device=self.device)
+        dist.all_to_all_single(buf[: 2 * n_recv], self.grouped16[: 2 * n],
+                               output_split_sizes=[2 * c for c in recv], input_split_sizes=[2 * c for c in send])
+        self._sync(); self._t("a2a hashes")
+        # 2. owners dedup by hash; the answer is "first" or where the earlier record lives
+        O.insert_hashes(buf, n_recv, self.keep_o, self.first_o)
+        O.hash_replies(n_recv, self.keep_o, self.first_o, self.reply_o)
+        O.sync(); self._t("insert_hashes+replies")
+        dist.all_to_all_single(self.reply_back[:n], self.reply_o[:n_recv], output_split_sizes=send, input_split_sizes=recv)
+        self._sync()
+        L.scatter_u64(self.reply_back, self.origin, n, self.reply_orig)
+        # 3. candidates are checked key against key at the holder of the earlier record
+        L.sync(); self._t("a2a replies+scatter")
+        self._request_side(max(1024, n // 4) if self.req is None else 0)
+        cnt, fits = L.build_requests(self.reply_orig, n, base, self.req, self.req.numel() // rw, self.req_local)
+        if not fits:
+            self._request_side(cnt)
+            cnt, fits = L.build_requests(self.reply_orig, n, base, self.req, self.req.numel() // rw, self.req_local)
+        self._t("build_requests")
+        self._check_requests(cnt); self._t("check_requests")
+        # 4. flags; refuted candidates (rare: two keys, one hash) go through the side set
+        refuted = L.apply_replies(self.reply_orig, n, keep, self.verdict_back, cnt)
+        self._settle_refuted(cnt, refuted, keep); self._t("apply+settle")
+        self.local_base += n
+        self.stats["reads"] += n
+        self.stats["requests"] += cnt
+        self.stats["refuted"] += refuted
+        self.stats["bytes_out"] += 16 * n + 8 * n_recv + (8 * rw + 1) * cnt
+        return cnt
+
+    def _check_requests(self, cnt):
+        """Sends the cnt requests in self.req to the holders, slice by slice so that no message
+        exceeds MAX_MESSAGE, and fills verdict_back[k] for request k."""
+        L, dist, rw = self.local, self.dist, self.rw
+        limit = max(1, self.MAX_MESSAGE // (8 * rw))
+        # every rank must run the same number of slices: agree on the largest request count
+        t = torch.tensor([cnt], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=_reduce_max(dist))
+        most = int(t.item())
+        slice_len = max(1, min(most, limit * self.world // 2)) if most else 0
+        n_slices = (most + slice_len - 1) // slice_len if most else 0
+        for s in range(n_slices):
+            lo = min(cnt, s * slice_len)
+            m = min(cnt, lo + slice_len) - lo
+            self._request_side(max(m, 1))
+            req = self.req[lo * rw:]
+            L.partition_records(req, m, self.W, self.world, self.greq, self.counts, self.origin2)
+            L.sync()
+            send, recv = self._exchange_counts()
+            if max(send + [0]) * 8 * rw > 4 * self.MAX_MESSAGE:
+                raise RuntimeError("request exchange: one holder is the target of too many candidates in a slice")
+            m_recv = sum(recv)
+            self._holder_side(max(m_recv, 1))
+            dist.all_to_all_single(self.recv_req[: m_recv * rw], self.greq[: m * rw],
+                                   output_split_sizes=[c * rw for c in recv], input_split_sizes=[c * rw for c in send])
+            self._sync()
+            L.verify_requests(self.recv_req, m_recv, self.verdict)
+            L.sync()
+            dist.all_to_all_single(self.verdict_grouped[:m], self.verdict[:m_recv], output_split_sizes=send, input_split_sizes=recv)
+            self._sync()
+            L.scatter_flags(self.verdict_grouped, self.origin2, m, self.verdict_back[lo:])
+        L.sync()
+
+    def _settle_refuted(self, cnt, refuted, keep):
+        t = torch.tensor([refuted], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(t)
+        if int(t.item()) == 0:
+            return
+        mine = []
+        if refuted:
+            k = (self.verdict_back[:cnt] == 0).nonzero().flatten()
+            rows = self.req.view(-1, self.rw)[k, 1:].cpu().numpy()
+            where = self.req_local[k.to(self.req_local.device)].cpu().tolist()
+            mine = [(int(i), rows[j].tobytes()) for j, i in enumerate(where)]       # requests are in read order
+        everyone = [None] * self.world
+        self.dist.all_gather_object(everyone, mine)
+        fresh = []
+        for r, items in enumerate(everyone):                 # global order: rank, then position
+            for i, key in items:
+                if key not in self.side:
+                    self.side.add(key)
+                    if r == self.rank:
+                        fresh.append(i)
+        if fresh:
+            keep[torch.tensor(fresh, dtype=torch.int64, device=keep.device)] = 1
+        self._sync()
+
+
+def _reduce_max(dist):
+    op = getattr(dist, "ReduceOp", None)
+    return op.MAX if op is not None else torch.distributed.ReduceOp.MAX

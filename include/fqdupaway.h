@@ -167,6 +167,42 @@ int  fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n,
  * in between. */
 int  fqd_reserve_records(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1, uint64_t** slot);
 
+/* ---- optimistic sharding: hashes first, keys only for candidate duplicates ---------------
+ * The exchange of fqd_insert_records moves every 72-byte record.  Here a rank keeps its keys
+ * (fqd_encode_batch), sends 16-byte [hash | payload] records to the owners, which dedup by the
+ * 64-bit hash alone (fqd_insert_hashes) and answer, per record, "first" or the payload of an
+ * earlier record with that hash (fqd_hash_replies).  Only those candidates are then checked key
+ * against key at the rank that holds the earlier record (fqd_build_requests /
+ * fqd_verify_requests).  Any refuted check (two unequal keys, one hash) is counted by
+ * fqd_apply_replies: the caller must then redo the step with full keys, so results stay exact. */
+
+/* fqd_submit without the set: appends the batch's keys to the engine's store (index continues)
+ * and writes the n placement hashes to `hashes` (device).  Device space only. */
+int  fqd_encode_batch(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint64_t* hashes);
+/* out[i] = [hashes[i] | payload_base + i]  (2 uint64 each, device). */
+int  fqd_make_hash_records(fqd_engine* e, const uint64_t* hashes, uint64_t n, uint64_t payload_base, uint64_t* out);
+/* Hash engine (segments = 1, used for nothing else): room for / insertion of n [hash | payload]
+ * records keyed by the hash itself.  first[j] (device uint32, n) = engine index of the earlier
+ * record with the same hash that took j's place, wherever keep[j] == 0. */
+int  fqd_reserve_hashes(fqd_engine* e, uint64_t n, uint64_t** slot);
+int  fqd_insert_hashes(fqd_engine* e, const uint64_t* records, uint64_t n, uint8_t* keep, uint32_t* first);
+/* For the n records just inserted: reply[j] = ~0 if keep[j], else the payload of the FIRST
+ * record with j's hash (first[] followed down to a record that kept its flag). */
+int  fqd_hash_replies(fqd_engine* e, uint64_t n, const uint8_t* keep, const uint32_t* first, uint64_t* reply);
+/* out[origin[k]] = vals[k], k < n. */
+int  fqd_scatter_u64(fqd_engine* e, const uint64_t* vals, const uint32_t* origin, uint64_t n, uint64_t* out);
+/* For every i < n with reply[i] != ~0, in the order of i: one request [reply[i] | key of local
+ * record local_base+i] (key_words+1 uint64) in `req`, req_local = i.  *count (host) = number of
+ * requests; when that exceeds req_capacity nothing is written and FQD_ERR_CAPACITY is returned
+ * (call again with a larger buffer). */
+int  fqd_build_requests(fqd_engine* e, const uint64_t* reply, uint64_t n, uint64_t local_base,
+                        uint64_t* req, uint64_t req_capacity, uint32_t* req_local, uint64_t* count);
+/* verdict[j] = 1 iff request j's key equals the local key of record (req[j][0] & (2^40-1)). */
+int  fqd_verify_requests(fqd_engine* e, const uint64_t* req, uint64_t m, uint8_t* verdict);
+/* keep[i] = (reply[i] == ~0); *refuted (host, added to) = number of zero verdicts among m. */
+int  fqd_apply_replies(fqd_engine* e, const uint64_t* reply, uint64_t n, uint8_t* keep,
+                       const uint8_t* verdict, uint64_t m, uint64_t* refuted);
+
 /* ---- the `--unordered` read-ID join (hash_dup_remover.hpp:150-192,257-347) ------------
  * ID tags of one file (FastqViewWithId::read_new, fastqview.cpp:190-204): the tag bytes of
  * all records back to back plus per-record offset and length.  Device pointers; n < 2^32-1. */

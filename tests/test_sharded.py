@@ -157,6 +157,81 @@ class ThreadDist:
         torch.cuda.synchronize()
         self.barrier.wait()
 
+    def _share(self, obj):
+        self.slots[self.local.rank] = obj
+        self.barrier.wait()
+        everyone = list(self.slots)
+        self.barrier.wait()
+        return everyone
+
+    def all_reduce(self, t, op=None):
+        torch.cuda.synchronize()
+        vals = self._share(t.clone())
+        stacked = torch.stack(vals)
+        t.copy_(stacked.max(dim=0).values if op == torch.distributed.ReduceOp.MAX else stacked.sum(dim=0))
+        torch.cuda.synchronize()
+
+    def all_gather_object(self, out, obj):
+        out[:] = self._share(obj)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("weak", [False, True])
+def test_lazy_exchange_on_gpu_with_virtual_ranks(oracle, world, paired, weak):
+    """Hashes first, keys only for candidates: same flags as the oracle, also when unequal keys
+    share a hash (weak = the test hash with 26 useful bits, so refuted checks do happen)."""
+    from fastq_dupaway_amd import Engine, Reads
+    from fastq_dupaway_amd.sharded import LazyShardedDedup
+    n_per, steps, LL = 20000, 3, 150
+    S = 2 if paired else 1
+    dev = torch.device("cuda", 0)
+    bases = [[[torch.empty(n_per * LL + 16, dtype=torch.uint8, device=dev) for _ in range(S)]
+              for _ in range(world)] for _ in range(steps)]
+    gen = Engine(segments=S)
+    for st in range(steps):
+        for r in range(world):
+            for m in range(S):
+                gen.synth_reads(11, (st * world + r) * n_per, n_per, LL, 300, m, bases[st][r][m], None)
+    gen.sync(); gen.close()
+    tdist = ThreadDist(world)
+    keeps = [[torch.zeros(n_per, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(steps)]
+    errors, stats = [], [None] * world
+
+    def worker(rank):
+        try:
+            tdist.bind(rank)
+            torch.cuda.set_device(0)
+            with Engine(segments=S, weak_hash=weak) as local, Engine(segments=1) as owner:
+                sd = LazyShardedDedup(local, owner, tdist, dev, n_max=n_per, len0=LL, len1=LL if paired else 0)
+                sd.MAX_MESSAGE = 64 << 10                  # several request slices per round
+                for st in range(steps):
+                    segs = [Reads(bases[st][rank][m], uniform_len=LL, uniform_stride=LL) for m in range(S)]
+                    sd.dedup(segs, n_per, keeps[st][rank])
+                    local.sync()
+                stats[rank] = dict(sd.stats)
+        except Exception as ex:
+            import traceback; traceback.print_exc()
+            errors.append(ex)
+            tdist.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]; [t.join() for t in threads]
+    assert not errors, errors
+    n = steps * world * n_per
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(LL); lens = np.full(n, LL, np.uint32)
+    host = [np.concatenate([bases[st][r][m][: n_per * LL].cpu().numpy() for st in range(steps) for r in range(world)]
+                           + [np.zeros(8, np.uint8)]) for m in range(S)]
+    exp = oracle.dedup_paired(host[0], offs, lens, host[1], offs, lens) if paired else oracle.dedup_single(host[0], offs, lens)
+    got = np.concatenate([keeps[st][r].cpu().numpy() for st in range(steps) for r in range(world)])
+    assert np.array_equal(got, exp)
+    dups = int((exp == 0).sum())
+    assert 0 < dups < n
+    refuted = sum(s["refuted"] for s in stats)
+    assert dups <= sum(s["requests"] for s in stats) <= dups + refuted      # a refuted candidate may still be a duplicate
+    assert (refuted > 0) == weak
+
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
@@ -292,5 +367,39 @@ def test_pipelined_rounds_under_rccl_single_rank(monkeypatch, pipeline):
                                  for k in range(rounds)])
                 e.sync()
                 assert torch.equal(keep, expect), f"step {step}"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("paired", [False, True])
+def test_lazy_exchange_under_rccl_single_rank(paired):
+    """The optimistic exchange with real RCCL collectives at sizes where the owner's hash set takes
+    the bulk (partitioned) insert: flags equal the generator's analytically known ones."""
+    import torch.distributed as dist
+    from fastq_dupaway_amd import Engine, Reads
+    from fastq_dupaway_amd.sharded import LazyShardedDedup
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    try:
+        S = 2 if paired else 1
+        n_per, rounds, LL = 2_500_000, 3, 150
+        n = n_per * rounds
+        with Engine(segments=S) as local, Engine(segments=1) as owner:
+            bases = [torch.empty(n * LL + 16, dtype=torch.uint8, device=dev) for _ in range(S)]
+            expect = torch.empty(n, dtype=torch.uint8, device=dev)
+            for m in range(S):
+                local.synth_reads(41, 0, n, LL, 250, m, bases[m], expect if m == S - 1 else None)
+            local.sync()
+            sd = LazyShardedDedup(local, owner, dist, dev, n_max=n_per, len0=LL, len1=LL if paired else 0)
+            keep = torch.zeros(n, dtype=torch.uint8, device=dev)
+            for k in range(rounds):
+                segs = [Reads(bases[m][k * n_per * LL:], uniform_len=LL, uniform_stride=LL) for m in range(S)]
+                sd.dedup(segs, n_per, keep[k * n_per:])
+            local.sync()
+            assert torch.equal(keep, expect)
+            assert sd.stats["refuted"] == 0
+            assert sd.stats["requests"] == int((expect == 0).sum().item())
     finally:
         dist.destroy_process_group()

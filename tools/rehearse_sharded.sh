@@ -6,3 +6,6 @@ for l in sys.stdin:
 echo pipe=1; FQD_SHARDED_PIPELINE=1 run
 echo pipe=0; FQD_SHARDED_PIPELINE=0 run
 echo pipe=1 paired 30M; FQD_SHARDED_PIPELINE=1 run --paired --reads 30000000
+echo lazy; FQD_SHARDED_LAZY=1 run
+echo lazy rounds=2; FQD_SHARDED_LAZY=1 FQD_BENCH_ROUNDS=2 run
+echo lazy paired 30M; FQD_SHARDED_LAZY=1 run --paired --reads 30000000

@@ -51,6 +51,7 @@ struct fqd_engine {
 
     DevBuf   table;    uint64_t slots = 0;
     uint32_t seg_bits = 0;                           // log2(slots per probing segment)
+    uint32_t tag_mask = 0;                           // slot tag = (hash >> 32) & tag_mask (slot_tag)
     bool     table_clear = false;                    // every slot is EMPTY right now
     bool     table_stale = false;                    // contents are garbage: clear (or rebuild) before use
     DevBuf   bulk_recs, bulk_meta;                   // scratch of the bulk (partitioned) insert
@@ -220,6 +221,24 @@ uint32_t seg_bits_for(uint64_t slots)
     return std::min<uint32_t>(14u, std::max<uint32_t>(want, t >= 16 ? t - 16 : 12u));
 }
 
+// How a table of 2^t slots with 2^seg_bits-slot segments is split into partition digits, and
+// how wide its slot tags can be so that a partition record fits 8 bytes (fqd_kernels.hpp,
+// BulkGeom): seg_bits + bits2 + tag bits = 32.
+void table_digits(uint32_t t, uint32_t seg_bits, uint32_t& bits1, uint32_t& bits2)
+{
+    const uint32_t nb_bits = t > seg_bits ? t - seg_bits : 0;
+    bits1 = nb_bits <= 8 ? nb_bits : (nb_bits + 1) / 2;
+    bits2 = nb_bits - bits1;
+}
+uint32_t tag_mask_for(uint64_t slots, uint32_t seg_bits)
+{
+    uint32_t t = 0; while ((1ull << t) < slots) ++t;
+    uint32_t bits1, bits2;
+    table_digits(t, seg_bits, bits1, bits2);
+    const uint32_t tag_bits = 32u - std::min(seg_bits, 14u) - std::min(bits2, 8u);
+    return tag_bits >= 32 ? 0xFFFFFFFFu : (1u << tag_bits) - 1u;
+}
+
 // Keeps the table at <= 50 % load.  `exact`: size for a known total (capacity hint);
 // otherwise grow geometrically so rehashes stay rare.
 int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
@@ -229,6 +248,7 @@ int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
     void* nt = nullptr;
     HIP_TRY(e, hipMalloc(&nt, want * sizeof(uint64_t)));
     const uint32_t new_seg_bits = seg_bits_for(want);
+    const uint32_t new_tag_mask = tag_mask_for(want, new_seg_bits);
     if (e->slots && e->n_records) {
         Bracket br(e, K_OTHER, 0);
         HIP_TRY(e, hipMemsetAsync(nt, 0xFF, want * sizeof(uint64_t), e->stream));
@@ -237,7 +257,7 @@ int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
                            e->table.as<uint64_t>(), e->slots, static_cast<uint64_t*>(nt), want - 1,
                            (1ull << new_seg_bits) - 1, ks, e->L0, e->L1, uint32_t(e->S == 2), uint32_t(e->hash_layout),
                            (e->hash_layout || !(e->flags & FQD_FLAG_WEAK_HASH)) ? ~0ull : 0x00000000FFFFFFC0ull,
-                           reinterpret_cast<unsigned long long*>(e->d_state + 1));
+                           new_tag_mask, reinterpret_cast<unsigned long long*>(e->d_state + 1));
         e->table_clear = false; e->table_stale = false;
     } else {
         e->table_clear = false; e->table_stale = true;       // cleared lazily by whoever uses it first
@@ -246,7 +266,7 @@ int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
         HIP_TRY(e, hipStreamSynchronize(e->stream));
         HIP_TRY(e, hipFree(e->table.p));
     }
-    e->table.p = nt; e->table.cap = want * sizeof(uint64_t); e->slots = want; e->seg_bits = new_seg_bits;
+    e->table.p = nt; e->table.cap = want * sizeof(uint64_t); e->slots = want; e->seg_bits = new_seg_bits; e->tag_mask = new_tag_mask;
     return FQD_OK;
 }
 
@@ -308,7 +328,7 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
 {
     if (!stream) stream = e->stream;
     const uint64_t hash_and = (e->flags & FQD_FLAG_WEAK_HASH) ? 0x00000000FFFFFFC0ull : ~0ull;
-    Hist1 h1{nullptr, BulkGeom{0, 0, 0, 0}, hash_and};
+    Hist1 h1{nullptr, BulkGeom{0, 0, 0, 0, 0}, hash_and};
     if (fold) { h1 = *fold; h1.hash_and = hash_and; }
     Bracket br(e, K_ENCODE, n, stream);
     const StagedChoice c = choose_staged(e, seg, uniform, ks);
@@ -362,7 +382,7 @@ int launch_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes, uin
     const uint32_t grid = uint32_t(std::min<uint64_t>(grid_for(e, n), uint64_t(e->n_cu) * blocks_per_cu));
     hipLaunchKernelGGL(insert_kernel, dim3(grid), dim3(kBlock), 0, e->stream,
                        e->table.as<uint64_t>(), e->slots - 1, (1ull << e->seg_bits) - 1, ks, hashes, hash_stride, n,
-                       Verdicts{keep, first, uint32_t(first_idx)},
+                       Verdicts{keep, first, uint32_t(first_idx)}, e->tag_mask,
                        reinterpret_cast<unsigned long long*>(e->d_state + 1));
     HIP_TRY(e, hipGetLastError());
     return FQD_OK;
@@ -380,13 +400,13 @@ bool bulk_applies(const fqd_engine* e, uint64_t n)
 
 struct BulkPlan {
     bool ok = false;
-    BulkGeom g{0, 0, 0, 0};
+    BulkGeom g{0, 0, 0, 0, 0};
     uint32_t nd1 = 0, n_buckets = 0;
     uint32_t *hist1 = nullptr, *start1 = nullptr, *cursor1 = nullptr, *tile_start1 = nullptr;
     uint32_t *hist2 = nullptr, *start2 = nullptr, *cursor2 = nullptr;
-    ulonglong2 *recA = nullptr, *recB = nullptr;
-    uint16_t *bucket16 = nullptr;
-    uint32_t *heavy_flag = nullptr;
+    uint64_t *recA = nullptr, *recB = nullptr;
+    uint8_t *digit2 = nullptr;
+    uint32_t *heavy_count = nullptr, *heavy_list = nullptr;
 };
 
 // Geometry + scratch of one bulk insert; zeroes the counters on the engine's stream.
@@ -396,24 +416,24 @@ int bulk_plan(fqd_engine* e, uint64_t n, BulkPlan& p)
     const uint32_t nb_bits = t - e->seg_bits;                // <= 16 by construction of seg_bits (t <= 30)
     p.ok = false;
     if (nb_bits > 16 || nb_bits == 0) return FQD_OK;
-    p.g.slot_mask = e->slots - 1; p.g.seg_bits = e->seg_bits;
-    p.g.bits1 = nb_bits <= 8 ? nb_bits : (nb_bits + 1) / 2;
-    p.g.bits2 = nb_bits - p.g.bits1;
+    p.g.slot_mask = e->slots - 1; p.g.seg_bits = e->seg_bits; p.g.tag_mask = e->tag_mask;
+    table_digits(t, e->seg_bits, p.g.bits1, p.g.bits2);
     p.nd1 = 1u << p.g.bits1; p.n_buckets = 1u << nb_bits;
     int rc;
-    const size_t rec_bytes = ((n * sizeof(ulonglong2)) + 255) & ~size_t(255);
-    const size_t b16_bytes = p.g.bits2 ? ((n * sizeof(uint16_t)) + 255) & ~size_t(255) : 0;
-    if ((rc = reserve(e, e->bulk_recs, rec_bytes * (p.g.bits2 ? 2 : 1) + b16_bytes))) return rc;
-    // meta: hist1[256] start1[257] cursor1[256] tile_start1[257] | hist2[nb] start2[nb+1] cursor2[nb]
-    const size_t meta_words = 1100 + 3 * size_t(p.n_buckets) + 8;
+    const size_t rec_bytes = ((n * sizeof(uint64_t)) + 255) & ~size_t(255);
+    const size_t d2_bytes = p.g.bits2 ? ((n * sizeof(uint8_t)) + 255) & ~size_t(255) : 0;
+    if ((rc = reserve(e, e->bulk_recs, rec_bytes * (p.g.bits2 ? 2 : 1) + d2_bytes))) return rc;
+    // meta: hist1[256] start1[257] cursor1[256] tile_start1[257] heavy_count | hist2[nb] start2[nb+1] cursor2[nb] heavy_list[nb]
+    const size_t meta_words = 1100 + 4 * size_t(p.n_buckets) + 16;
     if ((rc = reserve(e, e->bulk_meta, meta_words * sizeof(uint32_t)))) return rc;
     uint32_t* m = e->bulk_meta.as<uint32_t>();
     p.hist1 = m; p.start1 = m + 256; p.cursor1 = m + 520; p.tile_start1 = m + 780;
     p.hist2 = m + 1100; p.start2 = p.hist2 + p.n_buckets; p.cursor2 = p.start2 + p.n_buckets + 4;
-    p.heavy_flag = m + 1090;                                   // zeroed with the rest of meta
-    p.recA = e->bulk_recs.as<ulonglong2>();
-    p.recB = reinterpret_cast<ulonglong2*>(e->bulk_recs.as<char>() + rec_bytes);
-    p.bucket16 = p.g.bits2 ? reinterpret_cast<uint16_t*>(e->bulk_recs.as<char>() + 2 * rec_bytes) : nullptr;
+    p.heavy_count = m + 1090;                                  // zeroed with the rest of meta
+    p.heavy_list = p.cursor2 + p.n_buckets + 4;
+    p.recA = e->bulk_recs.as<uint64_t>();
+    p.recB = reinterpret_cast<uint64_t*>(e->bulk_recs.as<char>() + rec_bytes);
+    p.digit2 = p.g.bits2 ? reinterpret_cast<uint8_t*>(e->bulk_recs.as<char>() + 2 * rec_bytes) : nullptr;
     {
         Bracket br(e, K_OTHER, 0);
         HIP_TRY(e, hipMemsetAsync(m, 0, meta_words * sizeof(uint32_t), e->stream));
@@ -432,13 +452,13 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
     const uint32_t nd1 = p.nd1, n_buckets = p.n_buckets;
     uint32_t *hist1 = p.hist1, *start1 = p.start1, *cursor1 = p.cursor1, *tile_start1 = p.tile_start1;
     uint32_t *hist2 = p.hist2, *start2 = p.start2, *cursor2 = p.cursor2;
-    ulonglong2 *recA = p.recA, *recB = p.recB;
+    uint64_t *recA = p.recA, *recB = p.recB;
     const bool fresh = e->n_records == 0 || e->table_clear || e->table_stale;
     {
         Bracket br(e, K_OTHER, 0);
         HIP_TRY(e, hipMemsetAsync(keep, 1, n, e->stream));
     }
-    const ulonglong2* final_recs = recA; const uint32_t* bstart = start1;
+    const uint64_t* final_recs = recA; const uint32_t* bstart = start1;
     {
     Bracket part_br(e, K_PARTITION, n);
     const uint32_t part_grid = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile, uint64_t(e->n_cu) * 2u));
@@ -447,19 +467,19 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
     hipLaunchKernelGGL(bulk_scan256_kernel, dim3(1), dim3(320), 0, e->stream,
                        static_cast<const uint32_t*>(hist1), nd1, start1, cursor1, tile_start1);
     hipLaunchKernelGGL(bulk_scatter_kernel<1>, dim3(part_grid), dim3(kPartThreads), 0, e->stream,
-                       hashes, hash_stride, uint32_t(first_idx), static_cast<const ulonglong2*>(nullptr), n, g,
-                       static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor1, recA, p.bucket16);
+                       hashes, hash_stride, uint32_t(first_idx), static_cast<const uint64_t*>(nullptr), n, g,
+                       static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor1, recA, p.digit2);
     if (g.bits2) {
         const uint32_t grid2 = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile + nd1, uint64_t(e->n_cu) * 2u));
         hipLaunchKernelGGL(bulk_hist2_kernel, dim3(grid2), dim3(kPartThreads), 0, e->stream,
-                           static_cast<const uint16_t*>(p.bucket16), g, static_cast<const uint32_t*>(start1),
+                           static_cast<const uint8_t*>(p.digit2), g, static_cast<const uint32_t*>(start1),
                            static_cast<const uint32_t*>(tile_start1), hist2);
         hipLaunchKernelGGL(bulk_scan_buckets_kernel, dim3(1), dim3(1024), 0, e->stream,
                            static_cast<const uint32_t*>(hist2), n_buckets, start2, cursor2);
         hipLaunchKernelGGL(bulk_scatter_kernel<2>, dim3(grid2), dim3(kPartThreads), 0, e->stream,
-                           static_cast<const uint64_t*>(nullptr), 0u, 0u, static_cast<const ulonglong2*>(recA), n, g,
+                           static_cast<const uint64_t*>(nullptr), 0u, 0u, static_cast<const uint64_t*>(recA), n, g,
                            static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor2, recB,
-                           static_cast<uint16_t*>(nullptr));
+                           static_cast<uint8_t*>(nullptr));
         final_recs = recB; bstart = start2;
     }
     }
@@ -474,17 +494,17 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
     if (fresh) {
         if (lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_dedup_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         hipLaunchKernelGGL(bucket_dedup_kernel<true>, dim3(dgrid), dim3(dthreads), lds, e->stream,
-                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, ks, verdicts, counters,
-                           heavy_above, p.heavy_flag);
+                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, g.seg_bits + g.bits2, ks, verdicts, counters,
+                           heavy_above, p.heavy_count, p.heavy_list);
     } else {
         if (lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_dedup_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         hipLaunchKernelGGL(bucket_dedup_kernel<false>, dim3(dgrid), dim3(dthreads), lds, e->stream,
-                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, ks, verdicts, counters,
-                           heavy_above, p.heavy_flag);
+                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, g.seg_bits + g.bits2, ks, verdicts, counters,
+                           heavy_above, p.heavy_count, p.heavy_list);
     }
     hipLaunchKernelGGL(heavy_bucket_insert_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
-                       final_recs, bstart, n, g, e->table.as<uint64_t>(), ks, verdicts, counters,
-                       heavy_above, static_cast<const uint32_t*>(p.heavy_flag));
+                       final_recs, bstart, g, e->table.as<uint64_t>(), ks, verdicts, counters,
+                       static_cast<const uint32_t*>(p.heavy_count), static_cast<const uint32_t*>(p.heavy_list));
     HIP_TRY(e, hipGetLastError());
     e->table_clear = false; e->table_stale = false;
     return FQD_OK;

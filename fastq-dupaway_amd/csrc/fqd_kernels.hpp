@@ -59,7 +59,13 @@ struct BulkGeom {
     uint64_t slot_mask;
     uint32_t seg_bits;     // log2(slots per segment)
     uint32_t bits1, bits2; // partition digits: bucket = pos >> seg_bits = (d1 << bits2) | d2
+    uint32_t tag_mask;     // the table's slot tag = (hash >> 32) & tag_mask (see slot_tag)
 };
+// A table slot is (tag << 32) | record index.  The tag only filters which owners are worth a key
+// comparison, so it is kept narrow enough that a partition record — the bits of the table
+// position below the level-1 digit, the tag, the record index — fits 8 bytes:
+// seg_bits + bits2 + tag bits <= 32.  Every path that touches a table uses the table's mask.
+__host__ __device__ __forceinline__ uint64_t slot_tag(uint64_t hash, uint32_t tag_mask) { return (hash >> 32) & tag_mask; }
 __device__ __forceinline__ uint32_t bucket_of(uint64_t hash, const BulkGeom& g) { return uint32_t((hash & g.slot_mask) >> g.seg_bits); }
 struct Hist1 {
     uint32_t* hist;        // 256 global counters, or nullptr
@@ -361,7 +367,7 @@ __device__ __forceinline__ bool keys_equal(const KeyStore& ks, uint32_t a, uint3
 __global__ __launch_bounds__(kBlock)
 void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, uint64_t seg_mask, KeyStore ks,
                    const uint64_t* __restrict__ hashes, uint32_t hash_stride,
-                   uint64_t n, Verdicts out,
+                   uint64_t n, Verdicts out, uint32_t tag_mask,
                    unsigned long long* __restrict__ counters /* [0]=dups [1]=table-full */)
 {
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(table);
@@ -369,7 +375,7 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, uint64_t se
     for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
         const uint64_t h = hashes[i * uint64_t(hash_stride)];
         const uint32_t idx = out.first_idx + uint32_t(i);
-        const uint64_t tag = h >> 32;
+        const uint64_t tag = slot_tag(h, tag_mask);
         const unsigned long long mine = (tag << 32) | idx;
         uint64_t pos = h & slot_mask;
         bool placed = false;
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(kBlock)
 void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
                    uint64_t* __restrict__ new_table, uint64_t new_mask, uint64_t new_seg_mask, KeyStore ks,
                    uint32_t len0, uint32_t len1, uint32_t paired, uint32_t key_is_hash, uint64_t hash_and,
-                   unsigned long long* __restrict__ counters /* [1] = table-full */)
+                   uint32_t new_tag_mask, unsigned long long* __restrict__ counters /* [1] = table-full */)
 {
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(new_table);
     for (uint64_t s = blockIdx.x * uint64_t(kBlock) + threadIdx.x; s < old_slots; s += uint64_t(gridDim.x) * kBlock) {
@@ -428,7 +434,7 @@ void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
             h = hash_end(h);
         }
         h &= hash_and;
-        const unsigned long long mine = ((h >> 32) << 32) | idx;
+        const unsigned long long mine = (slot_tag(h, new_tag_mask) << 32) | idx;
         uint64_t pos = h & new_mask;
         uint64_t probe = 0;                                  // bounded: a full segment is reported, never spun on
         while (atomicCAS(&tab[pos], kEmptySlot, mine) != kEmptySlot) {
@@ -440,9 +446,10 @@ void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
 
 // ---------------------------------------------------------------------------
 // Bulk insert: no global atomics on the table.
-//   records (hash, index) are radix-partitioned by table segment (one or two passes of up to
-//   256 ways, LDS counting sort per 4096-record tile so the scatter leaves the CU as runs of
-//   whole lines), then one workgroup per segment replays the same probe/verify/first-wins logic
+//   8-byte records (q << 32 | index) are radix-partitioned by table segment (one or two passes
+//   of up to 256 ways, LDS counting sort per 4096-record tile so the scatter leaves the CU as
+//   runs of whole lines); q = the table position's bits below the level-1 digit, and above them
+//   the slot tag (part_q).  Then one workgroup per segment replays the same probe/verify/first-wins logic
 //   as insert_kernel on an LDS-resident copy of the segment and writes it back once.
 // Measured motive (tools/atomic_probe.hip): device-scope atomics cap at 18-27 G/s on this chip
 // wherever the table lives, LDS atomics do not.
@@ -485,6 +492,14 @@ __global__ void bulk_scan256_kernel(const uint32_t* __restrict__ count, uint32_t
     if (d <= nd) { start[d] = a[d]; tile_start[d] = t[d]; if (d < nd) cursor[d] = a[d]; }
 }
 
+// q of a partition record (see BulkGeom / slot_tag): low seg_bits + bits2 bits of the table
+// position, the slot tag above them.
+__device__ __forceinline__ uint32_t part_q(uint64_t hash, const BulkGeom& g)
+{
+    const uint32_t qshift = g.seg_bits + g.bits2;
+    return (uint32_t(hash & g.slot_mask) & ((1u << qshift) - 1u)) | (uint32_t(slot_tag(hash, g.tag_mask)) << qshift);
+}
+
 // Scatter pass shared by both levels.  LEVEL 1 reads the batch's hashes (index implicit),
 // LEVEL 2 reads level-1 records; the tile's records are counting-sorted by digit in LDS, each
 // digit's run reserves its place with ONE atomicAdd on that digit's cursor, and the runs are
@@ -492,14 +507,15 @@ __global__ void bulk_scan256_kernel(const uint32_t* __restrict__ count, uint32_t
 template <int LEVEL>
 __global__ __launch_bounds__(kPartThreads)
 void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stride, uint32_t first_idx,
-                         const ulonglong2* __restrict__ in, uint64_t n, BulkGeom g,
+                         const uint64_t* __restrict__ in, uint64_t n, BulkGeom g,
                          const uint32_t* __restrict__ start1, const uint32_t* __restrict__ tile_start1,
-                         uint32_t* __restrict__ cursor, ulonglong2* __restrict__ out,
-                         uint16_t* __restrict__ bucket_out /* LEVEL 1: bucket number per output record, for the level-2 count */)
+                         uint32_t* __restrict__ cursor, uint64_t* __restrict__ out,
+                         uint8_t* __restrict__ digit2_out /* LEVEL 1: level-2 digit per output record, for the level-2 count */)
 {
-    __shared__ ulonglong2 stage[kPartTile];
+    __shared__ uint64_t stage[kPartTile];
+    __shared__ uint8_t sdig[kPartTile];
     __shared__ uint32_t cnt[256], lstart[256], gbase[256];
-    const uint32_t nd1 = 1u << g.bits1;
+    const uint32_t nd1 = 1u << g.bits1, mask2 = (1u << g.bits2) - 1u;
     const uint64_t n_tiles = (LEVEL == 1) ? (n + kPartTile - 1) / kPartTile : tile_start1[nd1];
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         uint64_t lo, hi; uint32_t d1 = 0;
@@ -515,15 +531,19 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
         const uint32_t count = uint32_t(hi - lo);
         for (int k = threadIdx.x; k < 256; k += kPartThreads) cnt[k] = 0;
         __syncthreads();
-        ulonglong2 rec[kPartPer]; uint32_t dig[kPartPer], rank[kPartPer];
+        uint64_t rec[kPartPer]; uint32_t dig[kPartPer], rank[kPartPer];
 #pragma unroll
         for (int k = 0; k < kPartPer; ++k) {
             const uint32_t r = threadIdx.x + k * kPartThreads;
             if (r < count) {
-                if (LEVEL == 1) { rec[k].x = hashes[(lo + r) * uint64_t(hash_stride)]; rec[k].y = first_idx + uint32_t(lo + r); }
-                else rec[k] = in[lo + r];
-                const uint32_t bkt = bucket_of(rec[k].x, g);
-                dig[k] = (LEVEL == 1) ? (bkt >> g.bits2) : (bkt & ((1u << g.bits2) - 1u));
+                if (LEVEL == 1) {
+                    const uint64_t h = hashes[(lo + r) * uint64_t(hash_stride)];
+                    rec[k] = (uint64_t(part_q(h, g)) << 32) | (first_idx + uint32_t(lo + r));
+                    dig[k] = bucket_of(h, g) >> g.bits2;
+                } else {
+                    rec[k] = in[lo + r];
+                    dig[k] = (uint32_t(rec[k] >> 32) >> g.seg_bits) & mask2;
+                }
                 rank[k] = atomicAdd(&cnt[dig[k]], 1u);
             }
         }
@@ -544,28 +564,30 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
             gbase[k] = cnt[k] ? atomicAdd(&cursor[(LEVEL == 1 ? 0u : (d1 << g.bits2)) + k], cnt[k]) : 0u;
 #pragma unroll
         for (int k = 0; k < kPartPer; ++k)
-            if (threadIdx.x + k * kPartThreads < count) stage[lstart[dig[k]] + rank[k]] = rec[k];
+            if (threadIdx.x + k * kPartThreads < count) {
+                const uint32_t at = lstart[dig[k]] + rank[k];
+                stage[at] = rec[k]; sdig[at] = uint8_t(dig[k]);
+            }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kPartPer; ++k) {
             const uint32_t r = threadIdx.x + k * kPartThreads;
             if (r < count) {
-                const ulonglong2 v = stage[r];
-                const uint32_t bkt = bucket_of(v.x, g);
-                const uint32_t d = (LEVEL == 1) ? (bkt >> g.bits2) : (bkt & ((1u << g.bits2) - 1u));
+                const uint64_t v = stage[r];
+                const uint32_t d = sdig[r];
                 out[gbase[d] + (r - lstart[d])] = v;
-                if (LEVEL == 1 && bucket_out) bucket_out[gbase[d] + (r - lstart[d])] = uint16_t(bkt);
+                if (LEVEL == 1 && digit2_out) digit2_out[gbase[d] + (r - lstart[d])] = uint8_t((uint32_t(v >> 32) >> g.seg_bits) & mask2);
             }
         }
         __syncthreads();
     }
 }
 
-// Level-2 histogram over the level-1 output (read through the 2-byte bucket numbers the
+// Level-2 histogram over the level-1 output (read through the 1-byte level-2 digits the
 // level-1 scatter leaves beside the records: an eighth of the bytes).  A tile lies inside one
 // level-1 digit, so its counts go to consecutive buckets; LDS-aggregated, one global add per bin.
 __global__ __launch_bounds__(kPartThreads)
-void bulk_hist2_kernel(const uint16_t* __restrict__ bucket_in, BulkGeom g, const uint32_t* __restrict__ start1,
+void bulk_hist2_kernel(const uint8_t* __restrict__ digit2_in, BulkGeom g, const uint32_t* __restrict__ start1,
                        const uint32_t* __restrict__ tile_start1, uint32_t* __restrict__ hist2)
 {
     __shared__ uint32_t h[256];
@@ -580,7 +602,7 @@ void bulk_hist2_kernel(const uint16_t* __restrict__ bucket_in, BulkGeom g, const
         for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) h[k] = 0;
         __syncthreads();
         for (uint64_t r = lo + threadIdx.x; r < hi; r += kPartThreads)
-            atomicAdd(&h[bucket_in[r] & (nd2 - 1u)], 1u);
+            atomicAdd(&h[digit2_in[r] & (nd2 - 1u)], 1u);
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) if (h[k]) atomicAdd(&hist2[(d1 << g.bits2) + k], h[k]);
         __syncthreads();
@@ -636,10 +658,10 @@ constexpr uint32_t kDedupFly = 4;
 
 template <bool FRESH>
 __global__ __launch_bounds__(1024)
-void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __restrict__ bstart, uint32_t n_buckets,
-                         uint64_t* __restrict__ table, uint32_t seg_bits, KeyStore ks, Verdicts out,
+void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ bstart, uint32_t n_buckets,
+                         uint64_t* __restrict__ table, uint32_t seg_bits, uint32_t qshift, KeyStore ks, Verdicts out,
                          unsigned long long* __restrict__ counters,
-                         uint32_t heavy_above, uint32_t* __restrict__ heavy_flag)
+                         uint32_t heavy_above, uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long seg[];
     const uint32_t seg_slots = 1u << seg_bits, seg_mask = seg_slots - 1u;
@@ -650,9 +672,9 @@ void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __
 
     // One record's walk from `pos`: claims, or (inline == false) queues the first tag match,
     // or (inline == true) verifies tag matches on the spot.
-    auto walk = [&](const ulonglong2 v, uint32_t c, uint32_t pos, bool verify_inline) {
-        const uint32_t idx = uint32_t(v.y);
-        const uint64_t tag = v.x >> 32;
+    auto walk = [&](const uint64_t v, uint32_t c, uint32_t pos, bool verify_inline) {
+        const uint32_t idx = uint32_t(v);
+        const uint64_t tag = uint32_t(v >> 32) >> qshift;
         const unsigned long long mine = (tag << 32) | idx;
         for (uint32_t probe = 0; probe < seg_slots; ++probe) {
             const unsigned long long old = atomicCAS(&seg[pos], kEmptySlot, mine);
@@ -682,7 +704,7 @@ void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __
             // pin a single workgroup for the whole batch: leave it to heavy_bucket_insert_kernel,
             // which spreads its records over the chip with the atomic path.
             if (FRESH) for (uint32_t k = threadIdx.x; k < seg_slots; k += blockDim.x) gseg[k] = kEmptySlot;
-            if (threadIdx.x == 0) *heavy_flag = 1u;
+            if (threadIdx.x == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b;
             continue;
         }
         for (uint32_t k = threadIdx.x; k < seg_slots; k += blockDim.x) seg[k] = FRESH ? kEmptySlot : gseg[k];
@@ -692,8 +714,8 @@ void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __
             __syncthreads();
             // 1. probe
             for (uint32_t c = threadIdx.x; c < chunk_n; c += blockDim.x) {
-                const ulonglong2 v = recs[chunk_lo + c];
-                walk(v, c, uint32_t(v.x) & seg_mask, false);
+                const uint64_t v = recs[chunk_lo + c];
+                walk(v, c, uint32_t(v >> 32) & seg_mask, false);
             }
             __syncthreads();
             // 2. verify, eight lanes per candidate, kDedupFly candidates per group in flight
@@ -712,8 +734,8 @@ void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __
                     if (live[u]) {
                         const uint32_t ent = queue[q];
                         cc[u] = ent >> 16; pos[u] = ent & 0xFFFFu;
-                        const ulonglong2 v = recs[chunk_lo + cc[u]];
-                        idx[u] = uint32_t(v.y); tag[u] = uint32_t(v.x >> 32);
+                        const uint64_t v = recs[chunk_lo + cc[u]];
+                        idx[u] = uint32_t(v); tag[u] = uint32_t(v >> 32) >> qshift;
                         seen[u] = uint32_t(seg[pos[u]]);      // the slot's owner right now: same key class for good
                         const uint64_t* __restrict__ pa = ks.slot(idx[u]);
                         const uint64_t* __restrict__ pb = ks.slot(seen[u]);
@@ -766,42 +788,46 @@ void bucket_dedup_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __
     }
 }
 
-// Second half of the skew guard: records of buckets the LDS kernel skipped go through the
-// device-atomic protocol of insert_kernel.  Launched after every bulk dedup; when no bucket was
-// heavy every workgroup returns on its first instruction.
+// Second half of the skew guard: records of the buckets the LDS kernel skipped (it lists them)
+// go through the device-atomic protocol of insert_kernel, spread over the whole grid.  Launched
+// after every bulk dedup; when no bucket was heavy every workgroup returns on its first load.
 __global__ __launch_bounds__(kBlock)
-void heavy_bucket_insert_kernel(const ulonglong2* __restrict__ recs, const uint32_t* __restrict__ bstart, uint64_t n,
+void heavy_bucket_insert_kernel(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ bstart,
                                 BulkGeom g, uint64_t* __restrict__ table, KeyStore ks, Verdicts out,
                                 unsigned long long* __restrict__ counters,
-                                uint32_t heavy_above, const uint32_t* __restrict__ heavy_flag)
+                                const uint32_t* __restrict__ heavy_count, const uint32_t* __restrict__ heavy_list)
 {
-    if (*heavy_flag == 0u) return;
+    const uint32_t n_heavy = *heavy_count;
+    if (n_heavy == 0u) return;
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(table);
     const uint64_t seg_mask = (1ull << g.seg_bits) - 1ull;
+    const uint32_t qshift = g.seg_bits + g.bits2;
     uint32_t dups = 0, lost = 0;
-    for (uint64_t r = blockIdx.x * uint64_t(kBlock) + threadIdx.x; r < n; r += uint64_t(gridDim.x) * kBlock) {
-        const ulonglong2 v = recs[r];
-        const uint32_t b = bucket_of(v.x, g);
-        if (bstart[b + 1] - bstart[b] <= heavy_above) continue;
-        const uint32_t idx = uint32_t(v.y);
-        const uint64_t tag = v.x >> 32;
-        const unsigned long long mine = (tag << 32) | idx;
-        uint64_t pos = v.x & g.slot_mask;
-        bool placed = false;
-        for (uint64_t probe = 0; probe <= seg_mask; ++probe) {
-            const unsigned long long old = atomicCAS(&tab[pos], kEmptySlot, mine);
-            if (old == kEmptySlot) { placed = true; break; }
-            if ((old >> 32) == tag && keys_equal(ks, idx, uint32_t(old))) {
-                uint32_t owner = uint32_t(old);
-                if (owner > idx) owner = uint32_t(atomicMin(&tab[pos], mine));
-                if (owner < idx) out.lose(idx, owner);
-                else             out.lose(owner, idx);
-                ++dups; placed = true;
-                break;
+    for (uint32_t k = 0; k < n_heavy; ++k) {
+        const uint32_t b = heavy_list[k];
+        const uint64_t lo = bstart[b], hi = bstart[b + 1];
+        for (uint64_t r = lo + blockIdx.x * uint64_t(kBlock) + threadIdx.x; r < hi; r += uint64_t(gridDim.x) * kBlock) {
+            const uint64_t v = recs[r];
+            const uint32_t idx = uint32_t(v), q = uint32_t(v >> 32);
+            const uint64_t tag = q >> qshift;
+            const unsigned long long mine = (tag << 32) | idx;
+            uint64_t pos = (uint64_t(b) << g.seg_bits) | (q & seg_mask);
+            bool placed = false;
+            for (uint64_t probe = 0; probe <= seg_mask; ++probe) {
+                const unsigned long long old = atomicCAS(&tab[pos], kEmptySlot, mine);
+                if (old == kEmptySlot) { placed = true; break; }
+                if ((old >> 32) == tag && keys_equal(ks, idx, uint32_t(old))) {
+                    uint32_t owner = uint32_t(old);
+                    if (owner > idx) owner = uint32_t(atomicMin(&tab[pos], mine));
+                    if (owner < idx) out.lose(idx, owner);
+                    else             out.lose(owner, idx);
+                    ++dups; placed = true;
+                    break;
+                }
+                pos = (pos & ~seg_mask) | ((pos + 1) & seg_mask);
             }
-            pos = (pos & ~seg_mask) | ((pos + 1) & seg_mask);
+            if (!placed) ++lost;
         }
-        if (!placed) ++lost;
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { dups += __shfl_down(dups, d, 64); lost += __shfl_down(lost, d, 64); }

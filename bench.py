@@ -94,7 +94,7 @@ def main():
     # 2.10): a single all_to_all_single message above 1 GiB arrives corrupted.  The
     # job's input order is (round, rank, position) — file blocks dealt round-robin to the ranks —
     # so round k of rank r holds the global indices below.
-    rec_bytes = 8 * (1 + S * ((L + 31) // 32 + (L + 63) // 64))
+    rec_bytes = 8 * (1 + eng.key_words(L, L if S == 2 else 0))
     lazy = sharded_mode and os.environ.get("FQD_SHARDED_LAZY") == "1"       # hashes first, keys only for candidates
     if lazy:
         rec_bytes = 16

@@ -461,7 +461,9 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
     const uint64_t* final_recs = recA; const uint32_t* bstart = start1;
     {
     Bracket part_br(e, K_PARTITION, n);
-    const uint32_t part_grid = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile, uint64_t(e->n_cu) * 2u));
+    uint32_t part_per_cu = 3u;                                  // 39 KB of LDS per block: 2/3/4/6 swept, 3 best
+    if (const char* v = std::getenv("FQD_PART_BLOCKS_PER_CU")) part_per_cu = uint32_t(std::min(16, std::max(1, std::atoi(v))));
+    const uint32_t part_grid = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile, uint64_t(e->n_cu) * part_per_cu));
     if (!hist1_done)
         hipLaunchKernelGGL(bulk_hist1_kernel, dim3(part_grid), dim3(kPartThreads), 0, e->stream, hashes, hash_stride, n, g, hist1);
     hipLaunchKernelGGL(bulk_scan256_kernel, dim3(1), dim3(320), 0, e->stream,
@@ -470,7 +472,7 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
                        hashes, hash_stride, uint32_t(first_idx), static_cast<const uint64_t*>(nullptr), n, g,
                        static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor1, recA, p.digit2);
     if (g.bits2) {
-        const uint32_t grid2 = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile + nd1, uint64_t(e->n_cu) * 2u));
+        const uint32_t grid2 = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile + nd1, uint64_t(e->n_cu) * part_per_cu));
         hipLaunchKernelGGL(bulk_hist2_kernel, dim3(grid2), dim3(kPartThreads), 0, e->stream,
                            static_cast<const uint8_t*>(p.digit2), g, static_cast<const uint32_t*>(start1),
                            static_cast<const uint32_t*>(tile_start1), hist2);

@@ -461,7 +461,7 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
     const uint64_t* final_recs = recA; const uint32_t* bstart = start1;
     {
     Bracket part_br(e, K_PARTITION, n);
-    uint32_t part_per_cu = 3u;                                  // 39 KB of LDS per block: 2/3/4/6 swept, 3 best
+    uint32_t part_per_cu = 2u;                                  // 75 KB of LDS per 8192-record tile: two fit a CU (1/2/3 swept)
     if (const char* v = std::getenv("FQD_PART_BLOCKS_PER_CU")) part_per_cu = uint32_t(std::min(16, std::max(1, std::atoi(v))));
     const uint32_t part_grid = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile, uint64_t(e->n_cu) * part_per_cu));
     if (!hist1_done)
@@ -487,7 +487,7 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
     }
     Bracket br(e, K_DEDUP, n);
     const size_t lds = (size_t(1) << e->seg_bits) * sizeof(uint64_t) + (2 * kDedupChunk + 4) * sizeof(uint32_t);
-    uint32_t dthreads = kPartThreads;
+    uint32_t dthreads = 512;
     if (const char* v = std::getenv("FQD_DEDUP_THREADS")) dthreads = uint32_t(std::min(1024, std::max(64, std::atoi(v))));
     const uint32_t dgrid = std::min<uint32_t>(n_buckets, uint32_t(e->n_cu) * uint32_t(std::max<size_t>(1, (160 * 1024) / lds)));
     unsigned long long* counters = reinterpret_cast<unsigned long long*>(e->d_state + 1);

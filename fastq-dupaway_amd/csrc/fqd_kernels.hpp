@@ -447,16 +447,16 @@ void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
 // ---------------------------------------------------------------------------
 // Bulk insert: no global atomics on the table.
 //   8-byte records (q << 32 | index) are radix-partitioned by table segment (one or two passes
-//   of up to 256 ways, LDS counting sort per 4096-record tile so the scatter leaves the CU as
+//   of up to 256 ways, LDS counting sort per 8192-record tile so the scatter leaves the CU as
 //   runs of whole lines); q = the table position's bits below the level-1 digit, and above them
 //   the slot tag (part_q).  Then one workgroup per segment replays the same probe/verify/first-wins logic
 //   as insert_kernel on an LDS-resident copy of the segment and writes it back once.
 // Measured motive (tools/atomic_probe.hip): device-scope atomics cap at 18-27 G/s on this chip
 // wherever the table lives, LDS atomics do not.
 
-constexpr int kPartThreads = 512;
+constexpr int kPartThreads = 1024;
 constexpr int kPartPer = 8;
-constexpr int kPartTile = kPartThreads * kPartPer;      // 4096 records per tile
+constexpr int kPartTile = kPartThreads * kPartPer;      // 8192 records per tile (4096: runs too short, 16384: one block per CU)
 
 // level-1 histogram straight from the batch's hashes
 __global__ __launch_bounds__(kPartThreads)

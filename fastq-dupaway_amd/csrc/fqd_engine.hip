@@ -486,7 +486,7 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
     }
     }
     Bracket br(e, K_DEDUP, n);
-    const size_t lds = (size_t(1) << e->seg_bits) * sizeof(uint64_t) + (2 * kDedupChunk + 4) * sizeof(uint32_t);
+    const size_t lds = ((size_t(1) << e->seg_bits) + kDedupChunk + 2) * sizeof(uint64_t);
     uint32_t dthreads = 512;
     if (const char* v = std::getenv("FQD_DEDUP_THREADS")) dthreads = uint32_t(std::min(1024, std::max(64, std::atoi(v))));
     const uint32_t dgrid = std::min<uint32_t>(n_buckets, uint32_t(e->n_cu) * uint32_t(std::max<size_t>(1, (160 * 1024) / lds)));

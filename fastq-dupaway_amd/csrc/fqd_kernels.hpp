@@ -647,12 +647,15 @@ void bulk_scan_buckets_kernel(const uint32_t* __restrict__ count, uint32_t nb, u
 // verification inline, every loop iteration of every wave paid a full gather round trip and
 // 20 M duplicates cost 1.6 ms of a 2.6 ms kernel):
 //   1. probe: every lane walks its records through the LDS table (CAS on EMPTY claims; a tag
-//      match is only QUEUED as a candidate (record, slot));
+//      match is only QUEUED as a candidate);
 //   2. verify: eight lanes per candidate load one key word each of the record and of the slot's
 //      current owner — whole lines, dozens of candidates in flight per wave — and lane 0 applies
 //      the verdict (atomicMin / keep flags) or queues a retry from the next slot;
 //   3. retry (rare: a tag matched an unequal key): per-lane probing with inline verification.
-// LDS: segment (2^seg_bits * 8 B) + 2 queues of kDedupChunk uint32 + 2 counters.
+// A queue entry is self-contained — (tag << seg_bits | slot) << 32 | record index — so the verify
+// phase goes straight from LDS to the two key gathers.  Candidates fill the queue from the front,
+// retries from the back; a retry that would reach the candidates is walked on the spot instead.
+// LDS: segment (2^seg_bits * 8 B) + kDedupChunk queue entries of 8 B + 2 counters.
 constexpr uint32_t kDedupChunk = 1536;
 constexpr uint32_t kDedupFly = 4;
 
@@ -665,22 +668,23 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long seg[];
     const uint32_t seg_slots = 1u << seg_bits, seg_mask = seg_slots - 1u;
-    uint32_t* queue = reinterpret_cast<uint32_t*>(seg + seg_slots);      // (record in chunk << 16) | slot
-    uint32_t* retry = queue + kDedupChunk;
-    uint32_t* qn = retry + kDedupChunk;                                   // qn[0] candidates, qn[1] retries
+    unsigned long long* queue = seg + seg_slots;
+    uint32_t* qn = reinterpret_cast<uint32_t*>(queue + kDedupChunk);     // qn[0] candidates, qn[1] retries
     uint32_t dups = 0, lost = 0;
 
     // One record's walk from `pos`: claims, or (inline == false) queues the first tag match,
     // or (inline == true) verifies tag matches on the spot.
-    auto walk = [&](const uint64_t v, uint32_t c, uint32_t pos, bool verify_inline) {
-        const uint32_t idx = uint32_t(v);
-        const uint64_t tag = uint32_t(v >> 32) >> qshift;
+    auto walk = [&](uint32_t idx, uint32_t tag32, uint32_t pos, bool verify_inline) {
+        const uint64_t tag = tag32;
         const unsigned long long mine = (tag << 32) | idx;
         for (uint32_t probe = 0; probe < seg_slots; ++probe) {
             const unsigned long long old = atomicCAS(&seg[pos], kEmptySlot, mine);
             if (old == kEmptySlot) return;
             if ((old >> 32) == tag) {
-                if (!verify_inline) { queue[atomicAdd(&qn[0], 1u)] = (c << 16) | pos; return; }
+                if (!verify_inline) {
+                    queue[atomicAdd(&qn[0], 1u)] = (uint64_t((tag32 << seg_bits) | pos) << 32) | idx;
+                    return;
+                }
                 if (keys_equal(ks, idx, uint32_t(old))) {
                     uint32_t owner = uint32_t(old);
                     if (owner > idx) owner = uint32_t(atomicMin(&seg[pos], mine));
@@ -715,7 +719,8 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
             // 1. probe
             for (uint32_t c = threadIdx.x; c < chunk_n; c += blockDim.x) {
                 const uint64_t v = recs[chunk_lo + c];
-                walk(v, c, uint32_t(v >> 32) & seg_mask, false);
+                const uint32_t q = uint32_t(v >> 32);
+                walk(uint32_t(v), q >> qshift, q & seg_mask, false);
             }
             __syncthreads();
             // 2. verify, eight lanes per candidate, kDedupFly candidates per group in flight
@@ -724,18 +729,15 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
             for (uint32_t q0 = grp; q0 < n_cand; q0 += n_grp * kDedupFly) {
                 uint32_t pos[kDedupFly], idx[kDedupFly], seen[kDedupFly], tag[kDedupFly];
                 uint64_t diff[kDedupFly];
-                uint32_t cc[kDedupFly];
                 bool live[kDedupFly];
 #pragma unroll
                 for (uint32_t u = 0; u < kDedupFly; ++u) {        // issue every load of the batch first
                     const uint32_t q = q0 + u * n_grp;
                     live[u] = q < n_cand;
-                    diff[u] = 0; pos[u] = 0; idx[u] = 0; seen[u] = 0; tag[u] = 0; cc[u] = 0;
+                    diff[u] = 0; pos[u] = 0; idx[u] = 0; seen[u] = 0; tag[u] = 0;
                     if (live[u]) {
-                        const uint32_t ent = queue[q];
-                        cc[u] = ent >> 16; pos[u] = ent & 0xFFFFu;
-                        const uint64_t v = recs[chunk_lo + cc[u]];
-                        idx[u] = uint32_t(v); tag[u] = uint32_t(v >> 32) >> qshift;
+                        const unsigned long long ent = queue[q];
+                        idx[u] = uint32_t(ent); pos[u] = uint32_t(ent >> 32) & seg_mask; tag[u] = uint32_t(ent >> 32) >> seg_bits;
                         seen[u] = uint32_t(seg[pos[u]]);      // the slot's owner right now: same key class for good
                         const uint64_t* __restrict__ pa = ks.slot(idx[u]);
                         const uint64_t* __restrict__ pb = ks.slot(seen[u]);
@@ -762,17 +764,21 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
                             else                out.lose(owner, idx[u]);
                             ++dups;
                         } else {
-                            retry[atomicAdd(&qn[1], 1u)] = (cc[u] << 16) | ((pos[u] + 1u) & seg_mask);
+                            const uint32_t next = (pos[u] + 1u) & seg_mask;
+                            const uint32_t at = kDedupChunk - 1u - atomicAdd(&qn[1], 1u);
+                            if (at >= n_cand) queue[at] = (uint64_t((tag[u] << seg_bits) | next) << 32) | idx[u];
+                            else              walk(idx[u], tag[u], next, true);      // queue full: settle it now
                         }
                     }
                 }
             }
             __syncthreads();
             // 3. retry the few whose tag matched an unequal key
-            const uint32_t n_retry = qn[1];
+            const uint32_t n_tried = qn[1];
+            const uint32_t n_retry = n_tried < kDedupChunk - n_cand ? n_tried : kDedupChunk - n_cand;   // the rest were settled in phase 2
             for (uint32_t q = threadIdx.x; q < n_retry; q += blockDim.x) {
-                const uint32_t ent = retry[q];
-                walk(recs[chunk_lo + (ent >> 16)], ent >> 16, ent & 0xFFFFu, true);
+                const unsigned long long ent = queue[kDedupChunk - 1u - q];
+                walk(uint32_t(ent), uint32_t(ent >> 32) >> seg_bits, uint32_t(ent >> 32) & seg_mask, true);
             }
             __syncthreads();
         }

@@ -4,6 +4,7 @@
 // gzip, anything else is plain; same diagnostics when a file cannot be opened.
 #pragma once
 #include <cstddef>
+#include <cstdint>
 #include <cstdio>
 #include <deque>
 #include <future>
@@ -33,11 +34,14 @@ public:
     ~InputFile();
     InputFile(const InputFile&) = delete;
     InputFile& operator=(const InputFile&) = delete;
-    // Reads up to n bytes; fewer only at end of file (eof() turns true).
-    size_t read(char* dst, size_t n);
+    // Reads up to n bytes; fewer only at end of file (eof() turns true).  Large reads of a
+    // regular plain file are split over `threads` preads so the copy out of the page cache is
+    // not bound by one core.
+    size_t read(char* dst, size_t n, unsigned threads = 1);
     bool eof() const { return eof_; }
 private:
     bool gz_; gzFile g_ = nullptr; int fd_ = -1; bool eof_ = false;
+    bool regular_ = false; uint64_t size_ = 0, offset_ = 0;     // plain regular files: known size, own cursor
 };
 
 // Plain files go through a 256 KiB stdio buffer (file_utils.cpp:90).  ".gz" files are written
@@ -52,11 +56,18 @@ public:
     OutputFile(const OutputFile&) = delete;
     OutputFile& operator=(const OutputFile&) = delete;
     void write(const char* p, size_t n);
+    // Several pieces in one go: plain files hand them to writev() as they lie (no staging copy).
+    struct Piece { const char* p; size_t n; };
+    void write_pieces(const Piece* pieces, size_t count);
     void close();
 private:
     void submit_block();
     void drain(size_t keep_in_flight);
+    void flush_plain();
+    void put_plain(const char* p, size_t n);
     bool gz_; FILE* f_ = nullptr; std::string name_;
+    int fd_ = -1;                                         // plain: raw descriptor + own 256 KiB buffer
+    std::string plain_buf_;
     std::string block_;                                   // gz: bytes of the member being filled
     std::deque<std::future<std::string>> in_flight_;      // gz: members being deflated, oldest first
     size_t max_in_flight_ = 8;

@@ -144,7 +144,8 @@ struct Side {
         reader = std::thread([this] {
             (void)hipSetDevice(device);
             for (;;) {
-                PooledBlock* b = pool.pop();
+                PooledBlock* b;
+                { StageClock::Scope t("reader: wait for a free block"); b = pool.pop(); }
                 if (!b || stop.load()) break;
                 b->error = nullptr; b->stream_end = false;
                 bool more = false;
@@ -172,7 +173,8 @@ struct Side {
                 cur->release(); cur = nullptr;
                 if (was_last) { ended = true; break; }
             }
-            PooledBlock* b = ready.pop();
+            PooledBlock* b;
+            { StageClock::Scope t("main: wait for a block"); b = ready.pop(); }
             if (b->error) { std::exception_ptr err = b->error; b->error = nullptr; pool.push(b); ended = true; std::rethrow_exception(err); }
             if (b->stream_end) { pool.push(b); ended = true; break; }
             b->users.store(1);       // the feeder's reference
@@ -225,7 +227,9 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
     hipStream_t stream = nullptr;
     HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
-    EngineHandle eng(S, tuning_.device, stream);
+    std::unique_ptr<EngineHandle> eng_holder;
+    { StageClock::Scope t("main: engine create"); eng_holder = std::make_unique<EngineHandle>(S, tuning_.device, stream); }
+    EngineHandle& eng = *eng_holder;
 
     constexpr int kWorks = 3;
     std::vector<std::unique_ptr<Work>> works;
@@ -236,14 +240,18 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
     //      verbatim, in input order ----------------------------------------------------------
     Channel<Work> to_write[2];
     std::exception_ptr writer_error[2];
+    std::vector<OutputFile::Piece> pieces[2];
     auto writer_body = [&](int s) {
         bool failed_already = false;
         for (;;) {
-            Work* w = to_write[s].pop();
+            Work* w;
+            { StageClock::Scope t("writer: wait for a batch"); w = to_write[s].pop(); }
             const bool stop = w->stop;
             if (!stop && !failed_already) {
+                StageClock::Scope t("writer: write survivors");
                 try {
                     const Block& b = *w->blk[s];
+                    pieces[s].clear();                       // runs of adjacent survivors, written where they lie
                     const char* run_from = nullptr; size_t run_len = 0;
                     for (size_t k = 0; k < w->n; ++k) {
                         const RecordRef& r = b.recs[w->begin[s] + k];
@@ -251,10 +259,11 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
                         if (keep) {
                             const char* p = b.text.p + r.start;
                             if (run_from && run_from + run_len == p) run_len += r.size;
-                            else { if (run_len) sink[s]->write(run_from, run_len); run_from = p; run_len = r.size; }
+                            else { if (run_len) pieces[s].push_back({run_from, run_len}); run_from = p; run_len = r.size; }
                         }
                     }
-                    if (run_len) sink[s]->write(run_from, run_len);
+                    if (run_len) pieces[s].push_back({run_from, run_len});
+                    sink[s]->write_pieces(pieces[s].data(), pieces[s].size());
                 } catch (...) { writer_error[s] = std::current_exception(); failed_already = true; }
             }
             if (!stop) w->blk[s]->release();
@@ -278,7 +287,8 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
 
     auto finish = [&](Work* w) {
         // waits for the batch; on an unknown base cuts the output at that record
-        const int rc = fqd_engine_sync(eng.e);
+        int rc;
+        { StageClock::Scope t("main: wait for the GPU"); rc = fqd_engine_sync(eng.e); }
         if (rc == FQD_ERR_BAD_BASE) {
             uint32_t seg, pos;
             fqd_bad_base(eng.e, &bad_record, &seg, &pos, &bad_byte);
@@ -297,7 +307,9 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
             size_t n = kMaxBatch;
             for (int s = 0; s < S; ++s) n = std::min(n, side[s].available());
             if (n == 0) break;
-            Work* w = free_works.pop();
+            Work* w;
+            { StageClock::Scope t("main: wait for a free batch"); w = free_works.pop(); }
+            StageClock::Scope prep("main: prepare + enqueue batch");
             w->stop = false; w->n = n; w->first_index = next_index; w->emit_below = ~0ull;
             fqd_reads seg[2] = {};
             w->keep.reserve(n); w->d_keep.reserve(n);
@@ -345,9 +357,10 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
         stop_writer();
         throw;
     }
-    stop_writer();
+    { StageClock::Scope t("main: drain writers"); stop_writer(); }
     for (int s = 0; s < S; ++s) if (writer_error[s]) std::rethrow_exception(writer_error[s]);
-    for (int s = 0; s < S; ++s) sink[s]->close();
+    { StageClock::Scope t("main: close outputs"); for (int s = 0; s < S; ++s) sink[s]->close(); }
+    StageClock::report();
 
     fqd_stats st{};
     fqd_get_stats(eng.e, &st);

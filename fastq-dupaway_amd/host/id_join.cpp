@@ -19,9 +19,9 @@ void load_whole_file(const std::string& name, Format f, size_t block_bytes, Load
         size_t have = carry.size();
         if (have) std::memcpy(buf.get(), carry.data(), have);
         carry.clear();
-        have += file.read(buf.get() + have, cap - have);
+        have += file.read(buf.get() + have, cap - have, host_threads());
         refs.clear();
-        const size_t consumed = scan_records(f, true, buf.get(), have, refs, out.failure);
+        const size_t consumed = scan_records_parallel(f, true, buf.get(), have, refs, out.failure, host_threads());
         if (first && refs.empty() && !out.failure.set)
             throw std::runtime_error("Not enough memory to read a single object!");
         first = false;

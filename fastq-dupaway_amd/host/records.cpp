@@ -1,9 +1,16 @@
 #include "records.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 #include <cstring>
+#include <emmintrin.h>
 #include <hip/hip_runtime_api.h>
 #include <stdexcept>
+#include <thread>
 
 namespace fqdhost {
 
@@ -16,8 +23,11 @@ inline const char* find_nl(const char* b, const char* e)
 
 } // namespace
 
-size_t scan_records(Format f, bool want_tag, const char* text, size_t n,
-                    std::vector<RecordRef>& out, ParseFailure& fail)
+namespace {
+
+// The scanner proper; emit(record) receives every complete, well-formed record in order.
+template <class Emit>
+size_t scan_core(Format f, bool want_tag, const char* text, size_t n, Emit&& emit, ParseFailure& fail)
 {
     const char* const base = text;
     const char* const end = text + n;
@@ -66,10 +76,145 @@ size_t scan_records(Format f, bool want_tag, const char* text, size_t n,
             r.tag_off = static_cast<uint32_t>(tag - p);
             r.tag_len = static_cast<uint32_t>((sp ? sp : id_end) - tag);
         }
-        out.push_back(r);
+        emit(r);
         p += size;
     }
     return static_cast<size_t>(p - base);
+}
+
+} // namespace
+
+size_t scan_records(Format f, bool want_tag, const char* text, size_t n,
+                    std::vector<RecordRef>& out, ParseFailure& fail)
+{
+    return scan_core(f, want_tag, text, n, [&](const RecordRef& r) { out.push_back(r); }, fail);
+}
+
+namespace {
+double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+std::mutex g_clock_mutex;
+std::map<std::string, std::pair<double, uint64_t>> g_clock;
+} // namespace
+
+bool StageClock::on() { static const bool v = std::getenv("FQD_HOST_TIMING") != nullptr; return v; }
+void StageClock::add(const char* stage, double seconds)
+{
+    std::lock_guard<std::mutex> g(g_clock_mutex);
+    auto& e = g_clock[stage]; e.first += seconds; ++e.second;
+}
+void StageClock::report()
+{
+    if (!on()) return;
+    std::lock_guard<std::mutex> g(g_clock_mutex);
+    for (const auto& kv : g_clock) std::fprintf(stderr, "[host timing] %-28s %8.3f s  (%llu)\n", kv.first.c_str(), kv.second.first,
+                                                static_cast<unsigned long long>(kv.second.second));
+}
+StageClock::Scope::Scope(const char* s) : stage(s), t0(on() ? now_seconds() : 0.0) {}
+StageClock::Scope::~Scope() { if (on()) add(stage, now_seconds() - t0); }
+
+unsigned host_threads()
+{
+    if (const char* v = std::getenv("FQD_HOST_THREADS")) return static_cast<unsigned>(std::max(1, std::atoi(v)));
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(8u, hw ? hw : 1u));
+}
+
+namespace {
+
+// Runs body(0..parts-1), part 0 on the calling thread.  An exception of any part is rethrown.
+template <class Body>
+void run_parts(unsigned parts, Body&& body)
+{
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> err(parts);
+    auto guarded = [&](unsigned p) { try { body(p); } catch (...) { err[p] = std::current_exception(); } };
+    for (unsigned p = 1; p < parts; ++p) pool.emplace_back(guarded, p);
+    guarded(0);
+    for (std::thread& t : pool) t.join();
+    for (unsigned p = 0; p < parts; ++p) if (err[p]) std::rethrow_exception(err[p]);
+}
+
+size_t count_newlines(const char* b, const char* e)
+{
+    size_t cnt = 0;
+    const __m128i nl = _mm_set1_epi8('\n'), zero = _mm_setzero_si128();
+    while (b + 16 <= e) {
+        // matches are 0xFF = -1 per byte: subtract them into byte counters, 255 rounds at most
+        __m128i acc = zero;
+        const size_t rounds = std::min<size_t>(255, static_cast<size_t>(e - b) / 16);
+        for (size_t r = 0; r < rounds; ++r, b += 16)
+            acc = _mm_sub_epi8(acc, _mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(b)), nl));
+        const __m128i sums = _mm_sad_epu8(acc, zero);         // two 64-bit partial sums
+        cnt += static_cast<size_t>(_mm_cvtsi128_si64(sums)) + static_cast<size_t>(_mm_cvtsi128_si64(_mm_srli_si128(sums, 8)));
+    }
+    for (; b < e; ++b) cnt += *b == '\n';
+    return cnt;
+}
+
+} // namespace
+
+size_t scan_records_parallel(Format f, bool want_tag, const char* text, size_t n,
+                             std::vector<RecordRef>& out, ParseFailure& fail, unsigned threads)
+{
+    static const size_t kMinSlice = [] {                   // FQD_SCAN_MIN_SLICE: test hook
+        const char* v = std::getenv("FQD_SCAN_MIN_SLICE");
+        return v ? static_cast<size_t>(std::max(1L, std::atol(v))) : size_t(4u << 20);
+    }();
+    const unsigned parts = static_cast<unsigned>(std::min<size_t>(threads, n / kMinSlice));
+    if (parts <= 1) return scan_records(f, want_tag, text, n, out, fail);
+    const size_t n_lines = f == Format::Fastq ? 4 : 2;
+
+    // 1. newlines per slice -> index of the line each slice starts in
+    std::vector<size_t> cut(parts + 1), lines(parts);
+    for (unsigned p = 0; p <= parts; ++p) cut[p] = n / parts * p;
+    cut[parts] = n;
+    run_parts(parts, [&](unsigned p) { lines[p] = count_newlines(text + cut[p], text + cut[p + 1]); });
+
+    // 2. first record start at or after each cut (a line start whose index is a multiple of
+    //    n_lines) and how many records start before it
+    std::vector<size_t> start(parts + 1, n), first_rec(parts + 1, 0);
+    size_t before = 0;                                     // newlines in text[0, cut[p])
+    for (unsigned p = 0; p < parts; ++p) {
+        const char* q = text + cut[p];
+        size_t line = before;                              // index of the line q lies in
+        if (cut[p] != 0 && q[-1] != '\n') {                // inside a line: go to the next line start
+            const char* nl = find_nl(q, text + n);
+            q = nl ? nl + 1 : nullptr; ++line;
+        }
+        while (q && line % n_lines != 0) {
+            const char* nl = find_nl(q, text + n);
+            q = nl ? nl + 1 : nullptr; ++line;
+        }
+        start[p] = q ? static_cast<size_t>(q - text) : n;
+        first_rec[p] = line / n_lines;
+        before += lines[p];
+    }
+    first_rec[parts] = before / n_lines;                   // complete records in the whole text, if all are well formed
+    for (unsigned p = parts; p-- > 0;)                     // a slice that lies inside one long record owns nothing
+        if (start[p] >= start[p + 1]) { start[p] = start[p + 1]; first_rec[p] = first_rec[p + 1]; }
+
+    // 3. every slice writes its records straight to their final places
+    const size_t base = out.size();
+    out.resize(base + first_rec[parts]);
+    std::vector<size_t> found(parts, 0), consumed(parts, 0);
+    std::vector<ParseFailure> failed(parts);
+    run_parts(parts, [&](unsigned p) {
+        RecordRef* dst = out.data() + base + first_rec[p];
+        const size_t room = first_rec[p + 1] - first_rec[p], off = start[p];
+        size_t k = 0;
+        consumed[p] = scan_core(f, want_tag, text + off, start[p + 1] - off,
+                                [&](const RecordRef& r) { if (k < room) { dst[k] = r; dst[k].start += off; } ++k; }, failed[p]);
+        found[p] = k;
+    });
+    for (unsigned p = 0; p < parts; ++p) {
+        const bool whole = !failed[p].set && consumed[p] == start[p + 1] - start[p] && found[p] == first_rec[p + 1] - first_rec[p];
+        if (whole) continue;
+        // a malformed record, or the incomplete record at the end of the text: the scan ends here
+        out.resize(base + first_rec[p] + std::min(found[p], first_rec[p + 1] - first_rec[p]));
+        if (failed[p].set) fail = failed[p];
+        return start[p] + consumed[p];
+    }
+    return start[parts];
 }
 
 int compare_tags(const char* a, uint32_t alen, const char* b, uint32_t blen)
@@ -99,12 +244,13 @@ bool RecordStream::fill(Block& b)
     if (done_) return false;
     b.recs.clear(); b.used = 0; b.last = false; b.failure = ParseFailure(); b.held_back = false; b.first_record = n_records_;
     const size_t want = std::max(block_bytes_, carry_.size() + block_bytes_ / 2);
-    b.text.reserve(want + 16);
+    { StageClock::Scope t("reader: pinned alloc"); b.text.reserve(want + 16); }
     size_t have = carry_.size();
     if (have) std::memcpy(b.text.p, carry_.data(), have);
     carry_.clear();
-    have += file_.read(b.text.p + have, want - have);
-    size_t consumed = scan_records(fmt_, want_tag_, b.text.p, have, b.recs, b.failure);
+    { StageClock::Scope t("reader: file read"); have += file_.read(b.text.p + have, want - have, host_threads()); }
+    size_t consumed;
+    { StageClock::Scope t("reader: record scan"); consumed = scan_records_parallel(fmt_, want_tag_, b.text.p, have, b.recs, b.failure, host_threads()); }
     if (b.failure.set) {
         b.last = true; done_ = true;
         if (!b.recs.empty()) { b.recs.pop_back(); b.held_back = true; }      // fetched by the lookahead, never processed

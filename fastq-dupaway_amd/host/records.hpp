@@ -19,6 +19,7 @@ enum class Format { Fastq, Fasta };
 
 // One record inside a block; positions are byte offsets into the block's text.
 struct RecordRef {
+    RecordRef() {}       // left uninitialised on purpose: vectors of millions are resized, then filled by several threads
     uint64_t start;      // first byte of the ID line ('@' or '>')
     uint32_t size;       // whole record, every newline included (what survivors are written with)
     uint32_t id_len;     // ID line including its '\n'
@@ -39,6 +40,29 @@ struct ParseFailure {
 // (start of the first incomplete record).  Stops at a malformed record and fills `fail`.
 size_t scan_records(Format f, bool want_tag, const char* text, size_t n,
                     std::vector<RecordRef>& out, ParseFailure& fail);
+
+// The same scan on several threads, with the same result: lines are counted per slice first, so
+// every slice knows which of its line starts begin a record (every 4th / 2nd line of the file),
+// then the slices are scanned independently and stitched together in order; the earliest
+// malformed record wins, exactly as when scanning from the front.  Falls back to scan_records
+// for small inputs or threads <= 1.
+size_t scan_records_parallel(Format f, bool want_tag, const char* text, size_t n,
+                             std::vector<RecordRef>& out, ParseFailure& fail, unsigned threads);
+
+// FQD_HOST_TIMING=1: wall time per host stage, summed over the run and printed to stderr at exit.
+struct StageClock {
+    static bool on();
+    static void add(const char* stage, double seconds);
+    static void report();
+    struct Scope {
+        const char* stage; double t0;
+        explicit Scope(const char* s);
+        ~Scope();
+    };
+};
+
+// Worker threads a host stage may use: FQD_HOST_THREADS, else min(8, hardware threads).
+unsigned host_threads();
 
 // Order of two ID tags: strncmp over the shorter, then shorter first (fastqview.cpp:168-178).
 int compare_tags(const char* a, uint32_t alen, const char* b, uint32_t blen);

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--paired", action="store_true")
     ap.add_argument("--dir", default="/tmp")
     ap.add_argument("--oracle-reads", type=int, default=2_000_000)
+    ap.add_argument("--host-threads", default="", help="comma list: also time the CLI under FQD_HOST_THREADS=<each>")
     a = ap.parse_args()
     from fastq_dupaway_amd import _lib
     from oracle import binding
@@ -59,9 +60,14 @@ def main():
     args = [str(_lib.CLI_PATH), "-i", str(files[0]), "-o", str(outs[0]), "--fast", "-v"]
     if a.paired:
         args += ["-u", str(files[1]), "-p", str(outs[1])]
-    for rep in range(2):
-        t0 = time.perf_counter(); r = subprocess.run(args, capture_output=True, text=True); dt = time.perf_counter() - t0
-        print(f"cli run {rep}: rc={r.returncode} {dt:.2f} s  {n / dt / 1e6:.2f} Mreads/s  {size / dt / 1e9:.2f} GB/s  | {r.stdout.strip()} {r.stderr.strip()[:200]}")
+    for threads in [t for t in a.host_threads.split(",") if t] + [""]:
+        env = dict(os.environ, FQD_HOST_THREADS=threads) if threads else dict(os.environ)
+        for rep in range(2):
+            for o in outs:                       # a fresh output file each time (rewriting an existing one pays an extra flush at close on ext4)
+                o.unlink(missing_ok=True)
+            t0 = time.perf_counter(); r = subprocess.run(args, capture_output=True, text=True, env=env); dt = time.perf_counter() - t0
+            print(f"cli run {rep} (host threads {threads or 'default'}): rc={r.returncode} {dt:.2f} s  {n / dt / 1e6:.2f} Mreads/s  "
+                  f"{size / dt / 1e9:.2f} GB/s  | {r.stdout.strip()} {r.stderr.strip()[:2000]}")
     oracle = binding.load_oracle()
     m = min(a.oracle_reads, n)
     if m < n:                                   # the oracle is timed on a prefix (one CPU core)

@@ -29,20 +29,50 @@ void throw_cannot_open(const std::string& name)
     throw DiagnosedError("Cannot open file " + name + "\n", "File does not exist or cannot be opened!");
 }
 
+namespace {
+
+// Length of the BGZF member that starts at p (at least 18 bytes readable), or 0 if p does not
+// start one: gzip header with FLG = FEXTRA and a 'B','C' subfield holding (total size - 1).
+size_t bgzf_member_size(const unsigned char* p, size_t avail, size_t* data_off)
+{
+    if (avail < 18 || p[0] != 31 || p[1] != 139 || p[2] != 8 || p[3] != 4) return 0;
+    const size_t xlen = p[10] | (size_t(p[11]) << 8);
+    if (avail < 12 + xlen) return 0;
+    for (size_t at = 12; at + 4 <= 12 + xlen;) {
+        const size_t slen = p[at + 2] | (size_t(p[at + 3]) << 8);
+        if (p[at] == 'B' && p[at + 1] == 'C' && slen == 2 && at + 6 <= 12 + xlen) {
+            *data_off = 12 + xlen;
+            const size_t total = (p[at + 4] | (size_t(p[at + 5]) << 8)) + 1;
+            return total >= 12 + xlen + 8 ? total : 0;
+        }
+        at += 4 + slen;
+    }
+    return 0;
+}
+
+} // namespace
+
 InputFile::InputFile(const std::string& name) : gz_(has_gz_extension(name))
 {
-    if (gz_) {
-        g_ = gzopen(name.c_str(), "rb");
-        if (!g_) throw_cannot_open(name);
-        gzbuffer(g_, 4u << 20);
-    } else {
-        fd_ = ::open(name.c_str(), O_RDONLY);
-        if (fd_ < 0) throw_cannot_open(name);
+    fd_ = ::open(name.c_str(), O_RDONLY);
+    if (fd_ < 0) throw_cannot_open(name);
 #ifdef POSIX_FADV_SEQUENTIAL
-        (void)posix_fadvise(fd_, 0, 0, POSIX_FADV_SEQUENTIAL);
+    (void)posix_fadvise(fd_, 0, 0, POSIX_FADV_SEQUENTIAL);
 #endif
-        struct stat st;
-        if (::fstat(fd_, &st) == 0 && S_ISREG(st.st_mode)) { regular_ = true; size_ = static_cast<uint64_t>(st.st_size); }
+    struct stat st;
+    if (::fstat(fd_, &st) == 0 && S_ISREG(st.st_mode)) { regular_ = true; size_ = static_cast<uint64_t>(st.st_size); }
+    if (gz_) {
+        unsigned char head[64];
+        size_t off = 0;
+        const ssize_t k = regular_ ? ::pread(fd_, head, sizeof head, 0) : 0;
+        if (k >= 18 && bgzf_member_size(head, static_cast<size_t>(k), &off) != 0) {
+            bgzf_ = true;
+        } else {
+            ::close(fd_); fd_ = -1;
+            g_ = gzopen(name.c_str(), "rb");
+            if (!g_) throw_cannot_open(name);
+            gzbuffer(g_, 4u << 20);
+        }
     }
 }
 
@@ -52,8 +82,118 @@ InputFile::~InputFile()
     if (fd_ >= 0) ::close(fd_);
 }
 
+// Tops the compressed buffer up; false when nothing more can come.
+bool InputFile::fill_compressed()
+{
+    if (comp_eof_) return false;
+    if (comp_pos_ > 0) { comp_.erase(comp_.begin(), comp_.begin() + static_cast<ptrdiff_t>(comp_pos_)); comp_pos_ = 0; }
+    constexpr size_t kChunk = 16u << 20;
+    const size_t old = comp_.size();
+    comp_.resize(old + kChunk);
+    size_t got = 0;
+    while (got < kChunk) {
+        const ssize_t k = ::pread(fd_, comp_.data() + old + got, kChunk - got, static_cast<off_t>(offset_));
+        if (k < 0) { if (errno == EINTR) continue; throw std::runtime_error(std::string("read failed: ") + std::strerror(errno)); }
+        if (k == 0) { comp_eof_ = true; break; }
+        got += static_cast<size_t>(k); offset_ += static_cast<uint64_t>(k);
+    }
+    comp_.resize(old + got);
+    return got > 0;
+}
+
+size_t InputFile::read_bgzf(char* dst, size_t n, unsigned threads)
+{
+    struct Member { size_t at, data_off, total, isize; };
+    // 1 = a whole member lies at `at`, 0 = more compressed bytes are needed, -1 = not a BGZF member
+    auto member_at = [&](size_t at, Member& m) -> int {
+        const size_t avail = comp_.size() - at;
+        const unsigned char* p = comp_.data() + at;
+        if (avail < 18) return 0;
+        if (p[0] != 31 || p[1] != 139 || p[2] != 8 || p[3] != 4) return -1;
+        if (avail < 12 + (p[10] | (size_t(p[11]) << 8))) return 0;
+        size_t off = 0;
+        const size_t total = bgzf_member_size(p, avail, &off);
+        if (total == 0) return -1;
+        if (avail < total) return 0;
+        const unsigned char* tail = p + total - 4;
+        m = Member{at, off, total, tail[0] | (size_t(tail[1]) << 8) | (size_t(tail[2]) << 16) | (size_t(tail[3]) << 24)};
+        return 1;
+    };
+    size_t got = 0;
+    while (got < n && !eof_) {
+        if (spill_pos_ < spill_.size()) {                        // what the previous call could not take
+            const size_t k = std::min(n - got, spill_.size() - spill_pos_);
+            std::memcpy(dst + got, spill_.data() + spill_pos_, k);
+            spill_pos_ += k; got += k;
+            continue;
+        }
+        // cut a batch of whole members out of the compressed buffer
+        std::vector<Member> batch;
+        size_t out_bytes = 0, at = comp_pos_;
+        for (;;) {
+            Member m{};
+            const int r = member_at(at, m);
+            if (r < 0) throw std::runtime_error("gzip input is corrupt or truncated");
+            if (r == 1) {
+                batch.push_back(m); out_bytes += m.isize; at += m.total;
+                if (out_bytes >= n - got || batch.size() >= 4096) break;
+                continue;
+            }
+            if (!batch.empty()) break;                           // inflate what is here before fetching more
+            const size_t pending = comp_.size() - comp_pos_;
+            if (!fill_compressed()) {
+                if (pending != 0) throw std::runtime_error("gzip input is corrupt or truncated");
+                eof_ = true;
+                break;
+            }
+            at = comp_pos_;
+        }
+        if (batch.empty()) continue;
+        // members that fit go straight to dst; one that straddles the end goes to the spill buffer
+        std::vector<char*> target(batch.size(), nullptr);
+        size_t pos = got, used = 0;
+        spill_.clear(); spill_pos_ = 0;
+        for (; used < batch.size(); ++used) {
+            if (pos + batch[used].isize <= n) { target[used] = dst + pos; pos += batch[used].isize; }
+            else { spill_.resize(batch[used].isize); target[used] = spill_.data(); ++used; break; }
+        }
+        batch.resize(used);
+        const unsigned parts = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(threads, batch.size() / 8)));
+        std::vector<int> bad(parts, 0);
+        auto work = [&](unsigned p) {
+            z_stream zs{};
+            if (inflateInit2(&zs, -15) != Z_OK) { bad[p] = 1; return; }
+            for (size_t k = p; k < batch.size(); k += parts) {
+                const Member& m = batch[k];
+                if (m.isize == 0) continue;                       // the end-of-file marker, or an empty flush
+                const unsigned char* src = comp_.data() + m.at;
+                inflateReset(&zs);
+                zs.next_in = const_cast<Bytef*>(src + m.data_off);
+                zs.avail_in = static_cast<uInt>(m.total - m.data_off - 8);
+                zs.next_out = reinterpret_cast<Bytef*>(target[k]);
+                zs.avail_out = static_cast<uInt>(m.isize);
+                const int rc = inflate(&zs, Z_FINISH);
+                const unsigned char* t = src + m.total - 8;
+                const uLong want_crc = t[0] | (uLong(t[1]) << 8) | (uLong(t[2]) << 16) | (uLong(t[3]) << 24);
+                if (rc != Z_STREAM_END || zs.avail_out != 0 ||
+                    crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(target[k]), static_cast<uInt>(m.isize)) != want_crc) { bad[p] = 1; break; }
+            }
+            inflateEnd(&zs);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned p = 1; p < parts; ++p) pool.emplace_back(work, p);
+        work(0);
+        for (std::thread& t : pool) t.join();
+        for (unsigned p = 0; p < parts; ++p) if (bad[p]) throw std::runtime_error("gzip input is corrupt or truncated");
+        comp_pos_ = batch.back().at + batch.back().total;
+        got = pos;
+    }
+    return got;
+}
+
 size_t InputFile::read(char* dst, size_t n, unsigned threads)
 {
+    if (bgzf_) return read_bgzf(dst, n, threads);
     constexpr size_t kMinPart = 16u << 20;
     if (!gz_ && regular_ && threads > 1 && n >= 2 * kMinPart && !eof_) {
         const size_t want = static_cast<size_t>(std::min<uint64_t>(n, size_ > offset_ ? size_ - offset_ : 0));
@@ -110,26 +250,45 @@ size_t InputFile::read(char* dst, size_t n, unsigned threads)
 
 namespace {
 
-constexpr size_t kGzMember = 1u << 20;                   // uncompressed bytes per gzip member
+constexpr size_t kBgzfInput = 0xff00;                     // input bytes per BGZF member (as bgzip)
+constexpr size_t kGzMember = 16 * kBgzfInput;             // input bytes per deflate job: 16 members
 
-// One complete gzip member (header + deflate stream + CRC/length trailer) for `raw`.
+// The BGZF members (header with the 'BC' size field + raw deflate stream + CRC/length trailer)
+// for `raw`, one per kBgzfInput bytes.
 std::string deflate_member(std::string raw)
 {
+    std::string out;
+    out.reserve(raw.size() / 3 + 1024);
     z_stream zs{};
-    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK)
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK)
         throw std::runtime_error("zlib: deflateInit2 failed");
-    std::string out(deflateBound(&zs, static_cast<uLong>(raw.size())) + 64, '\0');
-    zs.next_in = reinterpret_cast<Bytef*>(raw.data());
-    zs.avail_in = static_cast<uInt>(raw.size());
-    zs.next_out = reinterpret_cast<Bytef*>(out.data());
-    zs.avail_out = static_cast<uInt>(out.size());
-    const int rc = deflate(&zs, Z_FINISH);
-    const size_t produced = out.size() - zs.avail_out;
+    unsigned char body[65536];
+    for (size_t at = 0; at < raw.size(); at += kBgzfInput) {
+        const size_t len = std::min(kBgzfInput, raw.size() - at);
+        deflateReset(&zs);
+        zs.next_in = reinterpret_cast<Bytef*>(&raw[at]);
+        zs.avail_in = static_cast<uInt>(len);
+        zs.next_out = body;
+        zs.avail_out = static_cast<uInt>(sizeof body - 26);
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); throw std::runtime_error("zlib: deflate failed"); }
+        const size_t clen = sizeof body - 26 - zs.avail_out;
+        const size_t total = 18 + clen + 8;
+        const uLong crc = crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(&raw[at]), static_cast<uInt>(len));
+        const unsigned char head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0,
+                                        static_cast<unsigned char>((total - 1) & 0xFF), static_cast<unsigned char>((total - 1) >> 8)};
+        const unsigned char tail[8] = {static_cast<unsigned char>(crc), static_cast<unsigned char>(crc >> 8),
+                                       static_cast<unsigned char>(crc >> 16), static_cast<unsigned char>(crc >> 24),
+                                       static_cast<unsigned char>(len), static_cast<unsigned char>(len >> 8), 0, 0};
+        out.append(reinterpret_cast<const char*>(head), sizeof head);
+        out.append(reinterpret_cast<const char*>(body), clen);
+        out.append(reinterpret_cast<const char*>(tail), sizeof tail);
+    }
     deflateEnd(&zs);
-    if (rc != Z_STREAM_END) throw std::runtime_error("zlib: deflate failed");
-    out.resize(produced);
     return out;
 }
+
+// The empty member every BGZF file ends with.
+const unsigned char kBgzfEof[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 } // namespace
 
@@ -239,10 +398,7 @@ void OutputFile::close()
     if (!f_) return;
     submit_block();
     drain(0);
-    if (std::ftell(f_) == 0) {                              // nothing was written: still a valid (empty) gzip file
-        const std::string member = deflate_member(std::string());
-        std::fwrite(member.data(), 1, member.size(), f_);
-    }
+    if (std::fwrite(kBgzfEof, 1, sizeof kBgzfEof, f_) != sizeof kBgzfEof) throw std::runtime_error("write failed: " + name_);
     std::fclose(f_);
     f_ = nullptr;
 }

@@ -10,6 +10,7 @@
 #include <future>
 #include <stdexcept>
 #include <string>
+#include <vector>
 #include <zlib.h>
 
 namespace fqdhost {
@@ -40,15 +41,26 @@ public:
     size_t read(char* dst, size_t n, unsigned threads = 1);
     bool eof() const { return eof_; }
 private:
+    size_t read_bgzf(char* dst, size_t n, unsigned threads);
+    bool fill_compressed();
     bool gz_; gzFile g_ = nullptr; int fd_ = -1; bool eof_ = false;
     bool regular_ = false; uint64_t size_ = 0, offset_ = 0;     // plain regular files: known size, own cursor
+    // BGZF (blocked gzip, what bgzip / sequencer software write): every member says how long it
+    // is, so a batch of members is cut out of the compressed stream without inflating and then
+    // inflated on several threads, each member straight to its place in the caller's buffer.
+    bool bgzf_ = false, comp_eof_ = false;
+    std::vector<unsigned char> comp_;                           // compressed bytes not yet consumed
+    size_t comp_pos_ = 0;
+    std::vector<char> spill_;                                   // inflated tail of a member that did not fit the last read
+    size_t spill_pos_ = 0;
 };
 
-// Plain files go through a 256 KiB stdio buffer (file_utils.cpp:90).  ".gz" files are written
-// as a sequence of independent gzip members, one per 1 MiB of output, deflated on worker threads
-// and written in order: the decompressed content is what the reference would have written
-// (file_utils.cpp:87-88; gzip readers concatenate members), the deflate work no longer runs on
-// one core.
+// Plain files go through a 256 KiB buffer (file_utils.cpp:90).  ".gz" files are written as BGZF:
+// independent gzip members of at most 65280 input bytes, each carrying its compressed size in the
+// header's extra field, closed by the empty end-of-file member.  Batches of members are deflated
+// on worker threads and written in order: the decompressed content is what the reference would
+// have written (file_utils.cpp:87-88; gzip readers concatenate members), any gzip tool reads it,
+// and BGZF-aware readers (this one included) can inflate it in parallel.
 class OutputFile {
 public:
     explicit OutputFile(const std::string& name);

@@ -1,0 +1,28 @@
+// io_check — exercises the host driver's file layer (fastq-dupaway_amd/host/file_io.cpp) without a GPU:
+//   io_check w <out> <n bytes> <seed>       writes n pseudo-random bytes in uneven pieces; prints "<n> <fnv>"
+//   io_check r <in> <chunk> <threads>       reads the file back in chunks; prints "<n> <fnv>"
+// tests/test_host_io.py compares the two, also against Python's gzip module.
+#include "../../fastq-dupaway_amd/host/file_io.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+using namespace fqdhost;
+int main(int argc, char** argv) {
+    std::string mode = argv[1];
+    try {
+    if (mode == "w") {
+        size_t n = std::strtoull(argv[3], nullptr, 10); unsigned seed = std::atoi(argv[4]);
+        std::string data(n, 'A'); for (size_t i = 0; i < n; ++i) { seed = seed * 1664525u + 1013904223u; data[i] = "ACGTN\n@+I"[(seed >> 24) % 9]; }
+        OutputFile o(argv[2]); size_t at = 0; while (at < n) { size_t k = std::min<size_t>(n - at, 1 + (seed = seed * 1664525u + 1013904223u) % 200000); o.write(data.data() + at, k); at += k; } o.close();
+        unsigned long long h = 1469598103934665603ull; for (unsigned char c : data) { h ^= c; h *= 1099511628211ull; }
+        std::printf("%zu %llu\n", n, h);
+    } else {
+        InputFile in(argv[2]); size_t chunk = std::strtoull(argv[3], nullptr, 10); unsigned th = std::atoi(argv[4]);
+        std::vector<char> buf(chunk); unsigned long long h = 1469598103934665603ull; size_t tot = 0;
+        while (!in.eof()) { size_t k = in.read(buf.data(), chunk, th); for (size_t i = 0; i < k; ++i) { h ^= (unsigned char)buf[i]; h *= 1099511628211ull; } tot += k; if (k == 0 && in.eof()) break; }
+        std::printf("%zu %llu\n", tot, h);
+    }
+    } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 1; }
+    return 0;
+}

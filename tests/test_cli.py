@@ -251,7 +251,7 @@ def test_unordered_fastq_matches_oracle_bytes(exe, oracle, tmp_path, style, full
 @pytest.mark.gpu
 def test_gz_in_and_out(exe, oracle, tmp_path):
     rnd = random.Random(61)
-    # > 4 MiB of output: several gzip members deflated on worker threads, written in order
+    # > 4 MiB of output: batches of BGZF members deflated on worker threads, written in order
     raw = fastq([(b"g%05d" % k, s) for k, s in enumerate(random_reads(rnd, 60000, 30000, 30, 80))])
     src = tmp_path / "in.fq.gz"
     with gzip.open(src, "wb") as f:
@@ -267,6 +267,12 @@ def test_gz_in_and_out(exe, oracle, tmp_path):
     again = tmp_path / "again.fq"
     oracle.filter_single(got, again, FASTQ)
     assert again.read_bytes() == exp.read_bytes()
+    # and the CLI reads its own BGZF output back (members inflated on several threads): nothing left to remove
+    third = tmp_path / "third.fq"
+    r = run(exe, "-i", got, "-o", third, "--fast", "-v")
+    assert r.returncode == 0, r.stderr
+    assert third.read_bytes() == exp.read_bytes()
+    assert "out of which 0 duplicates were removed" in r.stdout
 
 
 # ---------------------------------------------------------------- GPU: error behaviour

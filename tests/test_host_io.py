@@ -1,0 +1,77 @@
+"""File layer of the host driver (fastq-dupaway_amd/host/file_io.cpp), no GPU involved:
+".gz" outputs are BGZF (any gzip reader takes them, members carry their size), BGZF inputs are
+inflated member by member on several threads, ordinary gzip inputs still go through zlib's
+gzread, plain files are read with several preads — always the same bytes."""
+import gzip
+import subprocess
+from pathlib import Path
+
+import pytest
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent
+SRC = HERE / "native" / "io_check.cpp"
+EXE = HERE / "native" / "io_check"
+HOST = ROOT / "fastq-dupaway_amd" / "host"
+
+
+def fnv(data: bytes) -> int:
+    h = 1469598103934665603
+    for c in data:
+        h = ((h ^ c) * 1099511628211) & (2 ** 64 - 1)
+    return h
+
+
+@pytest.fixture(scope="module")
+def io():
+    deps = [SRC, HOST / "file_io.cpp", HOST / "file_io.hpp"]
+    if not EXE.exists() or EXE.stat().st_mtime < max(d.stat().st_mtime for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(EXE), str(SRC), str(HOST / "file_io.cpp"), "-lz", "-lpthread"],
+                       check=True, capture_output=True)
+
+    def run(*args, ok=True):
+        r = subprocess.run([str(EXE), *map(str, args)], capture_output=True, text=True)
+        assert (r.returncode == 0) == ok, r.stderr
+        return r.stdout.split(), r.stderr
+    return run
+
+
+@pytest.mark.parametrize("n", [0, 1, 65279, 65280, 65281, 3_000_001])
+def test_gz_output_is_bgzf_and_reads_back(io, tmp_path, n):
+    out = tmp_path / "o.fq.gz"
+    (length, h), _ = io("w", out, n, 11)
+    assert int(length) == n
+    data = gzip.open(out, "rb").read()                       # any gzip reader
+    assert len(data) == n and (n > 300_000 or fnv(data) == int(h))
+    raw = out.read_bytes()
+    assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:16] == b"BC\x02\x00"       # BGZF member header
+    assert raw.endswith(bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+    for chunk, threads in [(1000, 1), (70_000, 4), (4_000_000, 8)]:
+        (l2, h2), _ = io("r", out, chunk, threads)
+        assert (int(l2), h2) == (n, h)
+
+
+def test_plain_gzip_and_plain_files_read_the_same(io, tmp_path):
+    (length, h), _ = io("w", tmp_path / "plain.fq", 40_000_000, 3)          # big enough for the parallel pread
+    data = (tmp_path / "plain.fq").read_bytes()
+    assert len(data) == int(length)
+    for chunk, threads in [(1 << 20, 1), (64 << 20, 4), (33 << 20, 3)]:
+        (l2, h2), _ = io("r", tmp_path / "plain.fq", chunk, threads)
+        assert (l2, h2) == (length, h)
+    with gzip.open(tmp_path / "std.fq.gz", "wb", compresslevel=1) as f:     # one ordinary member: zlib's gzread path
+        f.write(data[:250_000])
+    (l3, h3), _ = io("r", tmp_path / "std.fq.gz", 1 << 16, 4)
+    assert (int(l3), int(h3)) == (250_000, fnv(data[:250_000]))
+
+
+def test_damaged_bgzf_is_reported(io, tmp_path):
+    out = tmp_path / "o.fq.gz"
+    io("w", out, 500_000, 5)
+    raw = bytearray(out.read_bytes())
+    (tmp_path / "cut.fq.gz").write_bytes(raw[: len(raw) // 2])
+    _, err = io("r", tmp_path / "cut.fq.gz", 1 << 20, 4, ok=False)
+    assert "corrupt or truncated" in err
+    raw[len(raw) // 3] ^= 0x55
+    (tmp_path / "flip.fq.gz").write_bytes(raw)
+    _, err = io("r", tmp_path / "flip.fq.gz", 1 << 20, 4, ok=False)
+    assert "corrupt or truncated" in err

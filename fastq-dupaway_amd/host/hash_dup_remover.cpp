@@ -469,9 +469,11 @@ void HashDupRemover::run_unordered(const std::string* in, const std::string* out
         // reported in the reference's order: everything about file 1 before anything about file 2
         std::exception_ptr err[2];
         auto load = [&](int s) {
+            (void)hipSetDevice(tuning_.device);                  // pinned chunks belong to this device's context
             try { load_whole_file(in[s], format_, tuning_.block_bytes, file[s]); }
             catch (...) { err[s] = std::current_exception(); }
         };
+        StageClock::Scope t("unordered: load + index both files");
         std::thread second(load, 1);
         load(0);
         second.join();
@@ -493,52 +495,118 @@ void HashDupRemover::run_unordered(const std::string* in, const std::string* out
     std::vector<std::pair<uint64_t, uint64_t>> pairs;
     uint64_t unmatched = 0;
     {
+        StageClock::Scope t("unordered: tag join (GPU sort/match + host walk)");
         GpuTagJoin dev(eng.e, stream);
         join_by_tag(file[0], file[1], tuning_.reference_tail_rule, dev, pairs, unmatched);
     }
 
-    // 4. pair-dedup in tag order on the GPU
+    // 4. pair-dedup in tag order on the GPU.  When both files fit in HBM beside the set, their raw
+    //    text is uploaded once and the encoder reads every pair's sequences where they lie
+    //    (offset/length per mate); otherwise the sequences are gathered on the host batch by batch.
     std::vector<uint8_t> keep(pairs.size());
     uint64_t written_below = pairs.size();
     bool bad = false; uint8_t bad_byte = 0;
     {
+        StageClock::Scope t("unordered: sequences to the GPU + dedup");
         const size_t kBatch = 4u << 20;
-        std::vector<uint8_t> bases[2]; std::vector<uint64_t> off[2]; std::vector<uint32_t> len[2];
-        for (size_t a = 0; a < pairs.size() && !bad; a += kBatch) {
-            const size_t n = std::min(kBatch, pairs.size() - a);
-            fqd_reads seg[2] = {};
-            for (int s = 0; s < 2; ++s) {
-                off[s].resize(n); len[s].resize(n);
-                size_t total = 0;
-                for (size_t k = 0; k < n; ++k) {
-                    const FileRecord& r = file[s].recs[s == 0 ? pairs[a + k].first : pairs[a + k].second];
-                    off[s][k] = total; len[s][k] = r.seq_len; total += r.seq_len;
-                }
-                bases[s].resize(total + 16);
-                for (size_t k = 0; k < n; ++k) {
-                    const FileRecord& r = file[s].recs[s == 0 ? pairs[a + k].first : pairs[a + k].second];
-                    std::memcpy(bases[s].data() + off[s][k], r.text + r.id_len, r.seq_len);
-                }
-                seg[s].bases = bases[s].data(); seg[s].offsets = off[s].data(); seg[s].lengths = len[s].data();
-            }
-            const int rc = fqd_submit(eng.e, seg, n, FQD_MEM_HOST, keep.data() + a);
+        size_t text_bytes[2] = {0, 0};
+        for (int s = 0; s < 2; ++s) for (size_t u : file[s].chunk_used) text_bytes[s] += u;
+        size_t free_b = 0, total_b = 0;
+        HIP_OK(hipMemGetInfo(&free_b, &total_b));
+        const size_t need = text_bytes[0] + text_bytes[1] + pairs.size() * 200 + (size_t(2) << 30);   // text + keys, table, scratch
+        const bool in_place = !pairs.empty() && need < free_b && std::getenv("FQD_UNORDERED_HOST_GATHER") == nullptr;
+        auto check = [&](int rc) {
             if (rc == FQD_ERR_BAD_BASE) {
                 uint64_t rec; uint32_t sg2, pos;
                 fqd_bad_base(eng.e, &rec, &sg2, &pos, &bad_byte);
                 bad = true; written_below = rec;
             } else if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng.e));
+        };
+        if (in_place) {
+            Device<char> d_text[2];
+            std::vector<uint64_t> chunk_base[2];
+            for (int s = 0; s < 2; ++s) {
+                d_text[s].reserve(text_bytes[s] + 64);
+                uint64_t at = 0;
+                for (size_t c = 0; c < file[s].chunks.size(); ++c) {
+                    chunk_base[s].push_back(at);
+                    HIP_OK(hipMemcpyAsync(d_text[s].p + at, file[s].chunks[c]->p, file[s].chunk_used[c], hipMemcpyHostToDevice, stream));
+                    at += file[s].chunk_used[c];
+                }
+            }
+            Pinned<uint64_t> off[2]; Pinned<uint32_t> len[2]; Pinned<uint8_t> h_keep;
+            Device<uint64_t> d_off[2]; Device<uint32_t> d_len[2]; Device<uint8_t> d_keep;
+            for (size_t a = 0; a < pairs.size() && !bad; a += kBatch) {
+                const size_t n = std::min(kBatch, pairs.size() - a);
+                fqd_reads seg[2] = {};
+                for (int s = 0; s < 2; ++s) {
+                    off[s].reserve(n); len[s].reserve(n); d_off[s].reserve(n); d_len[s].reserve(n);
+                    const unsigned parts = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(host_threads(), n >> 16)));
+                    run_parts(parts, [&](unsigned p) {
+                        for (size_t k = n / parts * p, e = p + 1 == parts ? n : n / parts * (p + 1); k < e; ++k) {
+                            const FileRecord& r = file[s].recs[s == 0 ? pairs[a + k].first : pairs[a + k].second];
+                            off[s].p[k] = chunk_base[s][r.chunk] + static_cast<uint64_t>(r.text - file[s].chunks[r.chunk]->p) + r.id_len;
+                            len[s].p[k] = r.seq_len;
+                        }
+                    });
+                    HIP_OK(hipMemcpyAsync(d_off[s].p, off[s].p, n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+                    HIP_OK(hipMemcpyAsync(d_len[s].p, len[s].p, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                    seg[s].bases = reinterpret_cast<const uint8_t*>(d_text[s].p); seg[s].offsets = d_off[s].p; seg[s].lengths = d_len[s].p;
+                }
+                h_keep.reserve(n); d_keep.reserve(n);
+                int rc = fqd_submit(eng.e, seg, n, FQD_MEM_DEVICE, d_keep.p);
+                if (rc == FQD_OK) {
+                    HIP_OK(hipMemcpyAsync(h_keep.p, d_keep.p, n, hipMemcpyDeviceToHost, stream));
+                    rc = fqd_engine_sync(eng.e);                 // the offset arrays are reused by the next batch
+                }
+                check(rc);
+                std::memcpy(keep.data() + a, h_keep.p, n);
+            }
+            HIP_OK(hipStreamSynchronize(stream));
+        } else {
+            std::vector<uint8_t> bases[2]; std::vector<uint64_t> off[2]; std::vector<uint32_t> len[2];
+            for (size_t a = 0; a < pairs.size() && !bad; a += kBatch) {
+                const size_t n = std::min(kBatch, pairs.size() - a);
+                fqd_reads seg[2] = {};
+                for (int s = 0; s < 2; ++s) {
+                    off[s].resize(n); len[s].resize(n);
+                    size_t total = 0;
+                    for (size_t k = 0; k < n; ++k) {
+                        const FileRecord& r = file[s].recs[s == 0 ? pairs[a + k].first : pairs[a + k].second];
+                        off[s][k] = total; len[s][k] = r.seq_len; total += r.seq_len;
+                    }
+                    bases[s].resize(total + 16);
+                    for (size_t k = 0; k < n; ++k) {
+                        const FileRecord& r = file[s].recs[s == 0 ? pairs[a + k].first : pairs[a + k].second];
+                        std::memcpy(bases[s].data() + off[s][k], r.text + r.id_len, r.seq_len);
+                    }
+                    seg[s].bases = bases[s].data(); seg[s].offsets = off[s].data(); seg[s].lengths = len[s].data();
+                }
+                check(fqd_submit(eng.e, seg, n, FQD_MEM_HOST, keep.data() + a));
+            }
         }
     }
-    // 5. survivors in tag order
+    // 5. survivors in tag order: one thread per output file, records handed over where they lie
     uint64_t dups = 0;
-    for (uint64_t k = 0; k < pairs.size() && k < written_below; ++k) {
-        if (!keep[k]) { ++dups; continue; }
-        const FileRecord& l = file[0].recs[pairs[k].first];
-        const FileRecord& r = file[1].recs[pairs[k].second];
-        sink0.write(l.text, l.size);
-        sink1.write(r.text, r.size);
+    {
+        StageClock::Scope t("unordered: write survivors");
+        const uint64_t upto = std::min<uint64_t>(pairs.size(), written_below);
+        for (uint64_t k = 0; k < upto; ++k) dups += keep[k] == 0;
+        OutputFile* sinks[2] = {&sink0, &sink1};
+        run_parts(2, [&](unsigned s) {
+            std::vector<OutputFile::Piece> pieces;
+            pieces.reserve(1u << 16);
+            for (uint64_t k = 0; k < upto; ++k) {
+                if (!keep[k]) continue;
+                const FileRecord& r = file[s].recs[s == 0 ? pairs[k].first : pairs[k].second];
+                pieces.push_back({r.text, r.size});
+                if (pieces.size() == (1u << 16)) { sinks[s]->write_pieces(pieces.data(), pieces.size()); pieces.clear(); }
+            }
+            sinks[s]->write_pieces(pieces.data(), pieces.size());
+            sinks[s]->close();
+        });
     }
-    sink0.close(); sink1.close();
+    StageClock::report();
     if (bad) throw_unknown_base(bad_byte);
     summary_.total = pairs.size(); summary_.duplicates = dups; summary_.unmatched = unmatched;
     if (verbose_) {

@@ -15,23 +15,26 @@ void load_whole_file(const std::string& name, Format f, size_t block_bytes, Load
     bool first = true;
     while (true) {
         const size_t cap = std::max(block_bytes, carry.size() + block_bytes / 2);
-        std::unique_ptr<char[]> buf(new char[cap + 16]);
+        std::unique_ptr<PinnedBuffer> buf(new PinnedBuffer());
+        buf->reserve(cap + 16);
         size_t have = carry.size();
-        if (have) std::memcpy(buf.get(), carry.data(), have);
+        if (have) std::memcpy(buf->p, carry.data(), have);
         carry.clear();
-        have += file.read(buf.get() + have, cap - have, host_threads());
+        have += file.read(buf->p + have, cap - have, host_threads());
         refs.clear();
-        const size_t consumed = scan_records_parallel(f, true, buf.get(), have, refs, out.failure, host_threads());
+        const size_t consumed = scan_records_parallel(f, true, buf->p, have, refs, out.failure, host_threads());
         if (first && refs.empty() && !out.failure.set)
             throw std::runtime_error("Not enough memory to read a single object!");
         first = false;
+        const uint32_t chunk = static_cast<uint32_t>(out.chunks.size());
         for (const RecordRef& r : refs)
-            out.recs.push_back(FileRecord{buf.get() + r.start, r.size, r.id_len, r.seq_len, r.tag_off, r.tag_len});
+            out.recs.push_back(FileRecord{buf->p + r.start, r.size, r.id_len, r.seq_len, r.tag_off, r.tag_len, chunk});
         const bool at_end = file.eof();
         if (!out.failure.set && !at_end) {
             if (refs.empty()) throw std::runtime_error("Not enough memory to read a single object!");
-            carry.assign(buf.get() + consumed, buf.get() + have);
+            carry.assign(buf->p + consumed, buf->p + have);
         }
+        out.chunk_used.push_back(consumed);
         out.chunks.push_back(std::move(buf));
         if (out.failure.set || at_end) break;
     }

@@ -16,11 +16,13 @@ namespace fqdhost {
 struct FileRecord {
     const char* text;        // first byte of the record (stable for the life of the LoadedFile)
     uint32_t size, id_len, seq_len, tag_off, tag_len;
+    uint32_t chunk;          // which chunk of the LoadedFile holds it
     const char* tag() const { return text + tag_off; }
 };
 
 struct LoadedFile {
-    std::vector<std::unique_ptr<char[]>> chunks;
+    std::vector<std::unique_ptr<PinnedBuffer>> chunks;   // page-locked: uploaded to HBM as they are
+    std::vector<size_t> chunk_used;                      // bytes of each chunk that hold records
     std::vector<FileRecord> recs;        // in file order
     ParseFailure failure;                // a malformed record ended the load
 };

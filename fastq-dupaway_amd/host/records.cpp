@@ -121,19 +121,6 @@ unsigned host_threads()
 
 namespace {
 
-// Runs body(0..parts-1), part 0 on the calling thread.  An exception of any part is rethrown.
-template <class Body>
-void run_parts(unsigned parts, Body&& body)
-{
-    std::vector<std::thread> pool;
-    std::vector<std::exception_ptr> err(parts);
-    auto guarded = [&](unsigned p) { try { body(p); } catch (...) { err[p] = std::current_exception(); } };
-    for (unsigned p = 1; p < parts; ++p) pool.emplace_back(guarded, p);
-    guarded(0);
-    for (std::thread& t : pool) t.join();
-    for (unsigned p = 0; p < parts; ++p) if (err[p]) std::rethrow_exception(err[p]);
-}
-
 size_t count_newlines(const char* b, const char* e)
 {
     size_t cnt = 0;

@@ -7,8 +7,10 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <exception>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "file_io.hpp"
@@ -60,6 +62,19 @@ struct StageClock {
         ~Scope();
     };
 };
+
+// Runs body(0..parts-1), part 0 on the calling thread; an exception of any part is rethrown.
+template <class Body>
+void run_parts(unsigned parts, Body&& body)
+{
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> err(parts);
+    auto guarded = [&](unsigned p) { try { body(p); } catch (...) { err[p] = std::current_exception(); } };
+    for (unsigned p = 1; p < parts; ++p) pool.emplace_back(guarded, p);
+    guarded(0);
+    for (std::thread& t : pool) t.join();
+    for (unsigned p = 0; p < parts; ++p) if (err[p]) std::rethrow_exception(err[p]);
+}
 
 // Worker threads a host stage may use: FQD_HOST_THREADS, else min(8, hardware threads).
 unsigned host_threads();

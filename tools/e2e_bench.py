@@ -40,6 +40,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=5_000_000)
     ap.add_argument("--paired", action="store_true")
+    ap.add_argument("--unordered", action="store_true", help="paired: shuffle the records of file 2 and run --unordered")
+    ap.add_argument("--gz", action="store_true", help="gzip-compress inputs (with the CLI itself: BGZF) and outputs")
     ap.add_argument("--dir", default="/tmp")
     ap.add_argument("--oracle-reads", type=int, default=2_000_000)
     ap.add_argument("--host-threads", default="", help="comma list: also time the CLI under FQD_HOST_THREADS=<each>")
@@ -51,15 +53,32 @@ def main():
     pool = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(int(n * 0.8) + 1, L))
     idx = rng.integers(0, len(pool), size=n)
     d = Path(a.dir)
-    f1 = d / "e2e_r1.fq"; write_fastq(f1, n, L, rng, idx, pool, "/1" if a.paired else "")
+    f1 = d / "e2e_r1.fq"; write_fastq(f1, n, L, rng, idx, pool, (" 1:N" if a.unordered else "/1") if a.paired else "")
     files = [f1]
     if a.paired:
-        f2 = d / "e2e_r2.fq"; write_fastq(f2, n, L, rng, rng.integers(0, len(pool), size=n), pool, "/2"); files.append(f2)
+        f2 = d / "e2e_r2.fq"; write_fastq(f2, n, L, rng, rng.integers(0, len(pool), size=n), pool, " 2:N" if a.unordered else "/2"); files.append(f2)
+    if a.unordered:                              # fixed-size records: shuffle file 2 as rows
+        rec = files[1].stat().st_size // n
+        rows = np.fromfile(files[1], dtype=np.uint8).reshape(n, rec)
+        rows[rng.permutation(n)].tofile(files[1])
+        del rows
     size = sum(f.stat().st_size for f in files)
-    outs = [d / f"e2e_out{k}.fq" for k in range(len(files))]
+    plain_files = list(files)
+    ext = ".fq.gz" if a.gz else ".fq"
+    if a.gz:                                     # BGZF inputs, packed by the host driver's own file layer
+        packer = d / "e2e_bgzf_pack"
+        subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(packer), str(ROOT / "tools" / "bgzf_pack.cpp"),
+                        str(ROOT / "fastq-dupaway_amd" / "host" / "file_io.cpp"), "-lz", "-lpthread"], check=True)
+        for k, f in enumerate(files):
+            subprocess.run([str(packer), str(f), str(d / f"e2e_in{k}.fq.gz")], check=True)
+        files = [d / f"e2e_in{k}.fq.gz" for k in range(len(files))]
+        print("compressed inputs:", [f.stat().st_size for f in files])
+    outs = [d / f"e2e_out{k}{ext}" for k in range(len(files))]
     args = [str(_lib.CLI_PATH), "-i", str(files[0]), "-o", str(outs[0]), "--fast", "-v"]
     if a.paired:
         args += ["-u", str(files[1]), "-p", str(outs[1])]
+    if a.unordered:
+        args += ["--unordered"]
     for threads in [t for t in a.host_threads.split(",") if t] + [""]:
         env = dict(os.environ, FQD_HOST_THREADS=threads) if threads else dict(os.environ)
         for rep in range(2):
@@ -69,7 +88,8 @@ def main():
             print(f"cli run {rep} (host threads {threads or 'default'}): rc={r.returncode} {dt:.2f} s  {n / dt / 1e6:.2f} Mreads/s  "
                   f"{size / dt / 1e9:.2f} GB/s  | {r.stdout.strip()} {r.stderr.strip()[:2000]}")
     oracle = binding.load_oracle()
-    m = min(a.oracle_reads, n)
+    files = plain_files
+    m = n if a.unordered else min(a.oracle_reads, n)         # a prefix of shuffled files would not pair up
     if m < n:                                   # the oracle is timed on a prefix (one CPU core)
         rec_bytes = files[0].stat().st_size // n
         for k, f in enumerate(files):
@@ -79,13 +99,17 @@ def main():
     exp = [d / f"e2e_exp{k}.fq" for k in range(len(files))]
     t0 = time.perf_counter()
     if a.paired:
-        oracle.filter_paired(files[0], files[1], exp[0], exp[1], binding.FASTQ)
+        oracle.filter_paired(files[0], files[1], exp[0], exp[1], binding.FASTQ, unordered=a.unordered)
     else:
         oracle.filter_single(files[0], exp[0], binding.FASTQ)
     dt = time.perf_counter() - t0
     print(f"oracle (1 core, {m} reads): {dt:.2f} s  {m / dt / 1e6:.3f} Mreads/s")
     if m == n:
-        print("outputs identical:", all(filecmp.cmp(o, e, shallow=False) for o, e in zip(outs, exp)))
+        if a.gz:
+            import gzip
+            print("outputs identical:", all(gzip.open(o, "rb").read() == e.read_bytes() for o, e in zip(outs, exp)))
+        else:
+            print("outputs identical:", all(filecmp.cmp(o, e, shallow=False) for o, e in zip(outs, exp)))
     for f in list(d.glob("e2e_*")):
         f.unlink()
 

@@ -243,6 +243,33 @@ def test_synthetic_1m_matches_oracle_and_closed_form(oracle, torch_cuda):
     assert (host[: n * L] == ord("N")).sum() > 0                            # the N path is exercised
 
 
+@pytest.mark.parametrize("paired", [False, True])
+def test_table_grows_between_bulk_batches(torch_cuda, paired):
+    """No capacity hint: the table is rebuilt (rehash) several times while batches large enough for
+    the bulk path keep arriving, so slot tags change width between batches (the tag is cut to what
+    fits an 8-byte partition record of the table's size) and old owners must still be found."""
+    torch = torch_cuda
+    S = 2 if paired else 1
+    sizes = [1_200_000, 1_300_000, 2_900_000, 1_100_000, 6_000_000, 5_000_000]
+    n, L = sum(sizes), 150
+    bases = [torch.empty(n * L + 16, dtype=torch.uint8, device="cuda") for _ in range(S)]
+    expect = torch.empty(n, dtype=torch.uint8, device="cuda")
+    keep = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    with Engine(segments=S) as e:
+        for m in range(S):
+            e.synth_reads(77, 0, n, L, 300, m, bases[m], expect if m == S - 1 else None)
+        at, slots = 0, []
+        for k in sizes:
+            e.submit([Reads(bases[m][at * L:], uniform_len=L, uniform_stride=L) for m in range(S)], k, keep=keep[at:])
+            e.sync()
+            slots.append(e.stats()["table_slots"])
+            at += k
+        st = e.stats()
+    assert len(set(slots)) >= 3                                            # the table really grew on the way
+    assert torch.equal(keep, expect)
+    assert st["duplicates"] == int((expect == 0).sum().item())
+
+
 def test_synthetic_pairs_match_oracle(oracle, torch_cuda):
     torch = torch_cuda
     n, L = 400_000, 150

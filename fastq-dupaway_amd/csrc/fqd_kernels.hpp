@@ -669,6 +669,7 @@ void bulk_scan_buckets_kernel(const uint32_t* __restrict__ count, uint32_t nb, u
 // LDS: segment (2^seg_bits * 8 B) + kDedupChunk queue entries of 8 B + 2 counters.
 constexpr uint32_t kDedupChunk = 1536;
 constexpr uint32_t kDedupFly = 4;
+constexpr uint32_t kDedupLoads = 3;                      // records a lane fetches at once in the probe phase (chunk / 512 lanes)
 
 template <bool FRESH>
 __global__ __launch_bounds__(1024)
@@ -742,11 +743,18 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
             const uint32_t chunk_n = hi - chunk_lo < kDedupChunk ? hi - chunk_lo : kDedupChunk;
             if (threadIdx.x == 0) { qn[0] = 0; qn[1] = 0; }
             __syncthreads();
-            // 1. probe
-            for (uint32_t c = threadIdx.x; c < chunk_n; c += blockDim.x) {
-                const uint64_t v = recs[chunk_lo + c];
-                const uint32_t q = uint32_t(v >> 32);
-                walk(uint32_t(v), q >> qshift, q & seg_mask, false);
+            // 1. probe (a lane's records are all fetched before the first walk: one round trip, not several)
+            for (uint32_t c0 = threadIdx.x; c0 < chunk_n; c0 += kDedupLoads * blockDim.x) {
+                uint64_t v[kDedupLoads];
+#pragma unroll
+                for (uint32_t u = 0; u < kDedupLoads; ++u) { const uint32_t c = c0 + u * blockDim.x; v[u] = recs[chunk_lo + (c < chunk_n ? c : chunk_n - 1u)]; }
+#pragma unroll
+                for (uint32_t u = 0; u < kDedupLoads; ++u) {
+                    if (c0 + u * blockDim.x < chunk_n) {
+                        const uint32_t q = uint32_t(v[u] >> 32);
+                        walk(uint32_t(v[u]), q >> qshift, q & seg_mask, false);
+                    }
+                }
             }
             __syncthreads();
             // 2. verify, eight lanes per candidate, kDedupFly candidates per group in flight

@@ -144,7 +144,8 @@ void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_id
 // Copies n16 16-byte chunks from global memory to LDS with the whole workgroup, kCopyBatch loads
 // per lane in flight at a time (a plain per-chunk loop compiles to load, wait, store: one
 // outstanding load per lane).  Loads are unconditional (index clamped into the range) so the
-// staging values stay in registers; the LDS stores are predicated.
+// staging values stay in registers; the LDS stores are predicated.  The input is read once:
+// non-temporal loads keep it from displacing anything in L2.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kCopyBatch = 5;                         // 1 -> 5: encoder 4.3 -> 4.0 ms per 100 M; 10: no better
 __device__ __forceinline__ void stage_chunks(const uint8_t* __restrict__ src_bytes, uint32_t* __restrict__ lds_dst, uint32_t n16, uint32_t R)
@@ -154,7 +155,7 @@ __device__ __forceinline__ void stage_chunks(const uint8_t* __restrict__ src_byt
     for (uint32_t c0 = threadIdx.x; c0 < n16; c0 += uint32_t(kCopyBatch) * R) {
         u32x4 v[kCopyBatch];
 #pragma unroll
-        for (int k = 0; k < kCopyBatch; ++k) { const uint32_t c = c0 + uint32_t(k) * R; v[k] = src[c < n16 ? c : n16 - 1u]; }
+        for (int k = 0; k < kCopyBatch; ++k) { const uint32_t c = c0 + uint32_t(k) * R; v[k] = __builtin_nontemporal_load(&src[c < n16 ? c : n16 - 1u]); }
 #pragma unroll
         for (int k = 0; k < kCopyBatch; ++k) { const uint32_t c = c0 + uint32_t(k) * R; if (c < n16) dst[c] = v[k]; }
     }
@@ -232,7 +233,7 @@ void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
             const uint32_t total = wave_reads * row_words;
             for (uint32_t x = lane; x < total; x += 64u) {
                 const uint32_t rr = __umulhi(x, rw_magic), kk = x - rr * row_words;
-                gout[x] = lds64[((in0 + (wave * 64u + rr) * s0.ustride + 4u + 7u) >> 3) + kk];
+                __builtin_nontemporal_store(lds64[((in0 + (wave * 64u + rr) * s0.ustride + 4u + 7u) >> 3) + kk], &gout[x]);
             }
         }
         __syncthreads();
@@ -324,7 +325,7 @@ void encode_staged_pe_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_
                 const uint32_t m = kk >= split ? 1u : 0u;
                 const uint32_t kw = m ? kk - split : kk;
                 const uint32_t pb = in_base[m] + (wave * 32u + rr) * (m ? s1.ustride : s0.ustride);
-                gout[x] = lds64[((pb + 4u + 7u) >> 3) + kw];
+                __builtin_nontemporal_store(lds64[((pb + 4u + 7u) >> 3) + kw], &gout[x]);
             }
         }
         __syncthreads();
@@ -586,7 +587,7 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
             if (r < count) {
                 const uint64_t v = stage[r];
                 const uint32_t d = sdig[r];
-                out[gbase[d] + (r - lstart[d])] = v;
+                out[gbase[d] + (r - lstart[d])] = v;      // plain stores: the short runs of neighbouring tiles combine in L2
                 if (LEVEL == 1 && digit2_out) digit2_out[gbase[d] + (r - lstart[d])] = uint8_t((uint32_t(v >> 32) >> g.seg_bits) & mask2);
             }
         }
@@ -820,7 +821,11 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
         {
             const ulonglong2* seg2 = reinterpret_cast<const ulonglong2*>(seg);
             ulonglong2* gseg2 = reinterpret_cast<ulonglong2*>(gseg);
-            for (uint32_t k = threadIdx.x; k < (seg_slots >> 1); k += blockDim.x) gseg2[k] = seg2[k];
+            for (uint32_t k = threadIdx.x; k < (seg_slots >> 1); k += blockDim.x) {   // written once, not read again by this launch
+                const ulonglong2 v = seg2[k];
+                __builtin_nontemporal_store(v.x, &gseg2[k].x);
+                __builtin_nontemporal_store(v.y, &gseg2[k].y);
+            }
         }
         __syncthreads();
     }

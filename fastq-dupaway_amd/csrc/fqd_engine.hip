@@ -52,6 +52,8 @@ struct fqd_engine {
     DevBuf   table;    uint64_t slots = 0;
     uint32_t seg_bits = 0;                           // log2(slots per probing segment)
     uint32_t tag_mask = 0;                           // slot tag = (hash >> 32) & tag_mask (slot_tag)
+    const uint64_t* hashed_records = nullptr;        // fqd_encode_uniform's last output whose hashes still lie in `hashes`
+    uint64_t hashed_n = 0; uint32_t hashed_rec_words = 0;
     bool     table_clear = false;                    // every slot is EMPTY right now
     bool     table_stale = false;                    // contents are garbage: clear (or rebuild) before use
     DevBuf   bulk_recs, bulk_meta;                   // scratch of the bulk (partitioned) insert
@@ -714,6 +716,7 @@ static int submit_impl(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memo
 
     const uint64_t first = e->n_records;
     if (!hashes_only && (rc = ensure_table(e, first + n))) return rc;
+    e->hashed_records = nullptr;                              // the scratch is about to be reused
     if (!hashes_only && (rc = reserve(e, e->hashes, n * sizeof(uint64_t)))) return rc;
 
     uint64_t new_words = 0;
@@ -873,7 +876,13 @@ int fqd_encode_uniform(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint64_t
     for (int s = 0; s < e->S; ++s) { sv[s].bases = seg[s].bases; sv[s].ulen = seg[s].uniform_len; sv[s].ustride = seg[s].uniform_stride; }
     const uint32_t W = seg_words(seg[0].uniform_len) + (e->S == 2 ? seg_words(seg[1].uniform_len) : 0u);
     KeyStore ks{records, nullptr, W, W + 1, 1};
-    return launch_encode(e, sv, true, seg, n, 0, ks, nullptr);
+    // the hashes also go, back to back, to the engine's scratch: fqd_partition_records counts owners
+    // from there instead of picking word 0 out of every record
+    int rc = reserve(e, e->hashes, n * sizeof(uint64_t));
+    if (rc) return rc;
+    rc = launch_encode(e, sv, true, seg, n, 0, ks, e->hashes.as<uint64_t>());
+    e->hashed_records = rc == FQD_OK ? records : nullptr; e->hashed_n = n; e->hashed_rec_words = W + 1;
+    return rc;
 }
 
 int fqd_partition_records(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
@@ -891,8 +900,9 @@ int fqd_partition_records(fqd_engine* e, const uint64_t* records, uint64_t n, ui
     if (rc) return rc;
     uint64_t* c2 = e->part_scratch.as<uint64_t>();
     Bracket br(e, K_OTHER, 0);
+    const bool compact = records == e->hashed_records && n == e->hashed_n && rec_words == e->hashed_rec_words;
     hipLaunchKernelGGL(part_count_kernel, dim3(n_blocks), dim3(kBlock), n_parts * sizeof(uint32_t), e->stream,
-                       records, n, rec_words, n_parts, c2, n_blocks);
+                       compact ? e->hashes.as<uint64_t>() : records, compact ? 1u : rec_words, n, n_parts, c2, n_blocks);
     if ((rc = scan_exclusive(e, c2, cells, 0, nullptr))) return rc;
     const size_t scatter_lds = size_t(kBlock) * rec_words * sizeof(uint64_t) + kBlock * sizeof(uint64_t) + size_t(n_parts) * 4 * sizeof(uint32_t);
     if (scatter_lds > 64 * 1024) return e->fail(FQD_ERR_ARG, "fqd_partition_records: records too long for the staged partition");

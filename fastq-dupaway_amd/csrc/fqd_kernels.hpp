@@ -101,7 +101,7 @@ __device__ __noinline__ uint64_t locate_bad_base(const uint8_t* p0, uint32_t l0,
 // encode_general: one record (all its mates) per lane, loads straight from HBM.
 // Handles ragged and uniform input, any length, any alignment.
 //   hash_out != nullptr : hash of record i -> hash_out[i]
-//   hash_out == nullptr : hash -> word 0 of the record's slot (records layout, lead == 1)
+//   ks.lead == 1        : hash -> word 0 of the record's slot (records layout); both may apply
 template <int S>
 __global__ __launch_bounds__(kBlock)
 void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx,
@@ -130,8 +130,8 @@ void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_id
             h = hash_end(h);
         }
         h &= h1.hash_and;
+        if (ks.lead) ks.slot(first_idx + i)[-1] = h;
         if (hash_out) hash_out[i] = h;
-        else          ks.slot(first_idx + i)[-1] = h;
         if (h1.hist) atomicAdd(&lhist[bucket_of(h, h1.g) >> h1.g.bits2], 1u);
         if (diff) {
             const uint64_t e = locate_bad_base(p0, l0, p1, l1, first_idx + i);
@@ -210,14 +210,16 @@ void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
                 auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
                 diff = pack_mate(lds + (b0 >> 2), b0 & 3u, l0, sink);
                 h = hash_end(h) & h1.hash_and;
-                if (hash_out) hash_out[i] = h; else row[-1] = h;
+                if (ks.lead) row[-1] = h;
+                if (hash_out) hash_out[i] = h;
             } else {
                 uint64_t* out = ks.slot(first_idx + i);
                 if (ks.koff) *out++ = uint64_t(l0);
                 auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
                 diff = pack_mate(lds + (b0 >> 2), b0 & 3u, l0, sink);
                 h = hash_end(h) & h1.hash_and;
-                if (hash_out) hash_out[i] = h; else ks.slot(first_idx + i)[-1] = h;
+                if (ks.lead) ks.slot(first_idx + i)[-1] = h;
+                if (hash_out) hash_out[i] = h;
             }
             if (h1.hist) atomicAdd(&lhist[bucket_of(h, h1.g) >> h1.g.bits2], 1u);
             if (diff) {
@@ -302,9 +304,8 @@ void encode_staged_pe_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_
         const uint64_t other = __shfl_xor(h, 1, 64);               // the partner lane's chain
         if (live && !mate) {
             const uint64_t hh = hash_pair(h, other) & h1.hash_and;
+            if (ks.lead) { if (LDS_OUT) row[-1] = hh; else ks.slot(first_idx + i)[-1] = hh; }
             if (hash_out) hash_out[i] = hh;
-            else if (LDS_OUT) row[-1] = hh;
-            else ks.slot(first_idx + i)[-1] = hh;
             if (h1.hist) atomicAdd(&lhist[bucket_of(hh, h1.g) >> h1.g.bits2], 1u);
         }
         if (live && diff) {
@@ -958,14 +959,14 @@ void relayout_ragged_kernel(const uint64_t* __restrict__ src, uint64_t* __restri
 __device__ __forceinline__ uint32_t owner_of(uint64_t hash, uint32_t n_parts) { return uint32_t((hash >> 40) % n_parts); }
 
 __global__ __launch_bounds__(kBlock)
-void part_count_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t rec_words, uint32_t n_parts,
+void part_count_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stride, uint64_t n, uint32_t n_parts,
                        uint64_t* __restrict__ counts2d, uint32_t n_blocks)
 {
     extern __shared__ uint32_t hist[];                 // n_parts
     for (uint32_t p = threadIdx.x; p < n_parts; p += kBlock) hist[p] = 0;
     __syncthreads();
     const uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x;
-    if (i < n) atomicAdd(&hist[owner_of(rec[i * uint64_t(rec_words)], n_parts)], 1u);
+    if (i < n) atomicAdd(&hist[owner_of(hashes[i * uint64_t(hash_stride)], n_parts)], 1u);
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < n_parts; p += kBlock) counts2d[uint64_t(p) * n_blocks + blockIdx.x] = hist[p];
 }

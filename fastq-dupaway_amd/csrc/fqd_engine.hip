@@ -478,8 +478,8 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
         hipLaunchKernelGGL(bulk_hist2_kernel, dim3(grid2), dim3(kPartThreads), 0, e->stream,
                            static_cast<const uint8_t*>(p.digit2), g, static_cast<const uint32_t*>(start1),
                            static_cast<const uint32_t*>(tile_start1), hist2);
-        hipLaunchKernelGGL(bulk_scan_buckets_kernel, dim3(1), dim3(1024), 0, e->stream,
-                           static_cast<const uint32_t*>(hist2), n_buckets, start2, cursor2);
+        hipLaunchKernelGGL(bulk_scan_buckets_kernel, dim3(nd1), dim3(256), 0, e->stream,
+                           static_cast<const uint32_t*>(hist2), g.bits2, static_cast<const uint32_t*>(start1), nd1, start2, cursor2);
         hipLaunchKernelGGL(bulk_scatter_kernel<2>, dim3(grid2), dim3(kPartThreads), 0, e->stream,
                            static_cast<const uint64_t*>(nullptr), 0u, 0u, static_cast<const uint64_t*>(recA), n, g,
                            static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor2, recB,

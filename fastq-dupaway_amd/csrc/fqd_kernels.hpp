@@ -622,34 +622,25 @@ void bulk_hist2_kernel(const uint8_t* __restrict__ digit2_in, BulkGeom g, const 
     }
 }
 
-// One block of 1024 threads: start[b] = exclusive prefix of count[b], b < nb (nb <= 65536);
-// start[nb] = total; cursor = start.
-__global__ __launch_bounds__(1024)
-void bulk_scan_buckets_kernel(const uint32_t* __restrict__ count, uint32_t nb, uint32_t* __restrict__ start,
-                              uint32_t* __restrict__ cursor)
+// One 256-thread block per level-1 digit d1: the level-1 output is grouped by d1, so the buckets
+// (d1, 0..nd2) start at start1[d1] plus the exclusive prefix of their own counts — no scan over
+// all buckets is needed.  start[b] for every bucket, start[nb] = total; cursor = start.
+__global__ __launch_bounds__(256)
+void bulk_scan_buckets_kernel(const uint32_t* __restrict__ count, uint32_t bits2, const uint32_t* __restrict__ start1,
+                              uint32_t nd1, uint32_t* __restrict__ start, uint32_t* __restrict__ cursor)
 {
-    __shared__ uint32_t part[1024];
-    const uint32_t per = (nb + 1023u) / 1024u;
-    const uint32_t lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
-    uint32_t s = 0;
-    for (uint32_t k = lo; k < hi; ++k) s += count[k];
-    part[threadIdx.x] = s;
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t nd2 = 1u << bits2, d1 = blockIdx.x, t = threadIdx.x;
+    const uint32_t c = t < nd2 ? count[(d1 << bits2) + t] : 0u;
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(inc, d, 64); if (int(t & 63u) >= d) inc += up; }
+    if ((t & 63u) == 63u) wave_tot[t >> 6] = inc;
     __syncthreads();
-    if (threadIdx.x < 64) {                                  // scan the 1024 partial sums with one wave
-        uint32_t c[16], t = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { c[k] = part[threadIdx.x * 16 + k]; t += c[k]; }
-        uint32_t inc = t;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(inc, d, 64); if (int(threadIdx.x) >= d) inc += up; }
-        uint32_t ex = inc - t;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { part[threadIdx.x * 16 + k] = ex; ex += c[k]; }
-    }
-    __syncthreads();
-    uint32_t run = part[threadIdx.x];
-    for (uint32_t k = lo; k < hi; ++k) { start[k] = run; cursor[k] = run; run += count[k]; }
-    if (threadIdx.x == 1023) start[nb] = run;
+    uint32_t before = start1[d1];
+    for (uint32_t w = 0; w < (t >> 6); ++w) before += wave_tot[w];
+    if (t < nd2) { start[(d1 << bits2) + t] = before + inc - c; cursor[(d1 << bits2) + t] = before + inc - c; }
+    if (d1 == nd1 - 1u && t == 0) start[nd1 << bits2] = start1[nd1];
 }
 
 // One workgroup per table segment.  FRESH: the segment is known to be empty (engine just reset):

@@ -546,15 +546,20 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
         __syncthreads();
         uint64_t rec[kPartPer]; uint32_t dig[kPartPer], rank[kPartPer];
 #pragma unroll
+        for (int k = 0; k < kPartPer; ++k) {                  // every load of the tile first (index clamped): one round trip
+            const uint32_t r = threadIdx.x + k * kPartThreads;
+            const uint64_t at = lo + (r < count ? r : count - 1u);
+            rec[k] = (LEVEL == 1) ? hashes[at * uint64_t(hash_stride)] : in[at];
+        }
+#pragma unroll
         for (int k = 0; k < kPartPer; ++k) {
             const uint32_t r = threadIdx.x + k * kPartThreads;
             if (r < count) {
                 if (LEVEL == 1) {
-                    const uint64_t h = hashes[(lo + r) * uint64_t(hash_stride)];
+                    const uint64_t h = rec[k];
                     rec[k] = (uint64_t(part_q(h, g)) << 32) | (first_idx + uint32_t(lo + r));
                     dig[k] = bucket_of(h, g) >> g.bits2;
                 } else {
-                    rec[k] = in[lo + r];
                     dig[k] = (uint32_t(rec[k] >> 32) >> g.seg_bits) & mask2;
                 }
                 rank[k] = atomicAdd(&cnt[dig[k]], 1u);
@@ -614,8 +619,12 @@ void bulk_hist2_kernel(const uint8_t* __restrict__ digit2_in, BulkGeom g, const 
         const uint64_t hi = lo + kPartTile < start1[d1 + 1] ? lo + kPartTile : start1[d1 + 1];
         for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) h[k] = 0;
         __syncthreads();
-        for (uint64_t r = lo + threadIdx.x; r < hi; r += kPartThreads)
-            atomicAdd(&h[digit2_in[r] & (nd2 - 1u)], 1u);
+        uint8_t dg[kPartPer];                                 // a tile is kPartPer digits per lane: all loads first
+#pragma unroll
+        for (int k = 0; k < kPartPer; ++k) { const uint64_t r = lo + threadIdx.x + uint64_t(k) * kPartThreads; dg[k] = digit2_in[r < hi ? r : hi - 1]; }
+#pragma unroll
+        for (int k = 0; k < kPartPer; ++k)
+            if (lo + threadIdx.x + uint64_t(k) * kPartThreads < hi) atomicAdd(&h[dg[k] & (nd2 - 1u)], 1u);
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) if (h[k]) atomicAdd(&hist2[(d1 << g.bits2) + k], h[k]);
         __syncthreads();

@@ -766,24 +766,45 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
                 uint32_t pos[kDedupFly], idx[kDedupFly], seen[kDedupFly], tag[kDedupFly];
                 uint64_t diff[kDedupFly];
                 bool live[kDedupFly];
+                uint64_t wa[kDedupFly][2], wb[kDedupFly][2];
 #pragma unroll
                 for (uint32_t u = 0; u < kDedupFly; ++u) {        // issue every load of the batch first
                     const uint32_t q = q0 + u * n_grp;
                     live[u] = q < n_cand;
                     diff[u] = 0; pos[u] = 0; idx[u] = 0; seen[u] = 0; tag[u] = 0;
+                    wa[u][0] = wa[u][1] = wb[u][0] = wb[u][1] = 0;
                     if (live[u]) {
                         const unsigned long long ent = queue[q];
                         idx[u] = uint32_t(ent); pos[u] = uint32_t(ent >> 32) & seg_mask; tag[u] = uint32_t(ent >> 32) >> seg_bits;
                         seen[u] = uint32_t(seg[pos[u]]);      // the slot's owner right now: same key class for good
+                    }
+                    if (!ks.koff) {
+                        // uniform keys: addresses are arithmetic, so the (up to) two words a lane owns of
+                        // each key are requested here and only looked at after the whole batch is in flight
+                        const uint64_t* __restrict__ pa = ks.keys + idx[u] * uint64_t(ks.stride) + ks.lead;
+                        const uint64_t* __restrict__ pb = ks.keys + seen[u] * uint64_t(ks.stride) + ks.lead;
+                        const bool w0 = live[u] && sub < ks.W0, w1 = live[u] && sub + 8u < ks.W0;
+                        wa[u][0] = w0 ? pa[sub] : 0; wb[u][0] = w0 ? pb[sub] : 0;
+                        wa[u][1] = w1 ? pa[sub + 8u] : 0; wb[u][1] = w1 ? pb[sub + 8u] : 0;
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kDedupFly; ++u) {
+                    if (!live[u]) continue;
+                    if (!ks.koff) {
+                        diff[u] = (wa[u][0] ^ wb[u][0]) | (wa[u][1] ^ wb[u][1]);
+                        if (ks.W0 > 16u) {                    // longer keys: the remaining words, the plain way
+                            const uint64_t* __restrict__ pa = ks.keys + idx[u] * uint64_t(ks.stride) + ks.lead;
+                            const uint64_t* __restrict__ pb = ks.keys + seen[u] * uint64_t(ks.stride) + ks.lead;
+                            for (uint32_t w = sub + 16u; w < ks.W0; w += 8u) diff[u] |= pa[w] ^ pb[w];
+                        }
+                    } else {
                         const uint64_t* __restrict__ pa = ks.slot(idx[u]);
                         const uint64_t* __restrict__ pb = ks.slot(seen[u]);
-                        uint32_t W = ks.W0;
-                        if (ks.koff) {
-                            const uint64_t ha = pa[0];
-                            diff[u] = ha ^ pb[0];             // mate lengths
-                            W = seg_words(uint32_t(ha)) + seg_words(uint32_t(ha >> 32));
-                            ++pa; ++pb;
-                        }
+                        const uint64_t ha = pa[0];
+                        diff[u] = ha ^ pb[0];                 // mate lengths
+                        const uint32_t W = seg_words(uint32_t(ha)) + seg_words(uint32_t(ha >> 32));
+                        ++pa; ++pb;
                         if (!diff[u]) for (uint32_t w = sub; w < W; w += 8u) diff[u] |= pa[w] ^ pb[w];
                     }
                 }

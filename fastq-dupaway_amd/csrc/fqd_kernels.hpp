@@ -1009,7 +1009,13 @@ void part_scatter_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t 
     const uint32_t cnt = uint32_t(n - base < kBlock ? n - base : kBlock);
     const uint32_t words = cnt * rec_words;
     const uint64_t* src = rec + base * rec_words;
-    for (uint32_t w = threadIdx.x; w < words; w += kBlock) ptile[w] = src[w];
+    for (uint32_t w0 = threadIdx.x; w0 < words; w0 += 5u * kBlock) {       // five loads per lane in flight (see stage_chunks)
+        uint64_t v[5];
+#pragma unroll
+        for (uint32_t k = 0; k < 5u; ++k) { const uint32_t w = w0 + k * kBlock; v[k] = src[w < words ? w : words - 1u]; }
+#pragma unroll
+        for (uint32_t k = 0; k < 5u; ++k) { const uint32_t w = w0 + k * kBlock; if (w < words) ptile[w] = v[k]; }
+    }
     __syncthreads();
     const bool live = threadIdx.x < cnt;
     const uint32_t mine = live ? owner_of(ptile[threadIdx.x * rec_words], n_parts) : 0xFFFFFFFFu;

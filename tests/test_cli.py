@@ -389,3 +389,77 @@ def test_unordered_tail_rule_fuzz_against_oracle(exe, oracle, tmp_path):
             assert g1.read_bytes() == e1.read_bytes() and g2.read_bytes() == e2.read_bytes(), (ids, ids2, full)
             assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
                                 f"{un} Non-matching entries from both files were skipped.\n"), (ids, ids2, full)
+
+
+@pytest.mark.gpu
+def test_differential_fuzz_single_and_paired_with_injected_errors(exe, oracle, tmp_path):
+    """Random small inputs — clean, or with one defect somewhere (unknown base, bad lead byte,
+    quality of another length, a line missing, no final newline, CRLF) — through the CLI and the
+    oracle's file driver: same exit status, same exception text, same bytes on disk."""
+    rnd = random.Random(2024)
+
+    def records(n, fmt):
+        out = []
+        for k in range(n):
+            s = bytes(rnd.choice(b"ACGTN") for _ in range(rnd.randrange(1, 70)))
+            if rnd.random() < 0.3 and out:
+                s = rnd.choice(out)[1]
+            out.append((b"id%d" % k, s))
+        return out
+
+    def render(recs, fmt, defect):
+        parts = []
+        for (i, s) in recs:
+            parts.append(b"@" + i + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n" if fmt == FASTQ else b">" + i + b"\n" + s + b"\n")
+        k = rnd.randrange(len(parts))
+        if defect == "base":
+            i, s = recs[k]
+            s = s[: len(s) // 2] + rnd.choice([b"x", b"a", b"R", b"."]) + s[len(s) // 2 + 1:]
+            parts[k] = b"@" + i + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n" if fmt == FASTQ else b">" + i + b"\n" + s + b"\n"
+        elif defect == "lead":
+            parts[k] = b"?" + parts[k][1:]
+        elif defect == "qual" and fmt == FASTQ:
+            parts[k] = parts[k][:-1] + b"I\n"
+        elif defect == "line":
+            parts[k] = parts[k].split(b"\n", 1)[1]
+        data = b"".join(parts)
+        if defect == "nonl":
+            data = data[:-1]
+        if defect == "crlf":
+            data = data.replace(b"\n", b"\r\n")
+        return data
+
+    defects = [None, None, "base", "lead", "qual", "line", "nonl", "crlf"]
+    for case in range(48):
+        fmt = rnd.choice([FASTQ, FASTA])
+        paired = case % 3 == 0
+        fmt_args = ["--format", "fasta"] if fmt == FASTA else []
+        d = tmp_path / f"c{case}"; d.mkdir()
+        n = rnd.randrange(2, 40)
+        f1 = d / "r1.txt"; f1.write_bytes(render(records(n, fmt), fmt, rnd.choice(defects)))
+        err = None
+        if paired:
+            f2 = d / "r2.txt"; f2.write_bytes(render(records(rnd.randrange(2, 40), fmt), fmt, rnd.choice(defects)))
+            e1, e2, g1, g2 = (d / x for x in ("e1", "e2", "g1", "g2"))
+            try:
+                oracle.filter_paired(f1, f2, e1, e2, fmt)
+            except RuntimeError as ex:
+                err = str(ex)
+            r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", *fmt_args)
+            pairs = [(g1, e1), (g2, e2)]
+        else:
+            e1, g1 = d / "e1", d / "g1"
+            try:
+                oracle.filter_single(f1, e1, fmt)
+            except RuntimeError as ex:
+                err = str(ex)
+            r = run(exe, "-i", f1, "-o", g1, "--fast", *fmt_args)
+            pairs = [(g1, e1)]
+        what = (case, fmt, paired, f1.read_bytes()[:200])
+        assert (r.returncode != 0) == (err is not None), (what, r.stderr, err)
+        if err is not None:
+            assert r.stderr.endswith("An error occured during fastq-dupaway execution:\n" + err + "\n"), (what, r.stderr, err)
+        for g, e in pairs:
+            assert g.exists() == e.exists(), what
+            if e.exists():
+                assert g.read_bytes() == e.read_bytes(), what

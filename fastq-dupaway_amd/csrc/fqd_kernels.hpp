@@ -393,8 +393,15 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, uint64_t se
         uint64_t pos = h & slot_mask;
         bool placed = false;
         for (uint64_t probe = 0; probe <= seg_mask; ++probe) {
-            const unsigned long long old = atomicCAS(&tab[pos], kEmptySlot, mine);
-            if (old == kEmptySlot) { placed = true; break; }
+            // A plain load first: an occupied slot never empties and never changes its key, so only a
+            // slot that looks empty is worth one of the (much scarcer) memory-side atomics.  A stale
+            // view is harmless: a stale EMPTY makes the CAS fail and return the truth, a stale owner
+            // is a younger record of the same key and is sorted out by the atomicMin below.
+            unsigned long long old = tab[pos];
+            if (old == kEmptySlot) {
+                old = atomicCAS(&tab[pos], kEmptySlot, mine);
+                if (old == kEmptySlot) { placed = true; break; }
+            }
             if ((old >> 32) == tag && keys_equal(ks, idx, uint32_t(old))) {
                 // The slot now belongs to my key for good.  If its owner is older I lose and the
                 // table needs no update; only an owner younger than me has to be displaced.

@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--paired", action="store_true", help="configs[2]: 2x150 bp pair-hash")
     ap.add_argument("--dup-permille", type=int, default=200)
     ap.add_argument("--seed", type=int, default=2026)
-    ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="reads timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     return ap.parse_args()
 
@@ -55,7 +55,7 @@ def cpu_baseline(bases, n_sample, L, paired, bases2):
     else:
         keep = oracle.dedup_single(host, offs, lens)
     dt = time.perf_counter() - t0
-    return {"value": round(n_sample / dt / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
+    return {"value": round(n_sample / dt / 1e6, 4), "unit": "Mpairs/s" if paired else "Mreads/s", "cores": 1, "kind": "port",
             "sample": f"first {n_sample} reads of the same synthetic workload, in-memory arrays "
                       f"(no file parsing or output), {dt:.1f} s; host has {os.cpu_count()} cores, the reference "
                       f"path is single-threaded"}, keep

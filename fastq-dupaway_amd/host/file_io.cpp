@@ -1,6 +1,7 @@
 #include "file_io.hpp"
 
 #include <cerrno>
+#include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
 #include <algorithm>
@@ -260,7 +261,9 @@ std::string deflate_member(std::string raw)
     std::string out;
     out.reserve(raw.size() / 3 + 1024);
     z_stream zs{};
-    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK)
+    // zlib's default level, as the reference's Boost gzip filter uses; FQD_GZ_LEVEL=1..9 trades size for speed
+    static const int level = [] { const char* v = std::getenv("FQD_GZ_LEVEL"); const int l = v ? std::atoi(v) : 0; return l >= 1 && l <= 9 ? l : Z_DEFAULT_COMPRESSION; }();
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK)
         throw std::runtime_error("zlib: deflateInit2 failed");
     unsigned char body[65536];
     for (size_t at = 0; at < raw.size(); at += kBgzfInput) {
@@ -300,7 +303,7 @@ OutputFile::OutputFile(const std::string& name) : gz_(has_gz_extension(name)), n
         std::setvbuf(f_, nullptr, _IOFBF, 256 * 1024);
         block_.reserve(kGzMember + 65536);
         const unsigned hw = std::thread::hardware_concurrency();
-        max_in_flight_ = hw >= 16 ? 8 : (hw >= 4 ? hw / 2 : 1);
+        max_in_flight_ = hw >= 32 ? 16 : (hw >= 16 ? 8 : (hw >= 4 ? hw / 2 : 1));    // deflate jobs in flight (16 BGZF members each)
     } else {
         fd_ = ::open(name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
         if (fd_ < 0) throw_cannot_open(name);

@@ -463,3 +463,16 @@ def test_differential_fuzz_single_and_paired_with_injected_errors(exe, oracle, t
             assert g.exists() == e.exists(), what
             if e.exists():
                 assert g.read_bytes() == e.read_bytes(), what
+
+
+@pytest.mark.gpu
+def test_pipes_as_input_and_output(exe, oracle, tmp_path):
+    """Not regular files: the input comes through /dev/stdin (no size, no pread), the output goes
+    to /dev/stdout."""
+    rnd = random.Random(77)
+    raw = fastq([(b"p%05d" % k, s) for k, s in enumerate(random_reads(rnd, 5000, 900, 10, 90))])
+    src = tmp_path / "in.fq"; src.write_bytes(raw)
+    exp = tmp_path / "exp.fq"; oracle.filter_single(src, exp, FASTQ)
+    r = subprocess.run([exe, "-i", "/dev/stdin", "-o", "/dev/stdout", "--fast"], input=raw, capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == exp.read_bytes()

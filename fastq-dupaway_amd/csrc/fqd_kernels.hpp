@@ -881,30 +881,75 @@ void heavy_bucket_insert_kernel(const uint64_t* __restrict__ recs, const uint32_
     const uint64_t seg_mask = (1ull << g.seg_bits) - 1ull;
     const uint32_t qshift = g.seg_bits + g.bits2;
     uint32_t dups = 0, lost = 0;
+    const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t k = 0; k < n_heavy; ++k) {
         const uint32_t b = heavy_list[k];
         const uint64_t lo = bstart[b], hi = bstart[b + 1];
-        for (uint64_t r = lo + blockIdx.x * uint64_t(kBlock) + threadIdx.x; r < hi; r += uint64_t(gridDim.x) * kBlock) {
-            const uint64_t v = recs[r];
+        // wave-uniform trip count: the lanes of a wave settle their duplicates together below
+        for (uint64_t r0 = lo + blockIdx.x * uint64_t(kBlock) + (threadIdx.x & ~63u); r0 < hi; r0 += uint64_t(gridDim.x) * kBlock) {
+            const uint64_t r = r0 + lane;
+            const bool live = r < hi;
+            const uint64_t v = live ? recs[r] : 0;
             const uint32_t idx = uint32_t(v), q = uint32_t(v >> 32);
             const uint64_t tag = q >> qshift;
             const unsigned long long mine = (tag << 32) | idx;
             uint64_t pos = (uint64_t(b) << g.seg_bits) | (q & seg_mask);
-            bool placed = false;
-            for (uint64_t probe = 0; probe <= seg_mask; ++probe) {
-                const unsigned long long old = atomicCAS(&tab[pos], kEmptySlot, mine);
-                if (old == kEmptySlot) { placed = true; break; }
-                if ((old >> 32) == tag && keys_equal(ks, idx, uint32_t(old))) {
-                    uint32_t owner = uint32_t(old);
-                    if (owner > idx) owner = uint32_t(atomicMin(&tab[pos], mine));
-                    if (owner < idx) out.lose(idx, owner);
-                    else             out.lose(owner, idx);
-                    ++dups; placed = true;
-                    break;
+            // 1. probe, the wave in step: claim an empty slot, or stop at the slot that holds my key.
+            //    Of the lanes that see the same empty slot only the earliest record tries the CAS
+            //    (the others look again): a million copies of one key starting together would
+            //    otherwise queue up on one address, one atomic each.
+            bool done = !live, found = false;
+            uint32_t owner = 0, steps = 0;
+            while (__any(!done)) {
+                unsigned long long old = done ? 0ull : tab[pos];
+                const bool empty = !done && old == kEmptySlot;
+                bool try_claim = false;
+                unsigned long long e_todo = __ballot(empty);
+                while (e_todo) {
+                    const int leader = __ffsll(static_cast<long long>(e_todo)) - 1;
+                    const uint64_t lpos = __shfl(pos, leader, 64);
+                    const bool same = empty && pos == lpos;
+                    const unsigned long long group = __ballot(same);
+                    uint32_t m = same ? idx : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(m, d, 64); m = o < m ? o : m; }
+                    if (same && idx == m) try_claim = true;
+                    e_todo &= ~group;
                 }
-                pos = (pos & ~seg_mask) | ((pos + 1) & seg_mask);
+                if (try_claim) {
+                    old = atomicCAS(&tab[pos], kEmptySlot, mine);
+                    if (old == kEmptySlot) done = true;
+                }
+                if (!done && (!empty || try_claim)) {              // `old` is a real owner now
+                    if ((old >> 32) == tag && keys_equal(ks, idx, uint32_t(old))) { owner = uint32_t(old); found = true; done = true; }
+                    else if (++steps > seg_mask) { ++lost; done = true; }
+                    else pos = (pos & ~seg_mask) | ((pos + 1) & seg_mask);
+                }
             }
-            if (!placed) ++lost;
+            // 2. the wave's duplicates, slot by slot: only the earliest record of the wave goes to the
+            //    table (one atomicMin instead of up to 64 on the same address), the others lose to it
+            unsigned long long todo = __ballot(found);
+            while (todo) {
+                const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+                const uint64_t lpos = __shfl(pos, leader, 64);
+                const bool mine_too = found && pos == lpos;
+                const unsigned long long group = __ballot(mine_too);
+                uint32_t m = mine_too ? idx : 0xFFFFFFFFu;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(m, d, 64); m = o < m ? o : m; }
+                if (mine_too) {
+                    if (idx == m) {
+                        uint32_t prev = owner;
+                        if (prev > idx) prev = uint32_t(atomicMin(&tab[pos], mine));
+                        if (prev < idx) out.lose(idx, prev);        // an earlier record holds this key
+                        else            out.lose(prev, idx);        // I am earlier: the displaced one loses
+                    } else {
+                        out.lose(idx, m);
+                    }
+                    ++dups;
+                }
+                todo &= ~group;
+            }
         }
     }
 #pragma unroll

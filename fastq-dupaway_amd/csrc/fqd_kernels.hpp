@@ -397,7 +397,7 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, uint64_t se
             // slot that looks empty is worth one of the (much scarcer) memory-side atomics.  A stale
             // view is harmless: a stale EMPTY makes the CAS fail and return the truth, a stale owner
             // is a younger record of the same key and is sorted out by the atomicMin below.
-            unsigned long long old = tab[pos];
+            unsigned long long old = __hip_atomic_load(&tab[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // from L2, never a stale L1 line
             if (old == kEmptySlot) {
                 old = atomicCAS(&tab[pos], kEmptySlot, mine);
                 if (old == kEmptySlot) { placed = true; break; }
@@ -901,7 +901,7 @@ void heavy_bucket_insert_kernel(const uint64_t* __restrict__ recs, const uint32_
             bool done = !live, found = false;
             uint32_t owner = 0, steps = 0;
             while (__any(!done)) {
-                unsigned long long old = done ? 0ull : tab[pos];
+                unsigned long long old = done ? 0ull : __hip_atomic_load(&tab[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // from L2, never a stale L1 line
                 const bool empty = !done && old == kEmptySlot;
                 bool try_claim = false;
                 unsigned long long e_todo = __ballot(empty);

@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Skew probe: 50 M synthetic reads of which a given fraction is overwritten with poly-G (one key
+repeated millions of times, as 2-colour sequencers produce), timed through the engine.
+  python tools/heavy_key_probe.py 0.3          [FQD_BULK_MIN=-1 for the atomic path]"""
 import sys, time, torch
 sys.path.insert(0, '/root/repo')
 from fastq_dupaway_amd import Engine, Reads

@@ -212,7 +212,7 @@ KeyStore key_store(const fqd_engine* e)
     return KeyStore{e->keys.as<uint64_t>(), e->ragged ? e->koff.as<uint64_t>() : nullptr, e->W0, e->W0, 0};
 }
 
-// Probing segments: 4096..16384 slots so that (slots / segment) <= 65536 buckets, or the whole
+// Probing segments: 4096..16384 slots so that (slots / segment) <= 131072 buckets, or the whole
 // table when it is smaller than one segment.
 uint32_t seg_bits_for(uint64_t slots)
 {
@@ -220,7 +220,7 @@ uint32_t seg_bits_for(uint64_t slots)
     if (t <= 12) return t;
     uint32_t want = 13u;                                 // 64 KiB of LDS per segment: best of the 12/13/14 sweep
     if (const char* v = std::getenv("FQD_SEG_BITS")) want = uint32_t(std::min(14, std::max(12, std::atoi(v))));
-    return std::min<uint32_t>(14u, std::max<uint32_t>(want, t >= 16 ? t - 16 : 12u));
+    return std::min<uint32_t>(14u, std::max<uint32_t>(want, t >= 17 ? t - 17 : 12u));
 }
 
 // How a table of 2^t slots with 2^seg_bits-slot segments is split into partition digits, and
@@ -229,15 +229,15 @@ uint32_t seg_bits_for(uint64_t slots)
 void table_digits(uint32_t t, uint32_t seg_bits, uint32_t& bits1, uint32_t& bits2)
 {
     const uint32_t nb_bits = t > seg_bits ? t - seg_bits : 0;
-    bits1 = nb_bits <= 8 ? nb_bits : (nb_bits + 1) / 2;
-    bits2 = nb_bits - bits1;
+    bits1 = nb_bits <= 8 ? nb_bits : std::min<uint32_t>(8u, (nb_bits + 1) / 2);   // level 1: 256 ways at most
+    bits2 = nb_bits - bits1;                                                      // level 2: 512 ways at most (bulk_plan checks)
 }
 uint32_t tag_mask_for(uint64_t slots, uint32_t seg_bits)
 {
     uint32_t t = 0; while ((1ull << t) < slots) ++t;
     uint32_t bits1, bits2;
     table_digits(t, seg_bits, bits1, bits2);
-    const uint32_t tag_bits = 32u - std::min(seg_bits, 14u) - std::min(bits2, 8u);
+    const uint32_t tag_bits = 32u - std::min(seg_bits, 14u) - std::min(bits2, 9u);
     return tag_bits >= 32 ? 0xFFFFFFFFu : (1u << tag_bits) - 1u;
 }
 
@@ -415,9 +415,9 @@ struct BulkPlan {
 int bulk_plan(fqd_engine* e, uint64_t n, BulkPlan& p)
 {
     uint32_t t = 0; while ((1ull << t) < e->slots) ++t;
-    const uint32_t nb_bits = t - e->seg_bits;                // <= 16 by construction of seg_bits (t <= 30)
+    const uint32_t nb_bits = t - e->seg_bits;                // <= 17 by construction of seg_bits (t <= 31)
     p.ok = false;
-    if (nb_bits > 16 || nb_bits == 0) return FQD_OK;
+    if (nb_bits > 17 || nb_bits == 0) return FQD_OK;
     p.g.slot_mask = e->slots - 1; p.g.seg_bits = e->seg_bits; p.g.tag_mask = e->tag_mask;
     table_digits(t, e->seg_bits, p.g.bits1, p.g.bits2);
     p.nd1 = 1u << p.g.bits1; p.n_buckets = 1u << nb_bits;
@@ -472,13 +472,18 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
                        static_cast<const uint32_t*>(hist1), nd1, start1, cursor1, tile_start1);
     hipLaunchKernelGGL(bulk_scatter_kernel<1>, dim3(part_grid), dim3(kPartThreads), 0, e->stream,
                        hashes, hash_stride, uint32_t(first_idx), static_cast<const uint64_t*>(nullptr), n, g,
-                       static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor1, recA, p.digit2);
+                       static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor1, recA, g.bits2 > 8 ? static_cast<uint8_t*>(nullptr) : p.digit2);
     if (g.bits2) {
         const uint32_t grid2 = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile + nd1, uint64_t(e->n_cu) * part_per_cu));
-        hipLaunchKernelGGL(bulk_hist2_kernel, dim3(grid2), dim3(kPartThreads), 0, e->stream,
-                           static_cast<const uint8_t*>(p.digit2), g, static_cast<const uint32_t*>(start1),
-                           static_cast<const uint32_t*>(tile_start1), hist2);
-        hipLaunchKernelGGL(bulk_scan_buckets_kernel, dim3(nd1), dim3(256), 0, e->stream,
+        if (g.bits2 > 8)
+            hipLaunchKernelGGL(bulk_hist2_kernel<true>, dim3(grid2), dim3(kPartThreads), 0, e->stream,
+                               static_cast<const uint8_t*>(nullptr), static_cast<const uint64_t*>(recA), g, static_cast<const uint32_t*>(start1),
+                               static_cast<const uint32_t*>(tile_start1), hist2);
+        else
+            hipLaunchKernelGGL(bulk_hist2_kernel<false>, dim3(grid2), dim3(kPartThreads), 0, e->stream,
+                               static_cast<const uint8_t*>(p.digit2), static_cast<const uint64_t*>(nullptr), g, static_cast<const uint32_t*>(start1),
+                               static_cast<const uint32_t*>(tile_start1), hist2);
+        hipLaunchKernelGGL(bulk_scan_buckets_kernel, dim3(nd1), dim3(512), 0, e->stream,
                            static_cast<const uint32_t*>(hist2), g.bits2, static_cast<const uint32_t*>(start1), nd1, start2, cursor2);
         hipLaunchKernelGGL(bulk_scatter_kernel<2>, dim3(grid2), dim3(kPartThreads), 0, e->stream,
                            static_cast<const uint64_t*>(nullptr), 0u, 0u, static_cast<const uint64_t*>(recA), n, g,

@@ -541,7 +541,8 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
 {
     __shared__ uint64_t stage[kPartTile];
     __shared__ uint8_t sdig[kPartTile];
-    __shared__ uint32_t cnt[256], lstart[256], gbase[256];
+    constexpr int kBins = (LEVEL == 1) ? 256 : 512;         // level 1: up to 8 bits, level 2: up to 9
+    __shared__ uint32_t cnt[kBins], lstart[kBins], gbase[kBins];
     const uint32_t nd1 = 1u << g.bits1, mask2 = (1u << g.bits2) - 1u;
     const uint64_t n_tiles = (LEVEL == 1) ? (n + kPartTile - 1) / kPartTile : tile_start1[nd1];
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -556,7 +557,7 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
             hi = lo + kPartTile < start1[d1 + 1] ? lo + kPartTile : start1[d1 + 1];
         }
         const uint32_t count = uint32_t(hi - lo);
-        for (int k = threadIdx.x; k < 256; k += kPartThreads) cnt[k] = 0;
+        for (int k = threadIdx.x; k < kBins; k += kPartThreads) cnt[k] = 0;
         __syncthreads();
         uint64_t rec[kPartPer]; uint32_t dig[kPartPer], rank[kPartPer];
 #pragma unroll
@@ -580,25 +581,27 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
             }
         }
         __syncthreads();
-        if (threadIdx.x < 64) {                               // exclusive scan of 256 counts by one wave
-            uint32_t c[4], s = 0;
+        if (threadIdx.x < 64) {                               // exclusive scan of the counts by one wave
+            constexpr int kPer = kBins / 64;
+            uint32_t c[kPer], s = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { c[k] = cnt[threadIdx.x * 4 + k]; s += c[k]; }
+            for (int k = 0; k < kPer; ++k) { c[k] = cnt[threadIdx.x * kPer + k]; s += c[k]; }
             uint32_t inc = s;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(inc, d, 64); if (int(threadIdx.x) >= d) inc += up; }
             uint32_t ex = inc - s;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { lstart[threadIdx.x * 4 + k] = ex; ex += c[k]; }
+            for (int k = 0; k < kPer; ++k) { lstart[threadIdx.x * kPer + k] = ex; ex += c[k]; }
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < 256; k += kPartThreads)
+        for (int k = threadIdx.x; k < kBins; k += kPartThreads)
             gbase[k] = cnt[k] ? atomicAdd(&cursor[(LEVEL == 1 ? 0u : (d1 << g.bits2)) + k], cnt[k]) : 0u;
 #pragma unroll
         for (int k = 0; k < kPartPer; ++k)
             if (threadIdx.x + k * kPartThreads < count) {
                 const uint32_t at = lstart[dig[k]] + rank[k];
-                stage[at] = rec[k]; sdig[at] = uint8_t(dig[k]);
+                stage[at] = rec[k];
+                if (LEVEL == 1) sdig[at] = uint8_t(dig[k]);       // level 2 finds its digit in the record itself
             }
         __syncthreads();
 #pragma unroll
@@ -606,7 +609,7 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
             const uint32_t r = threadIdx.x + k * kPartThreads;
             if (r < count) {
                 const uint64_t v = stage[r];
-                const uint32_t d = sdig[r];
+                const uint32_t d = (LEVEL == 1) ? uint32_t(sdig[r]) : ((uint32_t(v >> 32) >> g.seg_bits) & mask2);
                 out[gbase[d] + (r - lstart[d])] = v;      // plain stores: the short runs of neighbouring tiles combine in L2
                 if (LEVEL == 1 && digit2_out) digit2_out[gbase[d] + (r - lstart[d])] = uint8_t((uint32_t(v >> 32) >> g.seg_bits) & mask2);
             }
@@ -618,11 +621,13 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
 // Level-2 histogram over the level-1 output (read through the 1-byte level-2 digits the
 // level-1 scatter leaves beside the records: an eighth of the bytes).  A tile lies inside one
 // level-1 digit, so its counts go to consecutive buckets; LDS-aggregated, one global add per bin.
+// FROM_RECS: 9-bit level-2 digits do not fit the byte array; they are read out of the records.
+template <bool FROM_RECS>
 __global__ __launch_bounds__(kPartThreads)
-void bulk_hist2_kernel(const uint8_t* __restrict__ digit2_in, BulkGeom g, const uint32_t* __restrict__ start1,
+void bulk_hist2_kernel(const uint8_t* __restrict__ digit2_in, const uint64_t* __restrict__ recs, BulkGeom g, const uint32_t* __restrict__ start1,
                        const uint32_t* __restrict__ tile_start1, uint32_t* __restrict__ hist2)
 {
-    __shared__ uint32_t h[256];
+    __shared__ uint32_t h[512];
     const uint32_t nd1 = 1u << g.bits1, nd2 = 1u << g.bits2;
     const uint64_t n_tiles = tile_start1[nd1];
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -633,9 +638,12 @@ void bulk_hist2_kernel(const uint8_t* __restrict__ digit2_in, BulkGeom g, const 
         const uint64_t hi = lo + kPartTile < start1[d1 + 1] ? lo + kPartTile : start1[d1 + 1];
         for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) h[k] = 0;
         __syncthreads();
-        uint8_t dg[kPartPer];                                 // a tile is kPartPer digits per lane: all loads first
+        uint32_t dg[kPartPer];                                // a tile is kPartPer digits per lane: all loads first
 #pragma unroll
-        for (int k = 0; k < kPartPer; ++k) { const uint64_t r = lo + threadIdx.x + uint64_t(k) * kPartThreads; dg[k] = digit2_in[r < hi ? r : hi - 1]; }
+        for (int k = 0; k < kPartPer; ++k) {
+            const uint64_t r = lo + threadIdx.x + uint64_t(k) * kPartThreads, at = r < hi ? r : hi - 1;
+            dg[k] = FROM_RECS ? (uint32_t(recs[at] >> 32) >> g.seg_bits) : uint32_t(digit2_in[at]);
+        }
 #pragma unroll
         for (int k = 0; k < kPartPer; ++k)
             if (lo + threadIdx.x + uint64_t(k) * kPartThreads < hi) atomicAdd(&h[dg[k] & (nd2 - 1u)], 1u);
@@ -645,14 +653,14 @@ void bulk_hist2_kernel(const uint8_t* __restrict__ digit2_in, BulkGeom g, const 
     }
 }
 
-// One 256-thread block per level-1 digit d1: the level-1 output is grouped by d1, so the buckets
+// One 512-thread block per level-1 digit d1: the level-1 output is grouped by d1, so the buckets
 // (d1, 0..nd2) start at start1[d1] plus the exclusive prefix of their own counts — no scan over
 // all buckets is needed.  start[b] for every bucket, start[nb] = total; cursor = start.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(512)
 void bulk_scan_buckets_kernel(const uint32_t* __restrict__ count, uint32_t bits2, const uint32_t* __restrict__ start1,
                               uint32_t nd1, uint32_t* __restrict__ start, uint32_t* __restrict__ cursor)
 {
-    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t wave_tot[8];
     const uint32_t nd2 = 1u << bits2, d1 = blockIdx.x, t = threadIdx.x;
     const uint32_t c = t < nd2 ? count[(d1 << bits2) + t] : 0u;
     uint32_t inc = c;

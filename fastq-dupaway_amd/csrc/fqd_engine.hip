@@ -353,6 +353,16 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
             };
             if (c.lds_out) launch(encode_staged_pe_kernel<true>); else launch(encode_staged_pe_kernel<false>);
         }
+    } else if (!(e->flags & FQD_FLAG_NO_STAGE) && sv[0].offsets && (e->S == 1 || sv[1].offsets)) {
+        // ragged descriptors: stage each tile's span of the input through LDS where the records lie close together
+        const uint32_t R = 128, span_cap = e->S == 2 ? 24u * 1024u : 48u * 1024u;
+        const uint32_t grid = uint32_t(std::min<uint64_t>((n + R - 1) / R, uint64_t(e->n_cu) * blocks_per_cu));
+        if (e->S == 1)
+            hipLaunchKernelGGL(encode_span_kernel<1>, dim3(grid), dim3(R), span_cap, stream,
+                               sv[0], sv[1], n, first_idx, ks, hash_out, err, span_cap, h1);
+        else
+            hipLaunchKernelGGL(encode_span_kernel<2>, dim3(grid), dim3(R), 2 * span_cap, stream,
+                               sv[0], sv[1], n, first_idx, ks, hash_out, err, span_cap, h1);
     } else {
         const uint32_t grid = uint32_t(std::min<uint64_t>(grid_for(e, n), uint64_t(e->n_cu) * blocks_per_cu));
         if (e->S == 1)

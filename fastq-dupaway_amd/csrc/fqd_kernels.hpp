@@ -169,6 +169,100 @@ __device__ __forceinline__ void stage_chunks(const uint8_t* __restrict__ src_byt
 }
 
 // ---------------------------------------------------------------------------
+// encode_span: ragged batches whose reads lie close together in memory — trimmed reads packed back
+// to back, or the sequence lines of a FASTQ block with IDs and qualities in between.  A workgroup
+// takes R consecutive records; per mate, the bytes from its first record's sequence to the end of
+// its last one's (the span) are pulled into LDS with coalesced 16-byte loads when they fit the
+// mate's LDS budget and every record of the tile lies inside; then each lane packs its read out of
+// LDS.  A tile that does not qualify (offsets that jump around, as after the `--unordered` join, or
+// very long records) is encoded straight from HBM like encode_general does.  Keys go to their slots
+// with per-lane stores.   LDS: S * span_cap bytes.
+template <int S>
+__global__ __launch_bounds__(kBlock)
+void encode_span_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_idx, KeyStore ks,
+                        uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err, uint32_t span_cap, Hist1 h1)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ uint32_t lhist[256];
+    __shared__ uint32_t vote;
+    if (h1.hist) hist1_clear(lhist);
+    const uint32_t R = blockDim.x;
+    const uint64_t n_tiles = (n + R - 1) / R;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t i0 = tile * R;
+        const uint32_t nr = uint32_t(n - i0 < R ? n - i0 : R);
+        const uint64_t i = i0 + threadIdx.x;
+        const bool live = threadIdx.x < nr;
+        const uint8_t* p[2] = {nullptr, nullptr};
+        uint32_t len[2] = {0, 0}, head[2] = {0, 0};
+        const uint8_t* lo[2] = {nullptr, nullptr};
+        if (threadIdx.x == 0) vote = 1u;
+        __syncthreads();
+        bool fits = true;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const SegView& sv = s ? s1 : s0;
+            if (live) { p[s] = sv.ptr(i); len[s] = sv.len(i); }
+            lo[s] = sv.ptr(i0);
+            const uint8_t* hi = sv.ptr(i0 + nr - 1) + sv.len(i0 + nr - 1);
+            head[s] = uint32_t(reinterpret_cast<uintptr_t>(lo[s]) & 15u);
+            fits = fits && hi >= lo[s] && uint64_t(hi - lo[s]) + head[s] + 32u <= span_cap;
+            if (live) fits = fits && p[s] >= lo[s] && p[s] + len[s] <= hi;
+        }
+        if (!fits) vote = 0u;                                  // any lane can veto the tile
+        __syncthreads();
+        const bool staged = vote != 0u;
+        if (staged) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const SegView& sv = s ? s1 : s0;
+                const uint8_t* hi = sv.ptr(i0 + nr - 1) + sv.len(i0 + nr - 1);
+                stage_chunks(lo[s] - head[s], lds + s * (span_cap >> 2), (head[s] + uint32_t(hi - lo[s]) + 15u) >> 4, R);
+            }
+        }
+        __syncthreads();
+        if (live) {
+            uint64_t* out = ks.slot(first_idx + i);
+            uint64_t h = hash_begin(len[0], 0);
+            if (ks.koff) *out++ = uint64_t(len[0]) | (uint64_t(len[1]) << 32);
+            auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
+            uint32_t diff;
+            if (staged) {
+                const uint32_t b0 = head[0] + uint32_t(p[0] - lo[0]);
+                diff = pack_mate(lds + (b0 >> 2), b0 & 3u, len[0], sink);
+            } else {
+                const uintptr_t a0 = reinterpret_cast<uintptr_t>(p[0]);
+                diff = pack_mate(reinterpret_cast<const uint32_t*>(a0 & ~uintptr_t(3)), uint32_t(a0 & 3u), len[0], sink);
+            }
+            if (S == 2) {
+                const uint64_t m0 = h;
+                h = hash_begin(len[1], 0);
+                if (staged) {
+                    const uint32_t b1 = span_cap + head[1] + uint32_t(p[1] - lo[1]);
+                    diff |= pack_mate(lds + (b1 >> 2), b1 & 3u, len[1], sink);
+                } else {
+                    const uintptr_t a1 = reinterpret_cast<uintptr_t>(p[1]);
+                    diff |= pack_mate(reinterpret_cast<const uint32_t*>(a1 & ~uintptr_t(3)), uint32_t(a1 & 3u), len[1], sink);
+                }
+                h = hash_pair(m0, h);
+            } else {
+                h = hash_end(h);
+            }
+            h &= h1.hash_and;
+            if (ks.lead) ks.slot(first_idx + i)[-1] = h;
+            if (hash_out) hash_out[i] = h;
+            if (h1.hist) atomicAdd(&lhist[bucket_of(h, h1.g) >> h1.g.bits2], 1u);
+            if (diff) {
+                const uint64_t e = locate_bad_base(p[0], len[0], p[1], len[1], first_idx + i);
+                if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
+            }
+        }
+        __syncthreads();
+    }
+    if (h1.hist) hist1_flush(lhist, h1.hist);
+}
+
+// ---------------------------------------------------------------------------
 // encode_staged: uniform-length, uniform-stride input (the BASELINE layout: 150 B
 // per read, back to back).  A workgroup pulls a tile of R reads (R*stride bytes,
 // 16-B aligned chunks) into LDS with fully coalesced 16-byte loads, then each

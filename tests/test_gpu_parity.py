@@ -424,3 +424,41 @@ def test_very_long_and_empty_reads(oracle):
         keep = e.submit([Reads(data, uniform_len=L, uniform_stride=L)], 2000)
     exp = oracle.dedup_single(data, np.arange(2000, dtype=np.uint64) * np.uint64(L), np.full(2000, L, np.uint32))
     assert np.array_equal(keep, exp)
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_ragged_tiles_that_do_and_do_not_fit_the_staged_span(oracle, paired):
+    """The ragged encoder stages a tile's span of the input through LDS when its records lie close
+    together and falls back to per-lane loads otherwise: packed reads, a few records far away from
+    their neighbours, shuffled offsets and reads longer than the LDS budget all give the oracle's flags."""
+    rng = np.random.default_rng(77)
+    S = 2 if paired else 1
+    n = 9000
+    pools = [make_pool_reads(rng, n, 1200 if m == 0 else 40, 0, 180) for m in range(S)]
+    for m in range(S):                                       # a few very long reads (longer than a tile's LDS budget)
+        for k in (100, 2000, 2001, 7777):
+            pools[m][k] = bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=70_000))
+        pools[m][5000] = pools[m][100]
+    segs, host = [], []
+    for m in range(S):
+        order = np.arange(n)
+        if m == 0:
+            order[3000:6000] = rng.permutation(order[3000:6000])       # offsets that jump around inside tiles
+        chunks, offs, lens, pos = [None] * n, np.zeros(n, np.uint64), np.zeros(n, np.uint32), 0
+        for slot in range(n):                                # record order[slot] is laid out at position slot
+            k = int(order[slot])
+            gap = 5000 if slot % 1500 == 7 else (slot % 3)   # now and then a record far from its neighbours
+            pos += gap
+            offs[k], lens[k] = pos, len(pools[m][k])
+            chunks[slot] = b"#" * gap + pools[m][k]
+            pos += len(pools[m][k])
+        data = np.frombuffer(b"".join(chunks) + b"\0" * 16, dtype=np.uint8).copy()
+        segs.append(Reads(data, offs, lens)); host.append((data, offs, lens))
+    with Engine(segments=S) as e:
+        keep = e.submit(segs, n)
+    if paired:
+        exp = oracle.dedup_paired(*host[0], *host[1])
+    else:
+        exp = oracle.dedup_single(*host[0])
+    assert np.array_equal(keep, exp)
+    assert 0 < int((exp == 0).sum()) < n

@@ -510,17 +510,17 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
     unsigned long long* counters = reinterpret_cast<unsigned long long*>(e->d_state + 1);
     uint32_t heavy_above = 4u << e->seg_bits;                   // far beyond what a segment can hold at <= 50 % load
     if (const char* v = std::getenv("FQD_HEAVY_ABOVE")) heavy_above = uint32_t(std::max(0, std::atoi(v)));
-    if (fresh) {
-        if (lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_dedup_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        hipLaunchKernelGGL(bucket_dedup_kernel<true>, dim3(dgrid), dim3(dthreads), lds, e->stream,
+    auto launch_dedup = [&](auto kernel) -> int {
+        if (lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        hipLaunchKernelGGL(kernel, dim3(dgrid), dim3(dthreads), lds, e->stream,
                            final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, g.seg_bits + g.bits2, ks, verdicts, counters,
                            heavy_above, p.heavy_count, p.heavy_list);
-    } else {
-        if (lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_dedup_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        hipLaunchKernelGGL(bucket_dedup_kernel<false>, dim3(dgrid), dim3(dthreads), lds, e->stream,
-                           final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, g.seg_bits + g.bits2, ks, verdicts, counters,
-                           heavy_above, p.heavy_count, p.heavy_list);
-    }
+        return FQD_OK;
+    };
+    int drc;
+    if (fresh) drc = ks.koff ? launch_dedup(bucket_dedup_kernel<true, true>) : launch_dedup(bucket_dedup_kernel<true, false>);
+    else       drc = ks.koff ? launch_dedup(bucket_dedup_kernel<false, true>) : launch_dedup(bucket_dedup_kernel<false, false>);
+    if (drc) return drc;
     hipLaunchKernelGGL(heavy_bucket_insert_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
                        final_recs, bstart, g, e->table.as<uint64_t>(), ks, verdicts, counters,
                        static_cast<const uint32_t*>(p.heavy_count), static_cast<const uint32_t*>(p.heavy_list));

@@ -785,11 +785,13 @@ void bulk_scan_buckets_kernel(const uint32_t* __restrict__ count, uint32_t bits2
 // phase goes straight from LDS to the two key gathers.  Candidates fill the queue from the front,
 // retries from the back; a retry that would reach the candidates is walked on the spot instead.
 // LDS: segment (2^seg_bits * 8 B) + kDedupChunk queue entries of 8 B + 2 counters.
+// RAGGED = the key store is ragged (ks.koff): compiled apart so that neither verify variant pays
+// for the other's registers.
 constexpr uint32_t kDedupChunk = 1536;
 constexpr uint32_t kDedupFly = 4;
 constexpr uint32_t kDedupLoads = 3;                      // records a lane fetches at once in the probe phase (chunk / 512 lanes)
 
-template <bool FRESH>
+template <bool FRESH, bool RAGGED>
 __global__ __launch_bounds__(1024)
 void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ bstart, uint32_t n_buckets,
                          uint64_t* __restrict__ table, uint32_t seg_bits, uint32_t qshift, KeyStore ks, Verdicts out,
@@ -877,14 +879,15 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
             __syncthreads();
             // 2. verify, eight lanes per candidate, kDedupFly candidates per group in flight
             const uint32_t n_cand = qn[0];
+            constexpr uint32_t kFly = RAGGED ? 3u : kDedupFly;     // ragged keys need more registers per candidate
             const uint32_t grp = threadIdx.x >> 3, n_grp = blockDim.x >> 3, sub = threadIdx.x & 7u;
-            for (uint32_t q0 = grp; q0 < n_cand; q0 += n_grp * kDedupFly) {
-                uint32_t pos[kDedupFly], idx[kDedupFly], seen[kDedupFly], tag[kDedupFly];
-                uint64_t diff[kDedupFly];
-                bool live[kDedupFly];
-                uint64_t wa[kDedupFly][2], wb[kDedupFly][2];
+            for (uint32_t q0 = grp; q0 < n_cand; q0 += n_grp * kFly) {
+                uint32_t pos[kFly], idx[kFly], seen[kFly], tag[kFly];
+                uint64_t diff[kFly];
+                bool live[kFly];
+                uint64_t wa[kFly][2], wb[kFly][2];
 #pragma unroll
-                for (uint32_t u = 0; u < kDedupFly; ++u) {        // issue every load of the batch first
+                for (uint32_t u = 0; u < kFly; ++u) {        // issue every load of the batch first
                     const uint32_t q = q0 + u * n_grp;
                     live[u] = q < n_cand;
                     diff[u] = 0; pos[u] = 0; idx[u] = 0; seen[u] = 0; tag[u] = 0;
@@ -894,7 +897,7 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
                         idx[u] = uint32_t(ent); pos[u] = uint32_t(ent >> 32) & seg_mask; tag[u] = uint32_t(ent >> 32) >> seg_bits;
                         seen[u] = uint32_t(seg[pos[u]]);      // the slot's owner right now: same key class for good
                     }
-                    if (!ks.koff) {
+                    if (!RAGGED) {
                         // uniform keys: addresses are arithmetic, so the (up to) two words a lane owns of
                         // each key are requested here and only looked at after the whole batch is in flight
                         const uint64_t* __restrict__ pa = ks.keys + idx[u] * uint64_t(ks.stride) + ks.lead;
@@ -902,30 +905,56 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
                         const bool w0 = live[u] && sub < ks.W0, w1 = live[u] && sub + 8u < ks.W0;
                         wa[u][0] = w0 ? pa[sub] : 0; wb[u][0] = w0 ? pb[sub] : 0;
                         wa[u][1] = w1 ? pa[sub + 8u] : 0; wb[u][1] = w1 ? pb[sub + 8u] : 0;
+                    } else {
+                        // ragged keys, first of three dependent steps (slot offsets -> headers -> words),
+                        // each taken for the whole batch before the next: wa/wb[.][0] hold the offsets for now
+                        wa[u][0] = live[u] ? ks.koff[idx[u]] : 0; wb[u][0] = live[u] ? ks.koff[seen[u]] : 0;
                     }
                 }
+                if (RAGGED) {
+                    uint64_t oa[kFly], ob[kFly];
 #pragma unroll
-                for (uint32_t u = 0; u < kDedupFly; ++u) {
-                    if (!live[u]) continue;
-                    if (!ks.koff) {
+                    for (uint32_t u = 0; u < kFly; ++u) {        // headers: mate lengths
+                        oa[u] = wa[u][0]; ob[u] = wb[u][0];
+                        wa[u][1] = live[u] ? ks.keys[oa[u]] : 0; wb[u][1] = live[u] ? ks.keys[ob[u]] : 0;
+                    }
+                    uint32_t Wr[kFly];
+#pragma unroll
+                    for (uint32_t u = 0; u < kFly; ++u) {        // words
+                        const uint64_t ha = wa[u][1];
+                        diff[u] = ha ^ wb[u][1];
+                        Wr[u] = seg_words(uint32_t(ha)) + seg_words(uint32_t(ha >> 32));
+                        const bool same = live[u] && diff[u] == 0;
+                        const uint64_t* __restrict__ pa = ks.keys + oa[u] + 1;
+                        const uint64_t* __restrict__ pb = ks.keys + ob[u] + 1;
+                        const bool w0 = same && sub < Wr[u], w1 = same && sub + 8u < Wr[u];
+                        wa[u][0] = w0 ? pa[sub] : 0; wb[u][0] = w0 ? pb[sub] : 0;
+                        wa[u][1] = w1 ? pa[sub + 8u] : 0; wb[u][1] = w1 ? pb[sub + 8u] : 0;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < kFly; ++u) {
+                        if (!live[u] || diff[u]) continue;
+                        diff[u] = (wa[u][0] ^ wb[u][0]) | (wa[u][1] ^ wb[u][1]);
+                        if (Wr[u] > 16u) {
+                            const uint64_t* __restrict__ pa = ks.keys + oa[u] + 1;
+                            const uint64_t* __restrict__ pb = ks.keys + ob[u] + 1;
+                            for (uint32_t w = sub + 16u; w < Wr[u]; w += 8u) diff[u] |= pa[w] ^ pb[w];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t u = 0; u < kFly; ++u) {
+                        if (!live[u]) continue;
                         diff[u] = (wa[u][0] ^ wb[u][0]) | (wa[u][1] ^ wb[u][1]);
                         if (ks.W0 > 16u) {                    // longer keys: the remaining words, the plain way
                             const uint64_t* __restrict__ pa = ks.keys + idx[u] * uint64_t(ks.stride) + ks.lead;
                             const uint64_t* __restrict__ pb = ks.keys + seen[u] * uint64_t(ks.stride) + ks.lead;
                             for (uint32_t w = sub + 16u; w < ks.W0; w += 8u) diff[u] |= pa[w] ^ pb[w];
                         }
-                    } else {
-                        const uint64_t* __restrict__ pa = ks.slot(idx[u]);
-                        const uint64_t* __restrict__ pb = ks.slot(seen[u]);
-                        const uint64_t ha = pa[0];
-                        diff[u] = ha ^ pb[0];                 // mate lengths
-                        const uint32_t W = seg_words(uint32_t(ha)) + seg_words(uint32_t(ha >> 32));
-                        ++pa; ++pb;
-                        if (!diff[u]) for (uint32_t w = sub; w < W; w += 8u) diff[u] |= pa[w] ^ pb[w];
                     }
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < kDedupFly; ++u) {
+                for (uint32_t u = 0; u < kFly; ++u) {
                     uint64_t d = diff[u];
                     d |= __shfl_xor(d, 1, 64); d |= __shfl_xor(d, 2, 64); d |= __shfl_xor(d, 4, 64);
                     if (live[u] && sub == 0u) {

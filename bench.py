@@ -89,12 +89,12 @@ def main():
     eng = Engine(segments=S, device=local, capacity_reads=n, capacity_bases=S * n * L, profile=True)
     sharded_mode = dist is not None
     # Sharded runs move a step's reads in rounds sized so that no rank-to-rank message of the
-    # all-to-all exceeds 256 MiB (72-byte records for 150 bp): 4 rounds per step on 8 GPUs, enough for
+    # all-to-all exceeds 256 MiB (64-byte keys for 150 bp): 3 rounds per step on 8 GPUs, enough for
     # the round pipeline to hide most of the exchange.  Measured on this image (RCCL 2.26.6, torch
     # 2.10): a single all_to_all_single message above 1 GiB arrives corrupted.  The
     # job's input order is (round, rank, position) — file blocks dealt round-robin to the ranks —
     # so round k of rank r holds the global indices below.
-    rec_bytes = 8 * (1 + eng.key_words(L, L if S == 2 else 0))
+    rec_bytes = 8 * (eng.key_words(L, L if S == 2 else 0) + (1 if os.environ.get("FQD_SHARDED_WITH_HASH") == "1" else 0))   # keys travel without their hash
     lazy = sharded_mode and os.environ.get("FQD_SHARDED_LAZY") == "1"       # hashes first, keys only for candidates
     if lazy:
         rec_bytes = 16

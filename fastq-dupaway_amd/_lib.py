@@ -103,6 +103,9 @@ def load_library():
     L.fqd_sort_tags.argtypes = [vp, C.POINTER(TagsDesc), vp]
     L.fqd_match_sorted_tags.argtypes = [vp, C.POINTER(TagsDesc), vp, C.POINTER(TagsDesc), vp, vp]
     L.fqd_scatter_flags.argtypes = [vp, vp, vp, u64, vp]
+    L.fqd_partition_keys.argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
+    L.fqd_reserve_keys.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
+    L.fqd_insert_keys.argtypes = [vp, vp, u64, u32, u32, vp]
     L.fqd_encode_batch.argtypes = [vp, C.POINTER(ReadsDesc), u64, vp]
     L.fqd_make_hash_records.argtypes = [vp, vp, u64, u64, vp]
     L.fqd_reserve_hashes.argtypes = [vp, u64, C.POINTER(vp)]

@@ -900,8 +900,24 @@ int fqd_encode_uniform(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint64_t
     return rc;
 }
 
+static int partition_impl(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
+                          uint32_t n_parts, uint64_t* out, uint64_t* counts, uint32_t* origin, uint32_t strip);
+
 int fqd_partition_records(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
                           uint32_t n_parts, uint64_t* out, uint64_t* counts, uint32_t* origin)
+{
+    return partition_impl(e, records, n, key_words, n_parts, out, counts, origin, 0u);
+}
+
+int fqd_partition_keys(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
+                       uint32_t n_parts, uint64_t* out_keys, uint64_t* counts, uint32_t* origin)
+{
+    if (e && key_words == 0) return e->fail(FQD_ERR_ARG, "fqd_partition_keys: records without key words");
+    return partition_impl(e, records, n, key_words, n_parts, out_keys, counts, origin, 1u);
+}
+
+static int partition_impl(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
+                          uint32_t n_parts, uint64_t* out, uint64_t* counts, uint32_t* origin, uint32_t strip)
 {
     if (!e) return FQD_ERR_ARG;
     if (!n_parts || n_parts > 1024 || !counts || (n && (!records || !out || !origin)) || n > 0xFFFFFFFFull)
@@ -923,7 +939,7 @@ int fqd_partition_records(fqd_engine* e, const uint64_t* records, uint64_t n, ui
     if (scatter_lds > 64 * 1024) return e->fail(FQD_ERR_ARG, "fqd_partition_records: records too long for the staged partition");
     const uint32_t rw_magic = rec_words > 1 ? uint32_t(((1ull << 32) + rec_words - 1) / rec_words) : 0xFFFFFFFFu;
     hipLaunchKernelGGL(part_scatter_kernel, dim3(n_blocks), dim3(kBlock), scatter_lds, e->stream,
-                       records, n, rec_words, n_parts, static_cast<const uint64_t*>(c2), n_blocks, out, origin, rw_magic);
+                       records, n, rec_words, n_parts, static_cast<const uint64_t*>(c2), n_blocks, out, origin, rw_magic, strip);
     hipLaunchKernelGGL(part_totals_kernel, dim3((n_parts + 63) / 64), dim3(64), 0, e->stream,
                        static_cast<const uint64_t*>(c2), n_parts, n_blocks, n, counts);
     HIP_TRY(e, hipGetLastError());
@@ -978,6 +994,66 @@ int fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n, uint3
     if (bulk_applies(e, n) && (rc = bulk_plan(e, n, plan))) return rc;
     if (plan.ok) { if ((rc = launch_bulk_insert(e, ks, hashes, e->W0 + 1, n, first, keep, plan, false))) return rc; }
     else if ((rc = launch_insert(e, ks, hashes, e->W0 + 1, n, first, keep))) return rc;
+    e->n_records += n; e->keys_used += words;
+    return FQD_OK;
+}
+
+// Keys that arrive without their hash (the sharded exchange): the owner is an ordinary uniform
+// engine, the keys lie back to back at the tail of its key store.
+static int prepare_keys(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1)
+{
+    if (e->S == 1 && len1 != 0) return e->fail(FQD_ERR_ARG, "keys: single-end engine given a mate-2 length");
+    if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (!e->have_shape) {
+        e->have_shape = true; e->ragged = false; e->rec_layout = false;
+        e->L0 = len0; e->L1 = len1; e->W0 = seg_words(len0) + seg_words(len1);
+    } else if (e->ragged || e->rec_layout || e->hash_layout || e->L0 != len0 || e->L1 != len1)
+        return e->fail(FQD_ERR_ARG, "keys: engine holds keys of another shape or layout");
+    if (e->W0 == 0) return e->fail(FQD_ERR_ARG, "keys: empty keys");
+    int rc;
+    if ((rc = ensure_table(e, e->n_records + n))) return rc;
+    const uint64_t need = e->keys_used + n * uint64_t(e->W0);
+    return reserve(e, e->keys, std::max<uint64_t>(need, 64) * sizeof(uint64_t), e->keys_used * sizeof(uint64_t));
+}
+
+int fqd_reserve_keys(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1, uint64_t** slot)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!slot) return e->fail(FQD_ERR_ARG, "fqd_reserve_keys: bad arguments");
+    const int rc = prepare_keys(e, n, len0, len1);
+    if (rc) return rc;
+    *slot = e->keys.as<uint64_t>() + e->keys_used;
+    return FQD_OK;
+}
+
+int fqd_insert_keys(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (n && (!keys || !keep)) return e->fail(FQD_ERR_ARG, "fqd_insert_keys: bad arguments");
+    if (n == 0) return FQD_OK;
+    int rc;
+    if ((rc = prepare_keys(e, n, len0, len1))) return rc;
+    const uint64_t first = e->n_records;
+    const uint64_t words = n * uint64_t(e->W0);
+    uint64_t* tail = e->keys.as<uint64_t>() + e->keys_used;
+    if (keys != tail) {                                      // not received in place: one contiguous copy
+        Bracket br(e, K_OTHER, 0);
+        HIP_TRY(e, hipMemcpyAsync(tail, keys, words * sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream));
+    }
+    e->hashed_records = nullptr;                              // the hash scratch is reused
+    if ((rc = reserve(e, e->hashes, n * sizeof(uint64_t)))) return rc;
+    {
+        Bracket br(e, K_OTHER, 0);
+        const uint64_t hash_and = (e->flags & FQD_FLAG_WEAK_HASH) ? 0x00000000FFFFFFC0ull : ~0ull;
+        hipLaunchKernelGGL(hash_keys_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
+                           static_cast<const uint64_t*>(tail), e->W0, n, e->L0, e->L1, uint32_t(e->S == 2), hash_and, e->hashes.as<uint64_t>());
+    }
+    const KeyStore ks = key_store(e);
+    BulkPlan plan;
+    if (bulk_applies(e, n) && (rc = bulk_plan(e, n, plan))) return rc;
+    if (plan.ok) { if ((rc = launch_bulk_insert(e, ks, e->hashes.as<uint64_t>(), 1, n, first, keep, plan, false))) return rc; }
+    else if ((rc = launch_insert(e, ks, e->hashes.as<uint64_t>(), 1, n, first, keep))) return rc;
     e->n_records += n; e->keys_used += words;
     return FQD_OK;
 }

@@ -1190,7 +1190,8 @@ void part_count_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stride
 __global__ __launch_bounds__(kBlock)
 void part_scatter_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t rec_words, uint32_t n_parts,
                          const uint64_t* __restrict__ starts2d, uint32_t n_blocks,
-                         uint64_t* __restrict__ out, uint32_t* __restrict__ origin, uint32_t rw_magic)
+                         uint64_t* __restrict__ out, uint32_t* __restrict__ origin, uint32_t rw_magic,
+                         uint32_t strip /* 1: leave word 0 (the hash) out of the output rows */)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t ptile[];
     uint64_t* dst_of = ptile + size_t(kBlock) * rec_words;
@@ -1227,7 +1228,7 @@ void part_scatter_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t 
     __syncthreads();
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) {
         const uint32_t r = rec_words == 1u ? w : __umulhi(w, rw_magic), k = w - r * rec_words;
-        out[dst_of[r] * rec_words + k] = ptile[w];
+        if (k >= strip) out[dst_of[r] * (rec_words - strip) + (k - strip)] = ptile[w];
     }
 }
 
@@ -1240,6 +1241,32 @@ __global__ void part_totals_kernel(const uint64_t* __restrict__ starts2d, uint32
     const uint64_t lo = starts2d[uint64_t(p) * n_blocks];
     const uint64_t hi = (p + 1 < n_parts) ? starts2d[uint64_t(p + 1) * n_blocks] : n;
     counts[p] = hi - lo;
+}
+
+// Placement hashes of uniform keys that arrived without them (the sharded exchange sends keys only):
+// the same chains the encoders run, over the stored key words.
+__global__ __launch_bounds__(kBlock)
+void hash_keys_kernel(const uint64_t* __restrict__ keys, uint32_t stride, uint64_t n, uint32_t len0, uint32_t len1,
+                      uint32_t paired, uint64_t hash_and, uint64_t* __restrict__ hashes)
+{
+    const uint32_t w0 = seg_words(len0), W = w0 + (paired ? seg_words(len1) : 0u);
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
+        const uint64_t* __restrict__ p = keys + i * uint64_t(stride);
+        uint64_t h = hash_begin(len0, 0), h1 = hash_begin(len1, 0);
+        for (uint32_t k0 = 0; k0 < W; k0 += 8u) {             // eight words requested at a time, then chained
+            uint64_t w[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) w[j] = p[k0 + j < W ? k0 + j : W - 1u];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) {
+                const uint32_t k = k0 + j;
+                if (k < w0) h = hash_word(h, w[j]);
+                else if (k < W) h1 = hash_word(h1, w[j]);
+            }
+        }
+        h = paired ? hash_pair(h, h1) : hash_end(h);
+        hashes[i] = h & hash_and;
+    }
 }
 
 __global__ __launch_bounds__(kBlock)

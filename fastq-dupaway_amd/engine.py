@@ -158,6 +158,19 @@ class Engine:
     def insert_records(self, records, n: int, len0: int, len1: int, keep):
         self._check(self._L.fqd_insert_records(self._h, _addr(records), n, len0, len1, _addr(keep)))
 
+    def partition_keys(self, records, n: int, key_words: int, n_parts: int, out_keys, counts, origin):
+        self._check(self._L.fqd_partition_keys(self._h, _addr(records), n, key_words, n_parts,
+                                               _addr(out_keys), _addr(counts), _addr(origin)))
+
+    def reserve_keys(self, n: int, len0: int, len1: int) -> int:
+        """Device address of room for n keys at the tail of the key store (receive in place)."""
+        slot = C.c_void_p()
+        self._check(self._L.fqd_reserve_keys(self._h, n, len0, len1, C.byref(slot)))
+        return slot.value
+
+    def insert_keys(self, keys, n: int, len0: int, len1: int, keep):
+        self._check(self._L.fqd_insert_keys(self._h, _addr(keys), n, len0, len1, _addr(keep)))
+
     # -- optimistic sharding (hashes first) ------------------------------------------------------
     def encode_batch(self, segs: Sequence[Reads], n: int, hashes):
         self._check(self._L.fqd_encode_batch(self._h, _desc_array(segs), n, _addr(hashes)))

@@ -26,29 +26,42 @@ class _DeviceWords:
 
 
 class HipOps:
-    """The sharding halves of include/fqdupaway.h on one GPU."""
+    """The sharding halves of include/fqdupaway.h on one GPU.  What travels is the key alone (the
+    owner recomputes the hash): exchange_words = key words; FQD_SHARDED_WITH_HASH=1 keeps the older
+    [hash | key] records on the wire."""
 
     def __init__(self, engine):
+        import os
         self.e = engine
+        self.with_hash = os.environ.get("FQD_SHARDED_WITH_HASH") == "1"
 
     def key_words(self, len0, len1):
         return self.e.key_words(len0, len1)
+
+    def exchange_words(self, len0, len1):
+        return self.key_words(len0, len1) + (1 if self.with_hash else 0)
 
     def encode(self, segs, n, records):
         self.e.encode_uniform(segs, n, records)
 
     def partition(self, records, n, key_words, parts, out, counts, origin):
-        self.e.partition_records(records, n, key_words, parts, out, counts, origin)
+        if self.with_hash:
+            self.e.partition_records(records, n, key_words, parts, out, counts, origin)
+        else:
+            self.e.partition_keys(records, n, key_words, parts, out, counts, origin)
 
     def recv_buffer(self, n, len0, len1, device):
         """Room for n records at the tail of the engine's key store, as a tensor the all-to-all can
-        write into: the records are then inserted where they lie (fqd_reserve_records)."""
-        rw = self.key_words(len0, len1) + 1
-        ptr = self.e.reserve_records(n, len0, len1)
-        return torch.as_tensor(_DeviceWords(ptr, max(1, n * rw)), device=device)
+        write into: they are then inserted where they lie (fqd_reserve_keys / fqd_reserve_records)."""
+        xw = self.exchange_words(len0, len1)
+        ptr = self.e.reserve_records(n, len0, len1) if self.with_hash else self.e.reserve_keys(n, len0, len1)
+        return torch.as_tensor(_DeviceWords(ptr, max(1, n * xw)), device=device)
 
     def insert(self, records, n, len0, len1, keep):
-        self.e.insert_records(records, n, len0, len1, keep)
+        if self.with_hash:
+            self.e.insert_records(records, n, len0, len1, keep)
+        else:
+            self.e.insert_keys(records, n, len0, len1, keep)
 
     def scatter(self, flags, origin, n, keep_out):
         self.e.scatter_flags(flags, origin, n, keep_out)
@@ -63,10 +76,10 @@ class HipOps:
 class _Round:
     """Buffers of one round in flight (the pipeline keeps two)."""
 
-    def __init__(self, n_max, rw, world, cap_recv, device):
+    def __init__(self, n_max, rw, xw, world, cap_recv, device):
         i64 = torch.int64
         self.records = torch.empty(n_max * rw, dtype=i64, device=device)
-        self.grouped = torch.empty(n_max * rw, dtype=i64, device=device)
+        self.grouped = torch.empty(n_max * xw, dtype=i64, device=device)
         self.origin = torch.empty(n_max, dtype=torch.int32, device=device)
         self.counts = torch.zeros(world, dtype=i64, device=device)
         self.recv_counts = torch.zeros(world, dtype=i64, device=device)
@@ -85,11 +98,13 @@ class ShardedDedup:
         self.rank = dist.get_rank()
         self.len0, self.len1 = len0, len1
         self.W = ops.key_words(len0, len1)
-        self.rw = self.W + 1
+        self.rw = self.W + 1                                  # words of an encoded record [hash | key]
+        # words of a record on the wire: the device halves may leave the hash out (HipOps)
+        self.xw = ops.exchange_words(len0, len1) if hasattr(ops, "exchange_words") else self.rw
         self.n_max = n_max
         i64 = torch.int64
         self.records = torch.empty(n_max * self.rw, dtype=i64, device=device)
-        self.grouped = torch.empty(n_max * self.rw, dtype=i64, device=device)
+        self.grouped = torch.empty(n_max * self.xw, dtype=i64, device=device)
         self.origin = torch.empty(n_max, dtype=torch.int32, device=device)
         self.counts = torch.zeros(self.world, dtype=i64, device=device)
         self.recv_counts = torch.zeros(self.world, dtype=i64, device=device)
@@ -97,12 +112,12 @@ class ShardedDedup:
         import os
         # receive straight into the owner's key store (FQD_SHARDED_INPLACE=0: through a staging buffer)
         self.in_place = hasattr(ops, "recv_buffer") and os.environ.get("FQD_SHARDED_INPLACE", "1") != "0"
-        self.recv = None if self.in_place else torch.empty(self.cap_recv * self.rw, dtype=i64, device=device)
+        self.recv = None if self.in_place else torch.empty(self.cap_recv * self.xw, dtype=i64, device=device)
         self.keep_recv = torch.empty(self.cap_recv, dtype=torch.uint8, device=device)
         self.keep_back = torch.empty(n_max, dtype=torch.uint8, device=device)
 
     def dedup(self, segs: Sequence, n: int, keep):
-        ops, dist, rw = self.ops, self.dist, self.rw
+        ops, dist, xw = self.ops, self.dist, self.xw
         if n > self.n_max:
             raise ValueError("batch larger than the buffers this ShardedDedup was built for")
         ops.encode(segs, n, self.records)
@@ -115,11 +130,11 @@ class ShardedDedup:
         if n_recv > self.cap_recv:                   # a skewed step: grow once, keep going
             self.cap_recv = int(n_recv * 1.1) + 4096
             if not self.in_place:
-                self.recv = torch.empty(self.cap_recv * rw, dtype=torch.int64, device=self.device)
+                self.recv = torch.empty(self.cap_recv * xw, dtype=torch.int64, device=self.device)
             self.keep_recv = torch.empty(self.cap_recv, dtype=torch.uint8, device=self.device)
         recv_buf = ops.recv_buffer(n_recv, self.len0, self.len1, self.device) if self.in_place else self.recv
-        dist.all_to_all_single(recv_buf[: n_recv * rw], self.grouped[: n * rw],
-                               output_split_sizes=[c * rw for c in recv], input_split_sizes=[c * rw for c in send])
+        dist.all_to_all_single(recv_buf[: n_recv * xw], self.grouped[: n * xw],
+                               output_split_sizes=[c * xw for c in recv], input_split_sizes=[c * xw for c in send])
         self._sync_comm()
         ops.insert(recv_buf, n_recv, self.len0, self.len1, self.keep_recv)
         ops.sync()
@@ -143,7 +158,7 @@ class ShardedDedup:
         import os
         if os.environ.get("FQD_SHARDED_PIPELINE", "1") == "0":
             return [self.dedup(segs, n, keep) for segs, n, keep in rounds]
-        ops, dist, rw, dev = self.ops, self.dist, self.rw, self.device
+        ops, dist, rw, xw, dev = self.ops, self.dist, self.rw, self.xw, self.device
         if not hasattr(self, "_pipe"):
             try:
                 self._s_e = torch.cuda.ExternalStream(ops.stream_handle(), device=dev)
@@ -151,7 +166,7 @@ class ShardedDedup:
             except Exception:                                 # no stream interop: keep the simple order
                 self.in_place = self.in_place and False
                 return [self.dedup(segs, n, keep) for segs, n, keep in rounds]
-            self._pipe = [_Round(self.n_max, rw, self.world, self.cap_recv, dev) for _ in range(2)]
+            self._pipe = [_Round(self.n_max, rw, xw, self.world, self.cap_recv, dev) for _ in range(2)]
         s_e, s_c = self._s_e, self._s_c
         R = len(rounds)
         st = [dict() for _ in range(R)]
@@ -178,9 +193,9 @@ class ShardedDedup:
             buf = ops.recv_buffer(n_recv, self.len0, self.len1, dev)     # tail of the key store, after insert(k-1)
             s_c.wait_event(st[k]["ev_p"])
             with torch.cuda.stream(s_c):
-                work = dist.all_to_all_single(buf[: n_recv * rw], b.grouped[: n * rw],
-                                              output_split_sizes=[c * rw for c in recv],
-                                              input_split_sizes=[c * rw for c in send], async_op=True)
+                work = dist.all_to_all_single(buf[: n_recv * xw], b.grouped[: n * xw],
+                                              output_split_sizes=[c * xw for c in recv],
+                                              input_split_sizes=[c * xw for c in send], async_op=True)
             st[k].update(send=send, recv=recv, n_recv=n_recv, buf=buf, work=work)
 
         def insert(k):

@@ -167,6 +167,15 @@ int  fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n,
  * in between. */
 int  fqd_reserve_records(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1, uint64_t** slot);
 
+/* The same exchange with 8 bytes less per record: the hash is left out of what travels
+ * (fqd_partition_keys writes the key words only) and recomputed by the owner, which is then an
+ * ordinary uniform engine whose keys lie back to back, aligned like everywhere else.
+ * fqd_reserve_keys / fqd_insert_keys mirror fqd_reserve_records / fqd_insert_records. */
+int  fqd_partition_keys(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
+                        uint32_t n_parts, uint64_t* out_keys, uint64_t* counts, uint32_t* origin);
+int  fqd_reserve_keys(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1, uint64_t** slot);
+int  fqd_insert_keys(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep);
+
 /* ---- optimistic sharding: hashes first, keys only for candidate duplicates ---------------
  * The exchange of fqd_insert_records moves every 72-byte record.  Here a rank keeps its keys
  * (fqd_encode_batch), sends 16-byte [hash | payload] records to the owners, which dedup by the

@@ -236,7 +236,9 @@ def test_lazy_exchange_on_gpu_with_virtual_ranks(oracle, world, paired, weak):
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("paired", [False, True])
-def test_sharded_on_gpu_with_virtual_ranks(oracle, world, paired):
+@pytest.mark.parametrize("with_hash", ["0", "1"])
+def test_sharded_on_gpu_with_virtual_ranks(oracle, monkeypatch, world, paired, with_hash):
+    monkeypatch.setenv("FQD_SHARDED_WITH_HASH", with_hash)      # keys alone on the wire (default) / [hash | key] records
     from fastq_dupaway_amd import Engine, Reads
     from fastq_dupaway_amd.sharded import HipOps
     n_per, steps, LL = 20000, 2, 150
@@ -301,16 +303,26 @@ def test_partition_is_stable_and_complete():
     assert np.array_equal(counts.cpu().numpy(), np.bincount(owner, minlength=parts))
     assert np.array_equal(origin.cpu().numpy(), order.astype(np.int32))
     assert np.array_equal(o, r[order])
+    with Engine(segments=1) as e:                            # the same partition with the hash word left out of the rows
+        keys = torch.empty(n * W, dtype=torch.int64, device=dev)
+        e.partition_keys(rec, n, W, parts, keys, counts, origin)
+        e.sync()
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(owner, minlength=parts))
+    assert np.array_equal(origin.cpu().numpy(), order.astype(np.int32))
+    assert np.array_equal(keys.cpu().numpy().view(np.uint64).reshape(n, W), r[order][:, 1:])
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("in_place", [False, True])
 @pytest.mark.parametrize("bulk_min", ["0", "-1", None])
-def test_insert_records_over_several_rounds(oracle, monkeypatch, in_place, bulk_min):
-    """The owner-side half on its own: records arrive round after round (copied in, or received
-    in place at the tail of the key store) and first-occurrence-wins holds across rounds."""
+@pytest.mark.parametrize("with_hash", ["0", "1"])
+def test_insert_records_over_several_rounds(oracle, monkeypatch, in_place, bulk_min, with_hash):
+    """The owner-side half on its own: records ([hash | key], or keys alone) arrive round after
+    round (copied in, or received in place at the tail of the key store) and
+    first-occurrence-wins holds across rounds."""
     from fastq_dupaway_amd import Engine, Reads
     from fastq_dupaway_amd.sharded import HipOps
+    monkeypatch.setenv("FQD_SHARDED_WITH_HASH", with_hash)
     if bulk_min is not None:
         monkeypatch.setenv("FQD_BULK_MIN", bulk_min)
     n_per, rounds, LL = 1_200_000, 3, 150
@@ -318,6 +330,8 @@ def test_insert_records_over_several_rounds(oracle, monkeypatch, in_place, bulk_
     with Engine(segments=1) as e:
         ops = HipOps(e)
         W = e.key_words(LL); rw = W + 1
+        xw = ops.exchange_words(LL, 0)
+        assert xw == (rw if with_hash == "1" else W)
         bases = torch.empty(rounds * n_per * LL + 16, dtype=torch.uint8, device=dev)
         expect = torch.empty(rounds * n_per, dtype=torch.uint8, device=dev)
         e.synth_reads(77, 0, rounds * n_per, LL, 250, 0, bases, expect)
@@ -327,13 +341,14 @@ def test_insert_records_over_several_rounds(oracle, monkeypatch, in_place, bulk_
             seg = [Reads(bases[k * n_per * LL:], uniform_len=LL, uniform_stride=LL)]
             e.encode_uniform(seg, n_per, staging)
             e.sync()
+            wire = staging if with_hash == "1" else staging.view(n_per, rw)[:, 1:].contiguous().view(-1)
             if in_place:
                 buf = ops.recv_buffer(n_per, LL, 0, dev)
-                buf[: n_per * rw].copy_(staging)             # stands in for the all-to-all writing the records
+                buf[: n_per * xw].copy_(wire)                # stands in for the all-to-all writing the records
                 torch.cuda.synchronize()
             else:
-                buf = staging
-            e.insert_records(buf, n_per, LL, 0, keep[k * n_per:])
+                buf = wire
+            ops.insert(buf, n_per, LL, 0, keep[k * n_per:])
             e.sync()
         assert torch.equal(keep, expect)
         assert e.stats()["duplicates"] == int((expect == 0).sum().item())

@@ -3,9 +3,14 @@
 
 A step = one pass of the hot path over one batch of synthetic 150-bp reads already
 resident in HBM: empty the set, encode + insert every read, produce keep flags.
-  N = 1 : BASELINE.json configs[1] — 100 M single-end 150 bp reads, ~20 % duplicates.
+  N = 1 : BASELINE.json configs[1] — 100 M single-end 150 bp reads, ~20 % duplicates (the headline),
+          and beside it in the same JSON line: configs[2] (100 M pairs 2x150 bp, `pe`), the
+          PCIe-inclusive rate (`pcie_inclusive`: sequences start in pinned host memory) and the
+          end-to-end rate of the CLI, FASTQ file in -> FASTQ file out (`end_to_end`).
   N > 1 : weak scaling, the same per-GPU batch on every rank; reads are sharded by hash
           prefix with an all-to-all over RCCL (fastq-dupaway_amd/sharded.py).
+  --config se|pe|sharded1 : only that device-phase measurement (sharded1 = the N > 1 path
+          rehearsed on one rank under RCCL).
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under
 python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 Prints ONE JSON line on rank 0.
@@ -13,7 +18,10 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -21,6 +29,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0        # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s measured copy ceiling
+HBM_COPY_GBS = 6290.0
 
 
 def parse():
@@ -28,12 +37,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=["all", "se", "pe", "sharded1"], default="all",
+                    help="all (default, N=1): headline configs[1] + pe + pcie_inclusive + end_to_end")
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads (pairs) per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--paired", action="store_true", help="configs[2]: 2x150 bp pair-hash")
+    ap.add_argument("--paired", action="store_true", help="same as --config pe")
     ap.add_argument("--dup-permille", type=int, default=200)
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="reads timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--pe-cpu-sample", type=int, default=2_000_000, help="pairs of the pe run checked against the CPU oracle")
+    ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads of the end-to-end CLI run (0 = skip)")
+    ap.add_argument("--e2e-dir", default="", help="where the end-to-end FASTQ files go (default: a temp dir under /tmp)")
     ap.add_argument("--no-verify", action="store_true")
     return ap.parse_args()
 
@@ -56,45 +70,37 @@ def cpu_baseline(bases, n_sample, L, paired, bases2):
         keep = oracle.dedup_single(host, offs, lens)
     dt = time.perf_counter() - t0
     return {"value": round(n_sample / dt / 1e6, 4), "unit": "Mpairs/s" if paired else "Mreads/s", "cores": 1, "kind": "port",
-            "sample": f"first {n_sample} reads of the same synthetic workload, in-memory arrays "
+            "sample": f"first {n_sample} {'pairs' if paired else 'reads'} of the same synthetic workload, in-memory arrays "
                       f"(no file parsing or output), {dt:.1f} s; host has {os.cpu_count()} cores, the reference "
                       f"path is single-threaded"}, keep
 
 
-def main():
-    a = parse()
-    import torch
-    import fastq_dupaway_amd as fqd
+def committed_traffic():
+    """HBM bytes per launch from the newest committed PMC summary (two separate rocprofv3 --pmc passes of
+    `python bench.py --config se`, corrected per MI355X_MICROARCH.md §HBM by tools/summarize_pmc.py).
+    NOT measured in this run: the line names the file it comes from."""
+    pmc = sorted((ROOT / "profiles").glob("*_pmc_summary.json"))
+    if not pmc:
+        return None, None
+    return json.loads(pmc[-1].read_text())["kernels"], f"profiles/{pmc[-1].name}"
+
+
+def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, cpu_sample):
+    """Times exactly a.steps steps of the hot path on device-resident input.  Returns the result
+    dict (rank 0) plus the tensors the follow-up measurements reuse."""
     from fastq_dupaway_amd import Engine, Reads
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(local)
-    dist = None
-    force_sharded = os.environ.get("FQD_BENCH_FORCE_SHARDED") == "1"      # rehearse the N>1 path on one GPU
-    if world > 1 or force_sharded:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-
-    n, L, S = a.reads, a.read_len, (2 if a.paired else 1)
-    dev = torch.device("cuda", local)
+    n, L, S = a.reads, a.read_len, (2 if paired else 1)
     bases = [torch.empty(n * L + 16, dtype=torch.uint8, device=dev) for _ in range(S)]
     expect = torch.empty(n, dtype=torch.uint8, device=dev)
     keep = torch.empty(n, dtype=torch.uint8, device=dev)
 
     eng = Engine(segments=S, device=local, capacity_reads=n, capacity_bases=S * n * L, profile=True)
-    sharded_mode = dist is not None
-    # Sharded runs move a step's reads in rounds sized so that no rank-to-rank message of the
-    # all-to-all exceeds 256 MiB (64-byte keys for 150 bp): 3 rounds per step on 8 GPUs, enough for
-    # the round pipeline to hide most of the exchange.  Measured on this image (RCCL 2.26.6, torch
-    # 2.10): a single all_to_all_single message above 1 GiB arrives corrupted.  The
-    # job's input order is (round, rank, position) — file blocks dealt round-robin to the ranks —
-    # so round k of rank r holds the global indices below.
-    rec_bytes = 8 * (eng.key_words(L, L if S == 2 else 0) + (1 if os.environ.get("FQD_SHARDED_WITH_HASH") == "1" else 0))   # keys travel without their hash
+    # Sharded runs move a step's reads in rounds; ShardedDedup itself slices every exchange so that no
+    # rank-to-rank message exceeds its cap (RCCL 2.26.6 / torch 2.10 deliver only the first half of a
+    # message above 1 GiB: tools/a2a_probe.py, profiles/r02_a2a_probe.jsonl), the rounds here only give
+    # the pipeline something to overlap.  The job's input order is (round, rank, position) — file blocks
+    # dealt round-robin to the ranks — so round k of rank r holds the global indices below.
+    rec_bytes = 8 * (eng.key_words(L, L if S == 2 else 0) + (1 if os.environ.get("FQD_SHARDED_WITH_HASH") == "1" else 0))
     lazy = sharded_mode and os.environ.get("FQD_SHARDED_LAZY") == "1"       # hashes first, keys only for candidates
     if lazy:
         rec_bytes = 16
@@ -111,6 +117,7 @@ def main():
     eng.sync()
     segs = [Reads(bases[mate], uniform_len=L, uniform_stride=L) for mate in range(S)]
 
+    sharded = None
     if lazy:
         from fastq_dupaway_amd.sharded import LazyShardedDedup
         owner = Engine(segments=1, device=local, capacity_reads=int(n * 1.1))
@@ -124,7 +131,6 @@ def main():
     elif sharded_mode:
         from fastq_dupaway_amd.sharded import HipOps, ShardedDedup
         sharded = ShardedDedup(HipOps(eng), dist, dev, n_max=m, len0=L, len1=(L if S == 2 else 0))
-
         round_list = [([Reads(bases[mate][lo * L:], uniform_len=L, uniform_stride=L) for mate in range(S)], cnt, keep[lo:])
                       for lo, cnt in spans]
 
@@ -170,55 +176,193 @@ def main():
     if lazy and rank == 0 and sharded.timing is not None:
         print({k: round(v / a.steps, 3) for k, v in sharded.timing.items()}, file=sys.stderr)
 
+    res = None
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         value = world * n * a.steps / dt / 1e6
         bytes_per_unit = S * L                       # sequence bytes read once from HBM
-        kernels = {}
-        names = {"encode": "fqd::encode_staged_kernel", "insert": "fqd::insert_kernel",
+        names = {"encode": "fqd::encode_staged_pe_kernel" if paired else "fqd::encode_staged_kernel", "insert": "fqd::insert_kernel",
                  "partition": "fqd::bulk_hist/scatter passes (4 kernels, timed as one group)", "dedup": "fqd::bucket_dedup_kernel"}
+        kernels = {}
         for k in ("encode", "insert", "partition", "dedup"):
             if prof[f"{k}_launches"]:
                 avg_ms = prof[f"{k}_ms"] / prof[f"{k}_launches"]
-                per_launch = prof[f"{k}_reads"] / prof[f"{k}_launches"]
-                kernels[k] = {"avg_ms": round(avg_ms, 4), "launches": prof[f"{k}_launches"],
-                              "GBps": round(per_launch * bytes_per_unit / (avg_ms * 1e-3) / 1e9, 1)}
+                kernels[k] = {"name": names[k], "avg_ms": round(avg_ms, 4), "launches": prof[f"{k}_launches"]}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes (two separate
-        # rocprofv3 --pmc runs of this same command, corrected per MI355X_MICROARCH.md §HBM:
-        # tools/summarize_pmc.py).  Only valid for the workload those passes were taken on.
-        traffic = None
-        pmc = sorted((ROOT / "profiles").glob("*_pmc_summary.json"))
-        if pmc and world == 1 and n == 100_000_000 and L == 150 and not a.paired:
-            for name, rec in json.loads(pmc[-1].read_text())["kernels"].items():
-                if name.split("<")[0] == names[dom].split("<")[0].split(" ")[0]:
-                    traffic = rec["hbm_traffic"]
-        roofline = {"bound": "hbm", "kernel": names[dom], "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_unit": bytes_per_unit, "kernels": kernels,
-                    "whole_step_frac": round(value * 1e6 / world * bytes_per_unit / 1e9 / HBM_PEAK_GBS, 4)}
-        out = {"metric": "Mreads/s dedup, 150 bp %s FASTQ" % ("PE" if a.paired else "SE"),
-               "value": round(value, 2), "unit": "Mreads/s" if not a.paired else "Mpairs/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
-               "data": "synthetic",
-               "config": {"workload": ("100M paired-end 2x150 bp, --fast pair-hash" if a.paired and n == 100_000_000 else
+        per_launch = prof[f"{dom}_reads"] / prof[f"{dom}_launches"]
+        dom_gbps = per_launch * bytes_per_unit / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        step_gbps = value * 1e6 / world * bytes_per_unit / 1e9
+        traffic, source = None, None
+        if world == 1 and not sharded_mode and n == 100_000_000 and L == 150 and not paired:
+            per_kernel, source = committed_traffic()
+            if per_kernel:
+                for name, rec in per_kernel.items():
+                    for k in kernels:
+                        if name.split("<")[0] == names[k].split("<")[0].split(" ")[0]:
+                            kernels[k]["hbm_bytes_from_committed_profile"] = rec["hbm_traffic"]
+                traffic = kernels[dom].get("hbm_bytes_from_committed_profile")
+        # SURVEY §8(d) defines the contract figure over the whole device phase: reads/s x 150 B / 8 TB/s.
+        # That is `frac`; the dominant kernel's own figure stands beside it.
+        roofline = {"bound": "hbm", "achieved": round(step_gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(step_gbps / HBM_PEAK_GBS, 4),
+                    "frac_of_measured_copy_ceiling": round(step_gbps / HBM_COPY_GBS, 4),
+                    "scope": "whole device phase (all kernels of a step): algorithmic bytes / step time",
+                    "traffic": traffic, "traffic_source": (source + " (committed rocprofv3 --pmc passes of this command; not measured in this run)") if traffic else None,
+                    "algorithmic_bytes_per_unit": bytes_per_unit,
+                    "dominant_kernel": {"name": names[dom], "avg_ms": kernels[dom]["avg_ms"], "achieved": round(dom_gbps, 1),
+                                        "frac": round(dom_gbps / HBM_PEAK_GBS, 4),
+                                        "note": "algorithmic bytes per launch / average launch duration (HIP events on the engine's stream)"},
+                    "kernels": kernels}
+        what = "pairs" if paired else "reads"
+        res = {"value": round(value, 2), "unit": "Mpairs/s" if paired else "Mreads/s", "ms_per_step": round(ms_step, 3),
+               "config": {"workload": ("100M paired-end 2x150 bp, --fast pair-hash" if paired and n == 100_000_000 else
                                        "100M single-end 150 bp FASTQ (~20% dups), --fast" if n == 100_000_000 else
-                                       f"{n} {'pairs' if a.paired else 'reads'} x {L} bp per GPU"),
+                                       f"{n} {what} x {L} bp per GPU"),
+                          "input": "150-byte sequence lines extracted from the FASTQ records, resident in HBM when the timed region starts",
                           "reads_per_gpu": n, "read_len": L, "dup_fraction": a.dup_permille / 1000.0,
                           "sharding": "none" if not sharded_mode else f"hash-prefix all-to-all over {world} GPU(s), {rounds} round(s) per step"
                                       + (", hashes first / keys for candidates only" if lazy else "")},
                "parity": parity, "roofline": roofline}
-        if world == 1 and a.cpu_sample > 0:
-            m = min(a.cpu_sample, n)
-            cb, cpu_keep = cpu_baseline(bases[0], m, L, a.paired, bases[1] if S == 2 else None)
+        if world == 1 and cpu_sample > 0:
+            ms = min(cpu_sample, n)
+            cb, cpu_keep = cpu_baseline(bases[0], ms, L, paired, bases[1] if S == 2 else None)
             import numpy as np
-            if not np.array_equal(cpu_keep, keep[:m].cpu().numpy()):
+            if not np.array_equal(cpu_keep, keep[:ms].cpu().numpy()):
                 sys.exit("GPU keep flags differ from the CPU oracle on the baseline sample — result invalid")
-            out["cpu_baseline"] = cb
-            out["parity"] += f"; == CPU oracle on the first {m}"
+            res["cpu_baseline"] = cb
+            res["parity"] += f"; == CPU oracle on the first {ms}"
+    return res, eng, bases, expect, keep
+
+
+def pcie_inclusive(torch, eng, bases, expect, keep, n, L, reps=2):
+    """Sequences start in PINNED HOST memory, are copied to HBM in chunks and deduplicated; flags come
+    back to the host.  Never the bench `value`."""
+    from fastq_dupaway_amd import Reads
+    h_bases = torch.empty(n * L, dtype=torch.uint8).pin_memory()
+    h_bases.copy_(bases[: n * L]); torch.cuda.synchronize()
+    h_keep = torch.empty(n, dtype=torch.uint8).pin_memory()
+    chunks = 8
+    m = n // chunks
+    best = None
+    for _ in range(reps):
+        eng.reset(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(chunks):
+            cnt = m if k + 1 < chunks else n - k * m
+            bases[k * m * L:(k * m + cnt) * L].copy_(h_bases[k * m * L:(k * m + cnt) * L], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            eng.submit([Reads(bases[k * m * L:], uniform_len=L, uniform_stride=L)], cnt, keep=keep[k * m:])
+        eng.sync()
+        h_keep.copy_(keep, non_blocking=True); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    ok = bool(torch.equal(keep, expect))
+    del h_bases
+    return {"value": round(n / best / 1e6, 1), "unit": "Mreads/s", "sequence_GBps_over_pcie": round(n * L / best / 1e9, 1),
+            "what": f"{n} reads: 150-byte sequences in pinned host memory -> {chunks} hipMemcpyAsync chunks -> dedup -> flags back to the host; best of {reps}",
+            "parity": "keep flags == closed form" if ok else "MISMATCH"}
+
+
+def end_to_end(a, torch, bases, expect, L):
+    """The CLI, FASTQ file in -> FASTQ file out, on the first --e2e-reads reads of the same workload."""
+    import numpy as np
+    from fastq_dupaway_amd import _lib
+    n = min(a.e2e_reads, a.reads)
+    seqs = bases[: n * L].cpu().numpy().reshape(n, L)
+    exp_keep = expect[:n].cpu().numpy()
+    d = Path(a.e2e_dir) if a.e2e_dir else Path(tempfile.mkdtemp(prefix="fqd_e2e_", dir="/tmp"))
+    d.mkdir(parents=True, exist_ok=True)
+    src, dst = d / "in.fq", d / "out.fq"
+    rec_len = 12 + L + 1 + 2 + L + 1                         # "@r%09d\n" + seq\n + "+\n" + qual\n = 316 B at 150 bp
+    with open(src, "wb") as f:
+        step = 1_000_000
+        for lo in range(0, n, step):
+            cnt = min(step, n - lo)
+            rec = np.empty((cnt, rec_len), dtype=np.uint8)
+            rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+            idx = np.arange(lo, lo + cnt, dtype=np.int64)
+            for p in range(9):
+                rec[:, 10 - p] = 48 + (idx % 10); idx //= 10
+            rec[:, 11] = 10
+            rec[:, 12:12 + L] = seqs[lo:lo + cnt]
+            rec[:, 12 + L] = 10; rec[:, 13 + L] = ord("+"); rec[:, 14 + L] = 10
+            rec[:, 15 + L:15 + 2 * L] = ord("I"); rec[:, 15 + 2 * L] = 10
+            f.write(rec.tobytes())
+    size_in = src.stat().st_size
+    runs = []
+    out = None
+    for _ in range(2):
+        dst.unlink(missing_ok=True)
+        t0 = time.perf_counter()
+        r = subprocess.run([str(_lib.CLI_PATH), "-i", str(src), "-o", str(dst), "--fast", "-v"], capture_output=True, text=True)
+        runs.append(time.perf_counter() - t0)
+        out = r
+        if r.returncode != 0:
+            break
+    dups = int((exp_keep == 0).sum())
+    expected_line = f"{n} reads processed, out of which {dups} duplicates were removed.\n"
+    ok = out.returncode == 0 and out.stdout == expected_line and dst.stat().st_size == (n - dups) * rec_len
+    res = {"value": round(n / min(runs) / 1e6, 2), "unit": "Mreads/s", "seconds": [round(t, 3) for t in runs],
+           "input_GBps": round(size_in / min(runs) / 1e9, 2),
+           "what": f"fastq-dupaway -i in.fq -o out.fq --fast -v on {n} reads ({size_in / 1e9:.2f} GB FASTQ, 316 B/record), plain files on {d}, "
+                   f"page cache warm (the input was just written), process start-up and output close included; best of 2 runs",
+           "parity": "-v line and output size == closed form" if ok else f"MISMATCH rc={out.returncode} {out.stdout!r} {out.stderr[-300:]!r}"}
+    if not a.e2e_dir:
+        shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
+def main():
+    a = parse()
+    import torch
+    import fastq_dupaway_amd as fqd  # noqa: F401  (loads the HIP library or fails loudly)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    dist = None
+    config = "pe" if a.paired else a.config
+    force_sharded = os.environ.get("FQD_BENCH_FORCE_SHARDED") == "1" or config == "sharded1"   # rehearse the N>1 path on one GPU
+    if world > 1 or force_sharded:
+        import torch.distributed as dist
+        if force_sharded and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    sharded_mode = dist is not None
+    dev = torch.device("cuda", local)
+    L = a.read_len
+
+    headline_paired = config == "pe"
+    res, eng, bases, expect, keep = device_phase(a, torch, dist, dev, local, rank, world, headline_paired, sharded_mode, a.cpu_sample)
+    out = None
+    if rank == 0:
+        out = {"metric": "Mreads/s dedup, 150 bp %s FASTQ (device phase: sequences resident in HBM)" % ("PE" if headline_paired else "SE"),
+               "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "u8", "data": "synthetic", "config": res["config"], "parity": res["parity"], "roofline": res["roofline"]}
+        if "cpu_baseline" in res:
+            out["cpu_baseline"] = res["cpu_baseline"]
+    if config == "all" and world == 1 and not sharded_mode:
+        out["pcie_inclusive"] = pcie_inclusive(torch, eng, bases[0], expect, keep, a.reads, L)
+        if a.e2e_reads > 0:
+            out["end_to_end"] = end_to_end(a, torch, bases[0], expect, L)
+        eng.close()
+        del bases, expect, keep
+        torch.cuda.empty_cache()
+        # configs[2] beside the headline: 100 M pairs, same step definition, oracle-checked on a sample
+        pe, eng2, b2, e2, k2 = device_phase(a, torch, None, dev, local, rank, world, True, False, a.pe_cpu_sample)
+        out["pe"] = {k: pe[k] for k in ("value", "unit", "ms_per_step", "config", "parity", "cpu_baseline") if k in pe}
+        out["pe"]["roofline"] = {k: pe["roofline"][k] for k in ("achieved", "frac", "algorithmic_bytes_per_unit", "dominant_kernel", "kernels")}
+        eng2.close()
+    else:
+        eng.close()
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -36,6 +36,11 @@ class TagsDesc(C.Structure):
     _fields_ = [("bytes", C.c_void_p), ("offsets", C.c_void_p), ("lengths", C.c_void_p), ("n", C.c_uint64)]
 
 
+class JoinDesc(C.Structure):
+    _fields_ = [("perm_a", C.c_void_p), ("perm_b", C.c_void_p), ("match_a", C.c_void_p), ("match_b", C.c_void_p),
+                ("pair_a", C.c_void_p), ("pair_b", C.c_void_p), ("n_pairs", C.POINTER(C.c_uint64))]
+
+
 class Stats(C.Structure):
     _fields_ = [("records", C.c_uint64), ("duplicates", C.c_uint64), ("table_slots", C.c_uint64), ("key_bytes", C.c_uint64)]
 
@@ -101,7 +106,9 @@ def load_library():
     L.fqd_insert_records.argtypes = [vp, vp, u64, u32, u32, vp]
     L.fqd_reserve_records.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
     L.fqd_sort_tags.argtypes = [vp, C.POINTER(TagsDesc), vp]
-    L.fqd_match_sorted_tags.argtypes = [vp, C.POINTER(TagsDesc), vp, C.POINTER(TagsDesc), vp, vp]
+    L.fqd_extract_tags.argtypes = [vp, vp, vp, vp, u64, vp, vp]
+    L.fqd_join_tags.argtypes = [vp, C.POINTER(TagsDesc), C.POINTER(TagsDesc), C.POINTER(JoinDesc)]
+    L.fqd_gather_seqs.argtypes = [vp, vp, u64, vp, vp, vp, vp]
     L.fqd_scatter_flags.argtypes = [vp, vp, vp, u64, vp]
     L.fqd_partition_keys.argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
     L.fqd_reserve_keys.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]

@@ -518,8 +518,14 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
         return FQD_OK;
     };
     int drc;
-    if (fresh) drc = ks.koff ? launch_dedup(bucket_dedup_kernel<true, true>) : launch_dedup(bucket_dedup_kernel<true, false>);
-    else       drc = ks.koff ? launch_dedup(bucket_dedup_kernel<false, true>) : launch_dedup(bucket_dedup_kernel<false, false>);
+    // verify width: 16 bytes per lane when the uniform keys are whole 16-byte units (FQD_DEDUP_VL=0: the 8-byte form)
+    int vl = 0;
+    if (!ks.koff && ks.lead == 0 && ks.stride == ks.W0 && (ks.W0 & 1u) == 0) vl = ks.W0 <= 8 ? 4 : (ks.W0 <= 16 ? 8 : 0);
+    if (const char* v = std::getenv("FQD_DEDUP_VL")) { if (std::atoi(v) == 0) vl = 0; }
+    if (ks.koff)      drc = fresh ? launch_dedup(bucket_dedup_kernel<true, true, 0>) : launch_dedup(bucket_dedup_kernel<false, true, 0>);
+    else if (vl == 4) drc = fresh ? launch_dedup(bucket_dedup_kernel<true, false, 4>) : launch_dedup(bucket_dedup_kernel<false, false, 4>);
+    else if (vl == 8) drc = fresh ? launch_dedup(bucket_dedup_kernel<true, false, 8>) : launch_dedup(bucket_dedup_kernel<false, false, 8>);
+    else              drc = fresh ? launch_dedup(bucket_dedup_kernel<true, false, 0>) : launch_dedup(bucket_dedup_kernel<false, false, 0>);
     if (drc) return drc;
     hipLaunchKernelGGL(heavy_bucket_insert_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
                        final_recs, bstart, g, e->table.as<uint64_t>(), ks, verdicts, counters,

@@ -787,11 +787,18 @@ void bulk_scan_buckets_kernel(const uint32_t* __restrict__ count, uint32_t bits2
 // LDS: segment (2^seg_bits * 8 B) + kDedupChunk queue entries of 8 B + 2 counters.
 // RAGGED = the key store is ragged (ks.koff): compiled apart so that neither verify variant pays
 // for the other's registers.
-constexpr uint32_t kDedupChunk = 1536;
+constexpr uint32_t kDedupChunk = 1536;                   // queue entries (candidates from the front, retries from the back)
+constexpr uint32_t kDedupRecords = 3 * kDedupChunk;      // records per chunk: a segment's whole bucket, normally; a candidate that
+                                                         // finds the queue full is verified on the spot
 constexpr uint32_t kDedupFly = 4;
-constexpr uint32_t kDedupLoads = 3;                      // records a lane fetches at once in the probe phase (chunk / 512 lanes)
+constexpr uint32_t kDedupLoads = 3;                      // records a lane fetches at once in the probe phase
 
-template <bool FRESH, bool RAGGED>
+// VL: lanes per candidate in the verify phase of uniform key stores.  VL = 4 / 8: every lane
+// loads 16 bytes of each of the two keys (keys of up to 8 / 16 words with an even word count: 150 bp
+// single-end = 8 words = 4 lanes, 2 x 150 bp = 16 words = 8 lanes), so a 512-thread workgroup has
+// 128 / 64 groups of kFly candidates in flight; VL = 0: eight lanes, one or two 8-byte words each
+// (any length; ragged stores always).
+template <bool FRESH, bool RAGGED, int VL>
 __global__ __launch_bounds__(1024)
 void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ bstart, uint32_t n_buckets,
                          uint64_t* __restrict__ table, uint32_t seg_bits, uint32_t qshift, KeyStore ks, Verdicts out,
@@ -814,8 +821,9 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
             if (old == kEmptySlot) return;
             if ((old >> 32) == tag) {
                 if (!verify_inline) {
-                    queue[atomicAdd(&qn[0], 1u)] = (uint64_t((tag32 << seg_bits) | pos) << 32) | idx;
-                    return;
+                    const uint32_t at = atomicAdd(&qn[0], 1u);
+                    if (at < kDedupChunk) { queue[at] = (uint64_t((tag32 << seg_bits) | pos) << 32) | idx; return; }
+                    // queue full (a bucket with far more duplicates than expected): settle this one right here
                 }
                 if (keys_equal(ks, idx, uint32_t(old))) {
                     uint32_t owner = uint32_t(old);
@@ -859,8 +867,8 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
                 }
             }
         }
-        for (uint32_t chunk_lo = lo; chunk_lo < hi; chunk_lo += kDedupChunk) {
-            const uint32_t chunk_n = hi - chunk_lo < kDedupChunk ? hi - chunk_lo : kDedupChunk;
+        for (uint32_t chunk_lo = lo; chunk_lo < hi; chunk_lo += kDedupRecords) {
+            const uint32_t chunk_n = hi - chunk_lo < kDedupRecords ? hi - chunk_lo : kDedupRecords;
             if (threadIdx.x == 0) { qn[0] = 0; qn[1] = 0; }
             __syncthreads();
             // 1. probe (a lane's records are all fetched before the first walk: one round trip, not several)
@@ -877,10 +885,11 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
                 }
             }
             __syncthreads();
-            // 2. verify, eight lanes per candidate, kDedupFly candidates per group in flight
-            const uint32_t n_cand = qn[0];
-            constexpr uint32_t kFly = RAGGED ? 3u : kDedupFly;     // ragged keys need more registers per candidate
-            const uint32_t grp = threadIdx.x >> 3, n_grp = blockDim.x >> 3, sub = threadIdx.x & 7u;
+            // 2. verify: VL (or eight) lanes per candidate, kFly candidates per group in flight
+            const uint32_t n_cand = qn[0] < kDedupChunk ? qn[0] : kDedupChunk;
+            constexpr uint32_t kFly = RAGGED ? 3u : (VL == 4 ? 6u : kDedupFly);     // ragged keys need more registers per candidate
+            constexpr uint32_t kLanes = VL ? uint32_t(VL) : 8u;
+            const uint32_t grp = threadIdx.x / kLanes, n_grp = blockDim.x / kLanes, sub = threadIdx.x % kLanes;
             for (uint32_t q0 = grp; q0 < n_cand; q0 += n_grp * kFly) {
                 uint32_t pos[kFly], idx[kFly], seen[kFly], tag[kFly];
                 uint64_t diff[kFly];
@@ -897,7 +906,15 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
                         idx[u] = uint32_t(ent); pos[u] = uint32_t(ent >> 32) & seg_mask; tag[u] = uint32_t(ent >> 32) >> seg_bits;
                         seen[u] = uint32_t(seg[pos[u]]);      // the slot's owner right now: same key class for good
                     }
-                    if (!RAGGED) {
+                    if (!RAGGED && VL) {
+                        // 16 bytes of each key per lane: the whole key pair of a candidate is one request per lane
+                        const ulonglong2* __restrict__ pa = reinterpret_cast<const ulonglong2*>(ks.keys + idx[u] * uint64_t(ks.stride));
+                        const ulonglong2* __restrict__ pb = reinterpret_cast<const ulonglong2*>(ks.keys + seen[u] * uint64_t(ks.stride));
+                        if (live[u] && 2u * sub < ks.W0) {
+                            const ulonglong2 x = pa[sub], y = pb[sub];
+                            wa[u][0] = x.x; wa[u][1] = x.y; wb[u][0] = y.x; wb[u][1] = y.y;
+                        }
+                    } else if (!RAGGED) {
                         // uniform keys: addresses are arithmetic, so the (up to) two words a lane owns of
                         // each key are requested here and only looked at after the whole batch is in flight
                         const uint64_t* __restrict__ pa = ks.keys + idx[u] * uint64_t(ks.stride) + ks.lead;
@@ -946,7 +963,7 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
                     for (uint32_t u = 0; u < kFly; ++u) {
                         if (!live[u]) continue;
                         diff[u] = (wa[u][0] ^ wb[u][0]) | (wa[u][1] ^ wb[u][1]);
-                        if (ks.W0 > 16u) {                    // longer keys: the remaining words, the plain way
+                        if (!VL && ks.W0 > 16u) {             // longer keys: the remaining words, the plain way
                             const uint64_t* __restrict__ pa = ks.keys + idx[u] * uint64_t(ks.stride) + ks.lead;
                             const uint64_t* __restrict__ pb = ks.keys + seen[u] * uint64_t(ks.stride) + ks.lead;
                             for (uint32_t w = sub + 16u; w < ks.W0; w += 8u) diff[u] |= pa[w] ^ pb[w];
@@ -956,7 +973,8 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
 #pragma unroll
                 for (uint32_t u = 0; u < kFly; ++u) {
                     uint64_t d = diff[u];
-                    d |= __shfl_xor(d, 1, 64); d |= __shfl_xor(d, 2, 64); d |= __shfl_xor(d, 4, 64);
+                    d |= __shfl_xor(d, 1, 64); d |= __shfl_xor(d, 2, 64);
+                    if (kLanes == 8u) d |= __shfl_xor(d, 4, 64);
                     if (live[u] && sub == 0u) {
                         if (d == 0) {
                             const unsigned long long mine = (uint64_t(tag[u]) << 32) | idx[u];
@@ -968,8 +986,8 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
                         } else {
                             const uint32_t next = (pos[u] + 1u) & seg_mask;
                             const uint32_t at = kDedupChunk - 1u - atomicAdd(&qn[1], 1u);
-                            if (at >= n_cand) queue[at] = (uint64_t((tag[u] << seg_bits) | next) << 32) | idx[u];
-                            else              walk(idx[u], tag[u], next, true);      // queue full: settle it now
+                            if (at >= n_cand && at < kDedupChunk) queue[at] = (uint64_t((tag[u] << seg_bits) | next) << 32) | idx[u];
+                            else                                   walk(idx[u], tag[u], next, true);      // queue full: settle it now
                         }
                     }
                 }

@@ -218,9 +218,20 @@ class Engine:
         t = self._tags(bytes_, offsets, lengths, n)
         self._check(self._L.fqd_sort_tags(self._h, C.byref(t), _addr(perm)))
 
-    def match_sorted_tags(self, a, perm_a, b, perm_b, match):
+    def extract_tags(self, text, id_start, id_len, n: int, tag_off, tag_len):
+        self._check(self._L.fqd_extract_tags(self._h, _addr(text), _addr(id_start), _addr(id_len), n, _addr(tag_off), _addr(tag_len)))
+
+    def join_tags(self, a, b, perm_a, perm_b, match_a, match_b, pair_a, pair_b) -> int:
+        """a, b = (bytes, offsets, lengths, n); returns the number of pairs (the call drains the stream)."""
         ta, tb = self._tags(*a), self._tags(*b)
-        self._check(self._L.fqd_match_sorted_tags(self._h, C.byref(ta), _addr(perm_a), C.byref(tb), _addr(perm_b), _addr(match)))
+        n_pairs = C.c_uint64(0)
+        out = _lib.JoinDesc(perm_a=_addr(perm_a), perm_b=_addr(perm_b), match_a=_addr(match_a), match_b=_addr(match_b),
+                            pair_a=_addr(pair_a), pair_b=_addr(pair_b), n_pairs=C.pointer(n_pairs))
+        self._check(self._L.fqd_join_tags(self._h, C.byref(ta), C.byref(tb), C.byref(out)))
+        return int(n_pairs.value)
+
+    def gather_seqs(self, idx, n: int, off_table, len_table, off_out, len_out):
+        self._check(self._L.fqd_gather_seqs(self._h, _addr(idx), n, _addr(off_table), _addr(len_table), _addr(off_out), _addr(len_out)))
 
     def scatter_flags(self, flags, origin, n: int, keep_out):
         self._check(self._L.fqd_scatter_flags(self._h, _addr(flags), _addr(origin), n, _addr(keep_out)))

@@ -402,65 +402,29 @@ void HashDupRemover::filterPE(const std::string& infile1, const std::string& inf
 
 namespace {
 
-// Uploads a file's tags once (bytes back to back + offset/length per record) and runs the
-// device primitives of the join.
-class GpuTagJoin : public TagJoinDevice {
-public:
-    GpuTagJoin(fqd_engine* e, hipStream_t s) : e_(e), s_(s) {}
-    void sort(const LoadedFile& f, std::vector<uint32_t>& perm) override
-    {
-        Uploaded& u = upload(f);
-        Device<uint32_t> d_perm; d_perm.reserve(u.n);
-        fqd_tags t{reinterpret_cast<const uint8_t*>(u.bytes.p), u.off.p, u.len.p, u.n};
-        if (fqd_sort_tags(e_, &t, d_perm.p) != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(e_));
-        perm.resize(u.n);
-        HIP_OK(hipMemcpyAsync(perm.data(), d_perm.p, u.n * sizeof(uint32_t), hipMemcpyDeviceToHost, s_));
-        HIP_OK(hipStreamSynchronize(s_));
-    }
-    void match(const LoadedFile& a, const std::vector<uint32_t>& perm_a,
-               const LoadedFile& b, const std::vector<uint32_t>& perm_b, std::vector<uint32_t>& out) override
-    {
-        Uploaded& ua = upload(a); Uploaded& ub = upload(b);
-        Device<uint32_t> pa, pb, m; pa.reserve(ua.n); pb.reserve(ub.n); m.reserve(ua.n);
-        HIP_OK(hipMemcpyAsync(pa.p, perm_a.data(), ua.n * sizeof(uint32_t), hipMemcpyHostToDevice, s_));
-        HIP_OK(hipMemcpyAsync(pb.p, perm_b.data(), ub.n * sizeof(uint32_t), hipMemcpyHostToDevice, s_));
-        fqd_tags ta{reinterpret_cast<const uint8_t*>(ua.bytes.p), ua.off.p, ua.len.p, ua.n};
-        fqd_tags tb{reinterpret_cast<const uint8_t*>(ub.bytes.p), ub.off.p, ub.len.p, ub.n};
-        if (fqd_match_sorted_tags(e_, &ta, pa.p, &tb, pb.p, m.p) != FQD_OK)
-            throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(e_));
-        out.resize(ua.n);
-        HIP_OK(hipMemcpyAsync(out.data(), m.p, ua.n * sizeof(uint32_t), hipMemcpyDeviceToHost, s_));
-        HIP_OK(hipStreamSynchronize(s_));
-    }
-private:
-    struct Uploaded { const LoadedFile* f = nullptr; uint64_t n = 0; Device<char> bytes; Device<uint64_t> off; Device<uint32_t> len; };
-    Uploaded& upload(const LoadedFile& f)
-    {
-        for (Uploaded& u : up_) if (u.f == &f) return u;
-        Uploaded& u = up_[used_++ & 1]; u.f = &f; u.n = f.recs.size();
-        std::vector<uint64_t> off(u.n); std::vector<uint32_t> len(u.n);
-        uint64_t total = 0;
-        for (uint64_t k = 0; k < u.n; ++k) { off[k] = total; len[k] = f.recs[k].tag_len; total += f.recs[k].tag_len; }
-        std::vector<char> bytes(total + 16);
-        for (uint64_t k = 0; k < u.n; ++k) std::memcpy(bytes.data() + off[k], f.recs[k].tag(), len[k]);
-        u.bytes.reserve(total + 16); u.off.reserve(u.n); u.len.reserve(u.n);
-        HIP_OK(hipMemcpyAsync(u.bytes.p, bytes.data(), total, hipMemcpyHostToDevice, s_));
-        HIP_OK(hipMemcpyAsync(u.off.p, off.data(), u.n * sizeof(uint64_t), hipMemcpyHostToDevice, s_));
-        HIP_OK(hipMemcpyAsync(u.len.p, len.data(), u.n * sizeof(uint32_t), hipMemcpyHostToDevice, s_));
-        HIP_OK(hipStreamSynchronize(s_));
-        return u;
-    }
-    fqd_engine* e_; hipStream_t s_; Uploaded up_[2]; unsigned used_ = 0;
-};
+// Copies entry k of a device array of uint32.
+uint32_t peek_u32(const uint32_t* d, uint64_t k, hipStream_t s)
+{
+    uint32_t v = 0;
+    HIP_OK(hipMemcpyAsync(&v, d + k, sizeof v, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return v;
+}
 
 } // namespace
 
 // ---------------------------------------------------------------------------
 // --unordered (hash_dup_remover.hpp:150-192,257-347): join the two files on the ID tag,
 // dedup the joined pairs in tag order, write survivors in tag order.
+//
+// Both files are read and indexed in pinned memory, their raw text goes to HBM once, and from
+// there on the device works on the text where it lies: tag extraction, the tag sort + join
+// (fqd_extract_tags, fqd_join_tags: csrc/fqd_join.hip), the pairs' sequence descriptors
+// (fqd_gather_seqs) and the pair dedup (fqd_submit, ragged batches in tag order).  The host gets
+// back the pair list and one keep flag per pair and writes the survivors from its copy of the text.
 void HashDupRemover::run_unordered(const std::string* in, const std::string* out)
 {
-    (void)memlimit_; (void)tempdir_;          // intermediates live in memory, not in sorted temp files
+    (void)tempdir_;
     HIP_OK(hipSetDevice(tuning_.device));
     // 1. load + index both files (the reference's ExternalSorter reads them fully too, hpp:161-173)
     LoadedFile file[2];
@@ -490,107 +454,147 @@ void HashDupRemover::run_unordered(const std::string* in, const std::string* out
     HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
     EngineHandle eng(2, tuning_.device, stream);
+    auto engine_ok = [&](int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng.e)); };
 
-    // 3. join on tags: sort + match on the GPU (fqd_sort_tags / fqd_match_sorted_tags)
-    std::vector<std::pair<uint64_t, uint64_t>> pairs;
-    uint64_t unmatched = 0;
-    {
-        StageClock::Scope t("unordered: tag join (GPU sort/match + host walk)");
-        GpuTagJoin dev(eng.e, stream);
-        join_by_tag(file[0], file[1], tuning_.reference_tail_rule, dev, pairs, unmatched);
-    }
+    const uint64_t n_rec[2] = {file[0].recs.size(), file[1].recs.size()};
+    if (n_rec[0] >= 0x80000000ull || n_rec[1] >= 0x80000000ull)
+        throw std::runtime_error("--unordered: more than 2^31-1 records in one file");
 
-    // 4. pair-dedup in tag order on the GPU.  When both files fit in HBM beside the set, their raw
-    //    text is uploaded once and the encoder reads every pair's sequences where they lie
-    //    (offset/length per mate); otherwise the sequences are gathered on the host batch by batch.
-    std::vector<uint8_t> keep(pairs.size());
-    uint64_t written_below = pairs.size();
-    bool bad = false; uint8_t bad_byte = 0;
+    // 3. text + per-record index to HBM
+    Device<char> d_text[2]; Device<uint64_t> d_seq_off[2]; Device<uint32_t> d_id_len[2], d_seq_len[2];
+    Device<uint64_t> d_id_start[2], d_tag_off[2]; Device<uint32_t> d_tag_len[2];
     {
-        StageClock::Scope t("unordered: sequences to the GPU + dedup");
-        const size_t kBatch = 4u << 20;
+        StageClock::Scope t("unordered: text + index to the GPU");
         size_t text_bytes[2] = {0, 0};
         for (int s = 0; s < 2; ++s) for (size_t u : file[s].chunk_used) text_bytes[s] += u;
         size_t free_b = 0, total_b = 0;
         HIP_OK(hipMemGetInfo(&free_b, &total_b));
-        const size_t need = text_bytes[0] + text_bytes[1] + pairs.size() * 200 + (size_t(2) << 30);   // text + keys, table, scratch
-        const bool in_place = !pairs.empty() && need < free_b && std::getenv("FQD_UNORDERED_HOST_GATHER") == nullptr;
-        auto check = [&](int rc) {
-            if (rc == FQD_ERR_BAD_BASE) {
-                uint64_t rec; uint32_t sg2, pos;
-                fqd_bad_base(eng.e, &rec, &sg2, &pos, &bad_byte);
-                bad = true; written_below = rec;
-            } else if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng.e));
-        };
-        if (in_place) {
-            Device<char> d_text[2];
-            std::vector<uint64_t> chunk_base[2];
-            for (int s = 0; s < 2; ++s) {
-                d_text[s].reserve(text_bytes[s] + 64);
-                uint64_t at = 0;
-                for (size_t c = 0; c < file[s].chunks.size(); ++c) {
-                    chunk_base[s].push_back(at);
-                    HIP_OK(hipMemcpyAsync(d_text[s].p + at, file[s].chunks[c]->p, file[s].chunk_used[c], hipMemcpyHostToDevice, stream));
-                    at += file[s].chunk_used[c];
-                }
+        const size_t n_all = n_rec[0] + n_rec[1];
+        const size_t need = text_bytes[0] + text_bytes[1] + n_all * (40 + 40) + std::min(n_rec[0], n_rec[1]) * 230 + (size_t(2) << 30);
+        if (need > free_b)
+            throw std::runtime_error("--unordered: the two inputs (" + std::to_string((text_bytes[0] + text_bytes[1]) >> 20) +
+                                     " MiB of text) do not fit in GPU memory beside the join and the set");
+        Pinned<uint64_t> h_off, h_ids; Pinned<uint32_t> h_idl, h_sql;
+        for (int s = 0; s < 2; ++s) {
+            d_text[s].reserve(text_bytes[s] + 64);
+            std::vector<uint64_t> chunk_base;
+            uint64_t at = 0;
+            for (size_t c = 0; c < file[s].chunks.size(); ++c) {
+                chunk_base.push_back(at);
+                HIP_OK(hipMemcpyAsync(d_text[s].p + at, file[s].chunks[c]->p, file[s].chunk_used[c], hipMemcpyHostToDevice, stream));
+                at += file[s].chunk_used[c];
             }
-            Pinned<uint64_t> off[2]; Pinned<uint32_t> len[2]; Pinned<uint8_t> h_keep;
-            Device<uint64_t> d_off[2]; Device<uint32_t> d_len[2]; Device<uint8_t> d_keep;
-            for (size_t a = 0; a < pairs.size() && !bad; a += kBatch) {
-                const size_t n = std::min(kBatch, pairs.size() - a);
-                fqd_reads seg[2] = {};
-                for (int s = 0; s < 2; ++s) {
-                    off[s].reserve(n); len[s].reserve(n); d_off[s].reserve(n); d_len[s].reserve(n);
-                    const unsigned parts = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(host_threads(), n >> 16)));
-                    run_parts(parts, [&](unsigned p) {
-                        for (size_t k = n / parts * p, e = p + 1 == parts ? n : n / parts * (p + 1); k < e; ++k) {
-                            const FileRecord& r = file[s].recs[s == 0 ? pairs[a + k].first : pairs[a + k].second];
-                            off[s].p[k] = chunk_base[s][r.chunk] + static_cast<uint64_t>(r.text - file[s].chunks[r.chunk]->p) + r.id_len;
-                            len[s].p[k] = r.seq_len;
-                        }
-                    });
-                    HIP_OK(hipMemcpyAsync(d_off[s].p, off[s].p, n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-                    HIP_OK(hipMemcpyAsync(d_len[s].p, len[s].p, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-                    seg[s].bases = reinterpret_cast<const uint8_t*>(d_text[s].p); seg[s].offsets = d_off[s].p; seg[s].lengths = d_len[s].p;
+            const size_t n = n_rec[s];
+            h_off.reserve(n); h_ids.reserve(n); h_idl.reserve(n); h_sql.reserve(n);
+            const unsigned parts = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(host_threads(), n >> 16)));
+            run_parts(parts, [&](unsigned p) {
+                for (size_t k = n / parts * p, e = p + 1 == parts ? n : n / parts * (p + 1); k < e; ++k) {
+                    const FileRecord& r = file[s].recs[k];
+                    h_ids.p[k] = chunk_base[r.chunk] + static_cast<uint64_t>(r.text - file[s].chunks[r.chunk]->p);
+                    h_off.p[k] = h_ids.p[k] + r.id_len;
+                    h_idl.p[k] = r.id_len; h_sql.p[k] = r.seq_len;
                 }
-                h_keep.reserve(n); d_keep.reserve(n);
-                int rc = fqd_submit(eng.e, seg, n, FQD_MEM_DEVICE, d_keep.p);
-                if (rc == FQD_OK) {
-                    HIP_OK(hipMemcpyAsync(h_keep.p, d_keep.p, n, hipMemcpyDeviceToHost, stream));
-                    rc = fqd_engine_sync(eng.e);                 // the offset arrays are reused by the next batch
-                }
-                check(rc);
-                std::memcpy(keep.data() + a, h_keep.p, n);
-            }
-            HIP_OK(hipStreamSynchronize(stream));
-        } else {
-            std::vector<uint8_t> bases[2]; std::vector<uint64_t> off[2]; std::vector<uint32_t> len[2];
-            for (size_t a = 0; a < pairs.size() && !bad; a += kBatch) {
-                const size_t n = std::min(kBatch, pairs.size() - a);
-                fqd_reads seg[2] = {};
-                for (int s = 0; s < 2; ++s) {
-                    off[s].resize(n); len[s].resize(n);
-                    size_t total = 0;
-                    for (size_t k = 0; k < n; ++k) {
-                        const FileRecord& r = file[s].recs[s == 0 ? pairs[a + k].first : pairs[a + k].second];
-                        off[s][k] = total; len[s][k] = r.seq_len; total += r.seq_len;
-                    }
-                    bases[s].resize(total + 16);
-                    for (size_t k = 0; k < n; ++k) {
-                        const FileRecord& r = file[s].recs[s == 0 ? pairs[a + k].first : pairs[a + k].second];
-                        std::memcpy(bases[s].data() + off[s][k], r.text + r.id_len, r.seq_len);
-                    }
-                    seg[s].bases = bases[s].data(); seg[s].offsets = off[s].data(); seg[s].lengths = len[s].data();
-                }
-                check(fqd_submit(eng.e, seg, n, FQD_MEM_HOST, keep.data() + a));
-            }
+            });
+            d_seq_off[s].reserve(n); d_id_len[s].reserve(n); d_seq_len[s].reserve(n);
+            d_id_start[s].reserve(n); d_tag_off[s].reserve(n); d_tag_len[s].reserve(n);
+            HIP_OK(hipMemcpyAsync(d_seq_off[s].p, h_off.p, n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+            HIP_OK(hipMemcpyAsync(d_id_len[s].p, h_idl.p, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            HIP_OK(hipMemcpyAsync(d_seq_len[s].p, h_sql.p, n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            HIP_OK(hipMemcpyAsync(d_id_start[s].p, h_ids.p, n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+            engine_ok(fqd_extract_tags(eng.e, reinterpret_cast<const uint8_t*>(d_text[s].p), d_id_start[s].p, d_id_len[s].p, n,
+                                       d_tag_off[s].p, d_tag_len[s].p));
+            HIP_OK(hipStreamSynchronize(stream));                // the pinned staging arrays are reused by file 2
         }
     }
-    // 5. survivors in tag order: one thread per output file, records handed over where they lie
+
+    // 4. the join on the GPU
+    const uint64_t max_pairs = std::min(n_rec[0], n_rec[1]);
+    Device<uint32_t> d_perm[2], d_match[2], d_pair[2];
+    uint64_t n_pairs = 0;
+    TailOutcome outcome{0, false, 0};
+    {
+        StageClock::Scope t("unordered: tag join on the GPU");
+        for (int s = 0; s < 2; ++s) { d_perm[s].reserve(n_rec[s]); d_match[s].reserve(n_rec[s]); d_pair[s].reserve(max_pairs); }
+        const fqd_tags ta{reinterpret_cast<const uint8_t*>(d_text[0].p), d_tag_off[0].p, d_tag_len[0].p, n_rec[0]};
+        const fqd_tags tb{reinterpret_cast<const uint8_t*>(d_text[1].p), d_tag_off[1].p, d_tag_len[1].p, n_rec[1]};
+        const fqd_join jo{d_perm[0].p, d_perm[1].p, d_match[0].p, d_match[1].p, d_pair[0].p, d_pair[1].p, &n_pairs};
+        engine_ok(fqd_join_tags(eng.e, &ta, &tb, &jo));
+
+        JoinLookup look;
+        look.n = n_rec[0]; look.m = n_rec[1]; look.n_pairs = n_pairs;
+        look.match_a = [&](uint64_t k) { return peek_u32(d_match[0].p, k, stream); };
+        look.match_b = [&](uint64_t k) { return peek_u32(d_match[1].p, k, stream); };
+        // "how many tags of the other file are <= this one": a search over the other file's tag order
+        // with the reference's comparison, on the host's copy of the tags
+        std::vector<uint32_t> h_perm[2];
+        auto fetch_perm = [&](int s) {
+            if (h_perm[s].size() == n_rec[s]) return;
+            h_perm[s].resize(n_rec[s]);
+            HIP_OK(hipMemcpyAsync(h_perm[s].data(), d_perm[s].p, n_rec[s] * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+        };
+        auto count_le = [&](int of, uint64_t pos_other) {
+            const int other = 1 - of;
+            const FileRecord& key = file[other].recs[peek_u32(d_perm[other].p, pos_other, stream)];
+            fetch_perm(of);
+            uint64_t lo = 0, hi = n_rec[of];
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) / 2;
+                const FileRecord& r = file[of].recs[h_perm[of][mid]];
+                if (compare_tags(r.tag(), r.tag_len, key.tag(), key.tag_len) <= 0) lo = mid + 1; else hi = mid;
+            }
+            return lo;
+        };
+        look.count_b_le_a = [&](uint64_t i) { return count_le(1, i); };
+        look.count_a_le_b = [&](uint64_t j) { return count_le(0, j); };
+        outcome = tuning_.reference_tail_rule ? reference_tail_rule(look) : full_join_outcome(look);
+    }
+
+    // 5. pair-dedup in tag order on the GPU: the pairs' sequences are read where they lie in the
+    //    uploaded text through offset/length arrays gathered on the device; batches are queued
+    //    back to back, the host waits once
+    const uint64_t n_proc = outcome.pairs;                       // the reference never sees a dropped last pair
+    std::vector<uint8_t> keep(n_proc);
+    std::vector<uint32_t> pair_idx[2];
+    uint64_t written_below = n_proc;
+    bool bad = false; uint8_t bad_byte = 0;
+    {
+        StageClock::Scope t("unordered: pair dedup on the GPU");
+        Device<uint64_t> d_off[2]; Device<uint32_t> d_len[2]; Device<uint8_t> d_keep;
+        for (int s = 0; s < 2; ++s) {
+            d_off[s].reserve(n_proc); d_len[s].reserve(n_proc);
+            engine_ok(fqd_gather_seqs(eng.e, d_pair[s].p, n_proc, d_seq_off[s].p, d_seq_len[s].p, d_off[s].p, d_len[s].p));
+        }
+        d_keep.reserve(n_proc);
+        const size_t kBatch = 16u << 20;
+        int rc = FQD_OK;
+        for (size_t a = 0; a < n_proc && rc == FQD_OK; a += kBatch) {
+            const size_t n = std::min<size_t>(kBatch, n_proc - a);
+            fqd_reads seg[2] = {};
+            for (int s = 0; s < 2; ++s) {
+                seg[s].bases = reinterpret_cast<const uint8_t*>(d_text[s].p);
+                seg[s].offsets = d_off[s].p + a; seg[s].lengths = d_len[s].p + a;
+            }
+            rc = fqd_submit(eng.e, seg, n, FQD_MEM_DEVICE, d_keep.p + a);
+        }
+        if (rc == FQD_OK) rc = fqd_engine_sync(eng.e);
+        if (rc == FQD_ERR_BAD_BASE) {
+            uint64_t rec; uint32_t sg2, pos;
+            fqd_bad_base(eng.e, &rec, &sg2, &pos, &bad_byte);
+            bad = true; written_below = std::min<uint64_t>(rec, n_proc);
+        } else engine_ok(rc);
+        for (int s = 0; s < 2; ++s) {
+            pair_idx[s].resize(n_proc);
+            if (n_proc) HIP_OK(hipMemcpyAsync(pair_idx[s].data(), d_pair[s].p, n_proc * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        }
+        if (n_proc) HIP_OK(hipMemcpyAsync(keep.data(), d_keep.p, n_proc, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+    }
+    // 6. survivors in tag order: one thread per output file, records handed over where they lie
     uint64_t dups = 0;
     {
         StageClock::Scope t("unordered: write survivors");
-        const uint64_t upto = std::min<uint64_t>(pairs.size(), written_below);
+        const uint64_t upto = std::min<uint64_t>(n_proc, written_below);
         for (uint64_t k = 0; k < upto; ++k) dups += keep[k] == 0;
         OutputFile* sinks[2] = {&sink0, &sink1};
         run_parts(2, [&](unsigned s) {
@@ -598,7 +602,7 @@ void HashDupRemover::run_unordered(const std::string* in, const std::string* out
             pieces.reserve(1u << 16);
             for (uint64_t k = 0; k < upto; ++k) {
                 if (!keep[k]) continue;
-                const FileRecord& r = file[s].recs[s == 0 ? pairs[k].first : pairs[k].second];
+                const FileRecord& r = file[s].recs[pair_idx[s][k]];
                 pieces.push_back({r.text, r.size});
                 if (pieces.size() == (1u << 16)) { sinks[s]->write_pieces(pieces.data(), pieces.size()); pieces.clear(); }
             }
@@ -608,7 +612,7 @@ void HashDupRemover::run_unordered(const std::string* in, const std::string* out
     }
     StageClock::report();
     if (bad) throw_unknown_base(bad_byte);
-    summary_.total = pairs.size(); summary_.duplicates = dups; summary_.unmatched = unmatched;
+    summary_.total = n_proc; summary_.duplicates = dups; summary_.unmatched = outcome.unmatched;
     if (verbose_) {
         std::cout << summary_.total << " valid read pairs processed, out of which " << summary_.duplicates << " duplicates were removed.\n";
         std::cout << summary_.unmatched << " Non-matching entries from both files were skipped.\n";

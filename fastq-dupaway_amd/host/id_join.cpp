@@ -40,61 +40,46 @@ void load_whole_file(const std::string& name, Format f, size_t block_bytes, Load
     }
 }
 
-void join_by_tag(const LoadedFile& a, const LoadedFile& b, bool tail_rule, TagJoinDevice& dev,
-                 std::vector<std::pair<uint64_t, uint64_t>>& pairs, uint64_t& unmatched)
+TailOutcome full_join_outcome(const JoinLookup& j)
 {
-    pairs.clear(); unmatched = 0;
-    const size_t n = a.recs.size(), m = b.recs.size();
-    if (n == 0 || m == 0) return;
-    // the sort phase (hpp:161-173) and the equality tests of the merge (hpp:283-309) run on the GPU
-    std::vector<uint32_t> oa, ob, match;
-    dev.sort(a, oa);
-    dev.sort(b, ob);
-    dev.match(a, oa, b, ob, match);
-    constexpr uint32_t kNone = 0xFFFFFFFFu;
-    auto tag_a = [&](size_t k) -> const FileRecord& { return a.recs[oa[k]]; };
-    auto tag_b = [&](size_t k) -> const FileRecord& { return b.recs[ob[k]]; };
-    auto cmp_ab = [&](size_t i, size_t j) { return compare_tags(tag_a(i).tag(), tag_a(i).tag_len, tag_b(j).tag(), tag_b(j).tag_len); };
+    if (j.n == 0 || j.m == 0) return TailOutcome{0, false, 0};     // nothing is compared at all
+    return TailOutcome{j.n_pairs, false, j.n + j.m - 2 * j.n_pairs};
+}
 
-    if (!tail_rule) {                                        // intended semantics: full inner join
-        for (size_t k = 0; k < n; ++k)
-            if (match[k] != kNone) pairs.emplace_back(oa[k], ob[match[k]]);
-        unmatched = n + m - 2 * pairs.size();
-        return;
-    }
-    // The reference's loop (hpp:279-340) advances only while NEITHER cursor is on its file's last
-    // record, then compares once more.  Everything it finds before that point is exactly the set
-    // of matches below both second-to-last tags; what remains is one comparison at the exit state.
+TailOutcome reference_tail_rule(const JoinLookup& j)
+{
+    const uint64_t n = j.n, m = j.m;
+    if (n == 0 || m == 0) return TailOutcome{0, false, 0};          // the loop and the last check never run
     if (n == 1 || m == 1) {
-        if (cmp_ab(0, 0) == 0) pairs.emplace_back(oa[0], ob[0]); else unmatched = 1;
-        return;
+        // the loop body never runs: one comparison of the two smallest tags (hpp:317-340)
+        const bool equal = j.match_a(0) == 0;
+        return TailOutcome{equal ? 1u : 0u, !equal && j.n_pairs > 0, equal ? 0u : 1u};
     }
-    size_t i_exit, j_exit;
-    const int c = cmp_ab(n - 2, m - 2);
-    if (c <= 0) {
-        // a's cursor reaches its last record first (or both together): b stands on its first tag > a[n-2]
-        i_exit = n - 1;
-        if (c == 0) j_exit = m - 1;
-        else if (match[n - 2] != kNone) j_exit = size_t(match[n - 2]) + 1;
-        else {
-            size_t lo = 0, hi = m;                           // first b tag greater than a[n-2]
-            while (lo < hi) { const size_t mid = (lo + hi) / 2; if (cmp_ab(n - 2, mid) >= 0) lo = mid + 1; else hi = mid; }
-            j_exit = lo;
-        }
-        for (size_t k = 0; k + 1 < n; ++k)
-            if (match[k] != kNone) pairs.emplace_back(oa[k], ob[match[k]]);
-    } else {
-        j_exit = m - 1;
-        size_t lo = 0, hi = n;                               // first a tag greater than b[m-2]
-        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (cmp_ab(mid, m - 2) <= 0) lo = mid + 1; else hi = mid; }
-        i_exit = lo;
-        for (size_t k = 0; k < i_exit; ++k)
-            if (match[k] != kNone) pairs.emplace_back(oa[k], ob[match[k]]);
+    // The full merge visits its states (i, j) in order; the reference's loop is that merge cut at
+    // the first state with i == n-1 or j == m-1.  i becomes n-1 right after L[n-2] is consumed, in
+    // the state (n-2, j1): j1 = its partner's position when it has one, else everything of file 2
+    // with a tag <= its own has been consumed by then.  If file 2's cursor is still below m-1
+    // there (j1 <= m-2) that is where the loop stops; otherwise file 2 reached its last record
+    // first and the same holds with the files swapped.
+    uint64_t i_exit, j_exit;
+    const uint32_t mx = j.match_a(n - 2);
+    const uint64_t j1 = mx != kNoPartner ? mx : j.count_b_le_a(n - 2);
+    if (j1 <= m - 2) { i_exit = n - 1; j_exit = j1 + (mx != kNoPartner ? 1 : 0); }
+    else {
+        const uint32_t my = j.match_b(m - 2);
+        const uint64_t i2 = my != kNoPartner ? my : j.count_a_le_b(m - 2);
+        j_exit = m - 1; i_exit = i2 + (my != kNoPartner ? 1 : 0);
     }
-    const size_t before = pairs.size();
-    const bool last_equal = cmp_ab(i_exit, j_exit) == 0;     // hpp:317-340 "check 2 last records"
-    if (last_equal) pairs.emplace_back(oa[i_exit], ob[j_exit]);
-    unmatched = i_exit + j_exit - 2 * before + (last_equal ? 0 : 1);
+    // pairs below both last records are all found before the stop; a pair that involves a last
+    // record is the last pair of the full join, and found only if the stop state is that pair
+    const bool special = j.match_a(n - 1) != kNoPartner || j.match_b(m - 1) != kNoPartner;
+    const uint64_t before = j.n_pairs - (special ? 1 : 0);
+    const bool last_equal = j.match_a(i_exit) == j_exit;            // equal tags in a visited state = a pair of the full join
+    TailOutcome out;
+    out.pairs = before + (last_equal ? 1 : 0);
+    out.drop_last = special && !last_equal;
+    out.unmatched = i_exit + j_exit - 2 * before + (last_equal ? 0 : 1);
+    return out;
 }
 
 } // namespace fqdhost

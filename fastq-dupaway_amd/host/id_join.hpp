@@ -4,6 +4,7 @@
 // with the same ordering (FastqViewWithId::cmp, fastqview.cpp:168-204).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <utility>
@@ -31,23 +32,31 @@ struct LoadedFile {
 // throws "Not enough memory to read a single object!" like the reference's sorter does.
 void load_whole_file(const std::string& name, Format f, size_t block_bytes, LoadedFile& out);
 
-// The two device primitives the join is built on (include/fqdupaway.h: fqd_sort_tags,
-// fqd_match_sorted_tags), bound to an engine by the caller.
-struct fqd_engine_fwd;
-struct TagJoinDevice {
-    // perm[k] = record index of the k-th smallest tag
-    virtual void sort(const LoadedFile& f, std::vector<uint32_t>& perm) = 0;
-    // match[k] = position in perm_b of the record whose tag equals a's perm_a[k], or 0xFFFFFFFF
-    virtual void match(const LoadedFile& a, const std::vector<uint32_t>& perm_a,
-                       const LoadedFile& b, const std::vector<uint32_t>& perm_b, std::vector<uint32_t>& match) = 0;
-    virtual ~TagJoinDevice() = default;
+// What the device join (include/fqdupaway.h: fqd_join_tags) found: the FULL inner join of the two
+// files on the ID tag, k-th record with a tag in file 1 paired with the k-th in file 2.  Positions
+// are positions in each file's tag order.  The arrays stay on the device; these accessors fetch
+// what the end-of-file rule needs (a handful of entries, and a tag search only when the
+// second-to-last record of a file has no partner).
+constexpr uint32_t kNoPartner = 0xFFFFFFFFu;
+struct JoinLookup {
+    uint64_t n = 0, m = 0;               // records in file 1 / file 2
+    uint64_t n_pairs = 0;                // pairs of the full join
+    std::function<uint32_t(uint64_t)> match_a;        // sorted position in file 1 -> partner's sorted position in file 2
+    std::function<uint32_t(uint64_t)> match_b;        // the reverse
+    std::function<uint64_t(uint64_t)> count_b_le_a;   // records of file 2 whose tag is <= the tag at sorted position i of file 1
+    std::function<uint64_t(uint64_t)> count_a_le_b;   // records of file 1 whose tag is <= the tag at sorted position j of file 2
 };
 
-// Joins on the ID tag.  `pairs` receives (index in a, index in b) in tag order; unmatched
-// counts skipped records the way the reference does.  tail_rule: stop as the reference's
-// merge loop does, as soon as either side is on its LAST record, then compare once more
-// (hash_dup_remover.hpp:279-340).
-void join_by_tag(const LoadedFile& a, const LoadedFile& b, bool tail_rule, TagJoinDevice& dev,
-                 std::vector<std::pair<uint64_t, uint64_t>>& pairs, uint64_t& unmatched);
+// The reference's merge loop (hash_dup_remover.hpp:279-340) advances only while NEITHER cursor is
+// on its file's last record, then compares once more and stops.  Against the full
+// join that can only lose the LAST pair in tag order — the one that involves a file's last
+// record — which survives iff the loop happens to stop exactly on it.
+struct TailOutcome {
+    uint64_t pairs;        // pairs the reference processes: n_pairs, or n_pairs - 1 when the last one is lost
+    bool     drop_last;    // the last pair of the full join is not processed
+    uint64_t unmatched;    // what the reference counts as "Non-matching entries"
+};
+TailOutcome reference_tail_rule(const JoinLookup& j);
+TailOutcome full_join_outcome(const JoinLookup& j);
 
 } // namespace fqdhost

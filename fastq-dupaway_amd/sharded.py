@@ -116,6 +116,54 @@ class ShardedDedup:
         self.keep_recv = torch.empty(self.cap_recv, dtype=torch.uint8, device=device)
         self.keep_back = torch.empty(n_max, dtype=torch.uint8, device=device)
 
+    # No rank-to-rank message of an exchange may exceed this many bytes.  Measured on this image (RCCL
+    # 2.26.6, torch 2.10; tools/a2a_probe.py, profiles/r02_a2a_probe.jsonl): of a message above 1 GiB
+    # (2^30 bytes exactly is still fine) only the first half arrives — with ordinary torch tensors on
+    # both sides just as with the key store aliased in, so it is a limit of the library, not of the
+    # buffers used here.  Larger exchanges are cut into passes of equal slices (_all_to_all).
+    MAX_MESSAGE = 512 << 20
+
+    def _exchange_counts(self, counts):
+        """Every rank's send counts to every rank (world x world, row = sender): the receive counts of this
+        rank are a column, and the largest message of the exchange — which decides into how many passes it
+        is cut — is known everywhere without another collective."""
+        table = torch.empty(self.world * self.world, dtype=torch.int64, device=counts.device)
+        self.dist.all_gather_into_tensor(table, counts)
+        t = table.view(self.world, self.world).cpu()
+        send = [int(c) for c in t[self.rank].tolist()]
+        recv = [int(c) for c in t[:, self.rank].tolist()]
+        return send, recv, int(t.max().item())
+
+    def _all_to_all(self, out, inp, recv, send, width, largest, async_op=False):
+        """all_to_all_single of items `width` elements wide (recv/send in items), cut into passes when the
+        largest message anywhere (`largest` items) would exceed MAX_MESSAGE: pass p moves the p-th slice
+        of every rank-to-rank message through contiguous staging buffers."""
+        dist = self.dist
+        item_bytes = width * out.element_size()
+        passes = max(1, -(-(largest * item_bytes) // self.MAX_MESSAGE))
+        if passes == 1:
+            extra = {"async_op": True} if async_op else {}
+            return dist.all_to_all_single(out, inp, output_split_sizes=[c * width for c in recv],
+                                          input_split_sizes=[c * width for c in send], **extra)
+        def cut(c, p):                                   # slice p of a message of c items
+            per = -(-c // passes)
+            lo = min(c, p * per)
+            return lo, min(c, lo + per) - lo
+        s_off = [0]; r_off = [0]
+        for c in send: s_off.append(s_off[-1] + c)
+        for c in recv: r_off.append(r_off[-1] + c)
+        for p in range(passes):
+            s_cut = [cut(c, p) for c in send]; r_cut = [cut(c, p) for c in recv]
+            stage_in = torch.cat([inp[(s_off[j] + lo) * width:(s_off[j] + lo + m) * width] for j, (lo, m) in enumerate(s_cut)])
+            stage_out = torch.empty(sum(m for _, m in r_cut) * width, dtype=out.dtype, device=out.device)
+            dist.all_to_all_single(stage_out, stage_in, output_split_sizes=[m * width for _, m in r_cut],
+                                   input_split_sizes=[m * width for _, m in s_cut])
+            at = 0
+            for j, (lo, m) in enumerate(r_cut):
+                out[(r_off[j] + lo) * width:(r_off[j] + lo + m) * width].copy_(stage_out[at * width:(at + m) * width])
+                at += m
+        return None
+
     def dedup(self, segs: Sequence, n: int, keep):
         ops, dist, xw = self.ops, self.dist, self.xw
         if n > self.n_max:
@@ -123,9 +171,7 @@ class ShardedDedup:
         ops.encode(segs, n, self.records)
         ops.partition(self.records, n, self.W, self.world, self.grouped, self.counts, self.origin)
         ops.sync()                                   # the collectives run on torch's stream
-        dist.all_to_all_single(self.recv_counts, self.counts)
-        send = [int(c) for c in self.counts.tolist()]
-        recv = [int(c) for c in self.recv_counts.tolist()]
+        send, recv, largest = self._exchange_counts(self.counts)
         n_recv = sum(recv)
         if n_recv > self.cap_recv:                   # a skewed step: grow once, keep going
             self.cap_recv = int(n_recv * 1.1) + 4096
@@ -133,13 +179,11 @@ class ShardedDedup:
                 self.recv = torch.empty(self.cap_recv * xw, dtype=torch.int64, device=self.device)
             self.keep_recv = torch.empty(self.cap_recv, dtype=torch.uint8, device=self.device)
         recv_buf = ops.recv_buffer(n_recv, self.len0, self.len1, self.device) if self.in_place else self.recv
-        dist.all_to_all_single(recv_buf[: n_recv * xw], self.grouped[: n * xw],
-                               output_split_sizes=[c * xw for c in recv], input_split_sizes=[c * xw for c in send])
+        self._all_to_all(recv_buf[: n_recv * xw], self.grouped[: n * xw], recv, send, xw, largest)
         self._sync_comm()
         ops.insert(recv_buf, n_recv, self.len0, self.len1, self.keep_recv)
         ops.sync()
-        dist.all_to_all_single(self.keep_back[:n], self.keep_recv[:n_recv],
-                               output_split_sizes=send, input_split_sizes=recv)
+        self._all_to_all(self.keep_back[:n], self.keep_recv[:n_recv], send, recv, 1, largest)
         self._sync_comm()
         ops.scatter(self.keep_back, self.origin, n, keep)
         return n_recv
@@ -183,9 +227,7 @@ class ShardedDedup:
             b = self._pipe[k % 2]
             st[k]["ev_p"].synchronize()                       # host: the split sizes of round k are ready
             with torch.cuda.stream(s_c):                      # reads ordered behind the collective on s_c
-                dist.all_to_all_single(b.recv_counts, b.counts)
-                send = [int(c) for c in b.counts.tolist()]
-                recv = [int(c) for c in b.recv_counts.tolist()]
+                send, recv, largest = self._exchange_counts(b.counts)
             n_recv = sum(recv)
             if n_recv > b.cap_recv:
                 b.cap_recv = int(n_recv * 1.1) + 4096
@@ -193,15 +235,14 @@ class ShardedDedup:
             buf = ops.recv_buffer(n_recv, self.len0, self.len1, dev)     # tail of the key store, after insert(k-1)
             s_c.wait_event(st[k]["ev_p"])
             with torch.cuda.stream(s_c):
-                work = dist.all_to_all_single(buf[: n_recv * xw], b.grouped[: n * xw],
-                                              output_split_sizes=[c * xw for c in recv],
-                                              input_split_sizes=[c * xw for c in send], async_op=True)
-            st[k].update(send=send, recv=recv, n_recv=n_recv, buf=buf, work=work)
+                work = self._all_to_all(buf[: n_recv * xw], b.grouped[: n * xw], recv, send, xw, largest, async_op=True)
+            st[k].update(send=send, recv=recv, n_recv=n_recv, buf=buf, work=work, largest=largest)
 
         def insert(k):
             b = self._pipe[k % 2]
             with torch.cuda.stream(s_c):
-                st[k]["work"].wait()
+                if st[k]["work"] is not None:
+                    st[k]["work"].wait()
                 ev = torch.cuda.Event(); ev.record(s_c)
             s_e.wait_event(ev)                                # the engine's stream waits for the records
             ops.insert(st[k]["buf"], st[k]["n_recv"], self.len0, self.len1, b.keep_recv)
@@ -212,8 +253,7 @@ class ShardedDedup:
             b = self._pipe[k % 2]
             s_c.wait_event(st[k]["ev_i"])
             with torch.cuda.stream(s_c):
-                dist.all_to_all_single(b.keep_back[:n], b.keep_recv[: st[k]["n_recv"]],
-                                       output_split_sizes=st[k]["send"], input_split_sizes=st[k]["recv"])
+                self._all_to_all(b.keep_back[:n], b.keep_recv[: st[k]["n_recv"]], st[k]["send"], st[k]["recv"], 1, st[k]["largest"])
                 ev = torch.cuda.Event(); ev.record(s_c)
             s_e.wait_event(ev)
             ops.scatter(b.keep_back, b.origin, n, keep)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FQD_ABI_VERSION 1
+#define FQD_ABI_VERSION 2
 
 /* status codes */
 #define FQD_OK              0
@@ -213,8 +213,14 @@ int  fqd_apply_replies(fqd_engine* e, const uint64_t* reply, uint64_t n, uint8_t
                        const uint8_t* verdict, uint64_t m, uint64_t* refuted);
 
 /* ---- the `--unordered` read-ID join (hash_dup_remover.hpp:150-192,257-347) ------------
- * ID tags of one file (FastqViewWithId::read_new, fastqview.cpp:190-204): the tag bytes of
- * all records back to back plus per-record offset and length.  Device pointers; n < 2^32-1. */
+ * The reference sorts both files by ID tag on disk (ExternalSorter<T>::sort,
+ * external_sort.hpp:66-71,88-215, order = FastqViewWithId::cmp, fastqview.cpp:168-178) and
+ * merge-joins the sorted files (hpp:279-340).  Here both files' tags are ordered together in
+ * HBM by one hand-written radix sort over an order-preserving compact code of the tags, and the
+ * matches are read off the sorted union (csrc/fqd_join.hip).  All pointers are device pointers. */
+
+/* ID tags of one file: the tag bytes of record i are bytes[offsets[i] .. offsets[i]+lengths[i]) —
+ * anywhere, e.g. inside the file's raw text as uploaded.  n < 2^31. */
 typedef struct fqd_tags {
     const uint8_t*  bytes;
     const uint64_t* offsets;
@@ -222,17 +228,43 @@ typedef struct fqd_tags {
     uint64_t        n;
 } fqd_tags;
 
-/* perm[k] (device, n uint32) = index of the record with the k-th smallest tag, in the order of
- * FastqViewWithId::cmp (fastqview.cpp:168-178): bytewise over the shorter length, shorter
- * first on a tie; equal tags keep their input order.  Replaces ExternalSorter<T>::sort
- * (external_sort.hpp:66-71,88-117) by an LSD radix sort in HBM. */
+/* FastqViewWithId::read_new / FastaViewWithId::read_new (fastqview.cpp:190-204,
+ * fastaview.cpp:153-167) for n records whose ID lines lie in `text`: id_start[i] = offset of the
+ * leading '@' / '>', id_len[i] = length of the ID line including its newline.  Writes the tag's
+ * offset into `text` and its length: after the first '.' of the line if there is one, else after
+ * the first byte; up to the first ' ', else through the end of the line including the newline. */
+int  fqd_extract_tags(fqd_engine* e, const uint8_t* text, const uint64_t* id_start, const uint32_t* id_len,
+                      uint64_t n, uint64_t* tag_off, uint32_t* tag_len);
+
+/* perm[k] (n uint32) = index of the record with the k-th smallest tag in the order of
+ * FastqViewWithId::cmp: bytewise over the shorter length, shorter first on a tie; equal tags keep
+ * their input order.  Replaces ExternalSorter<T>::sort. */
 int  fqd_sort_tags(fqd_engine* e, const fqd_tags* t, uint32_t* perm);
 
-/* The equality branch of the merge-join (hpp:283-309) for two tag-sorted files: match[k]
- * (device, a->n uint32) = position in perm_b of the record of b whose tag equals the tag of
- * a's record perm_a[k], or 0xFFFFFFFF when b has none. */
-int  fqd_match_sorted_tags(fqd_engine* e, const fqd_tags* a, const uint32_t* perm_a,
-                           const fqd_tags* b, const uint32_t* perm_b, uint32_t* match);
+/* Result arrays of fqd_join_tags (device memory provided by the caller). */
+typedef struct fqd_join {
+    uint32_t* perm_a;    /* a->n: record of file 1 with the i-th smallest tag                    */
+    uint32_t* perm_b;    /* b->n: the same for file 2                                            */
+    uint32_t* match_a;   /* a->n: sorted position in file 2 of the partner of sorted record i,
+                            0xFFFFFFFF when it has none                                          */
+    uint32_t* match_b;   /* b->n: sorted position in file 1 of the partner, or 0xFFFFFFFF        */
+    uint32_t* pair_a;    /* min(a->n, b->n): record of file 1 of the k-th pair, in tag order     */
+    uint32_t* pair_b;    /* min(a->n, b->n): record of file 2 of the k-th pair                   */
+    uint64_t* n_pairs;   /* HOST: number of pairs                                                */
+} fqd_join;
+
+/* The merge-join of two tag-sorted files (hpp:283-309) without the sorted files: record x of
+ * file 1 and record y of file 2 are a pair iff their tags are equal and they have the same rank
+ * among the records with that tag in their files (k-th with k-th, which is what the merge loop
+ * does to repeated IDs).  This is the FULL inner join; the reference's end-of-file rule
+ * (hpp:281,317-340) only ever drops the last pair and is applied by the caller from
+ * perm/match.  Returns after the stream has drained (n_pairs is known). */
+int  fqd_join_tags(fqd_engine* e, const fqd_tags* a, const fqd_tags* b, const fqd_join* out);
+
+/* off_out[k] = off_table[idx[k]], len_out[k] = len_table[idx[k]] for k < n: turns a pair list into
+ * the ragged sequence descriptors (fqd_reads.offsets / lengths) of a dedup batch in tag order. */
+int  fqd_gather_seqs(fqd_engine* e, const uint32_t* idx, uint64_t n, const uint64_t* off_table,
+                     const uint32_t* len_table, uint64_t* off_out, uint32_t* len_out);
 
 /* keep_out[origin[k]] = flags[k] for k < n: puts the flags that came back from the
  * owners (in partition order) into input order.  All device pointers. */

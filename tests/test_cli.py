@@ -275,6 +275,90 @@ def test_gz_in_and_out(exe, oracle, tmp_path):
     assert "out of which 0 duplicates were removed" in r.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("full_join", ["0", "1"])
+def test_unordered_repeated_ids_pair_rank_by_rank(exe, oracle, tmp_path, full_join):
+    """IDs repeated inside one file and inside both (every copy used to pair with the same
+    partner): the k-th copy in file 1 pairs with the k-th in file 2, leftovers are counted as
+    non-matching — the oracle's stable merge-join, byte for byte, -v lines included."""
+    rnd = random.Random(71)
+    seqs = random_reads(rnd, 400, 50, 20, 40)
+    ids1 = [b"x"] * 3 + [b"y"] + [b"dup%d" % (k % 17) for k in range(120)] + [b"u%d" % k for k in range(60)]
+    ids2 = [b"x"] + [b"y"] * 4 + [b"dup%d" % (k % 23) for k in range(150)] + [b"u%d" % k for k in range(30, 90)]
+    rnd.shuffle(ids1); rnd.shuffle(ids2)
+    f1, f2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    f1.write_bytes(fastq([(i + b" 1", seqs[k % 400]) for k, i in enumerate(ids1)]))
+    f2.write_bytes(fastq([(i + b" 2", seqs[(7 * k) % 400]) for k, i in enumerate(ids2)]))
+    e1, e2, g1, g2 = (tmp_path / x for x in ("e1.fq", "e2.fq", "g1.fq", "g2.fq"))
+    tot, dup, un = oracle.filter_paired(f1, f2, e1, e2, FASTQ, unordered=True, tail_rule=(full_join == "0"))
+    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", env={"FQD_FULL_JOIN": full_join})
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(g1, e1, shallow=False) and filecmp.cmp(g2, e2, shallow=False)
+    assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
+                        f"{un} Non-matching entries from both files were skipped.\n")
+    assert tot > 100 and un > 50
+
+
+def write_fastq_np(path, ids, seq_codes, gz):
+    """FASTQ of len(ids) records from a uint8 matrix of bases, written in slabs (keeps Python out of the
+    per-record loop for the base and quality lines)."""
+    import io
+    opener = (lambda p: gzip.open(p, "wb", compresslevel=1)) if gz else (lambda p: open(p, "wb"))
+    L = seq_codes.shape[1]
+    qual = b"I" * L
+    with opener(path) as f:
+        for lo in range(0, len(ids), 100000):
+            buf = io.BytesIO()
+            rows = seq_codes[lo:lo + 100000]
+            for k, row in enumerate(rows):
+                buf.write(b"@"); buf.write(ids[lo + k]); buf.write(b"\n"); buf.write(row.tobytes()); buf.write(b"\n+\n"); buf.write(qual); buf.write(b"\n")
+            f.write(buf.getvalue())
+
+
+@pytest.mark.gpu
+def test_config4_shape_gz_unordered_2m_pairs(exe, oracle, tmp_path):
+    """BASELINE configs[4] at a size the oracle finishes in seconds: paired-end FASTQ, .gz in AND
+    out, --unordered, Illumina-style IDs, file 2 shuffled, orphans on both sides, >= 2 M pairs:
+    CLI output bytes (inflated) and -v lines equal the oracle's (hash_dup_remover.hpp:257-347;
+    reference test/test_unordered.py:7-48 at 10 records)."""
+    rng = np.random.default_rng(404)
+    n, L = 2_150_000, 100
+    pool = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, L), dtype=np.uint8)]
+    parent = rng.integers(0, n, size=n)
+    is_dup = rng.random(n) < 0.2
+    src = np.where(is_dup, np.minimum(parent, np.arange(n)), np.arange(n))     # ~20 % copies of an earlier pair's mate 1
+    s1 = pool[src]
+    s2 = np.ascontiguousarray(pool[src][:, ::-1])                                 # mate 2 follows mate 1: pair duplicates
+    flip = rng.random(n) < 0.5
+    s2[is_dup & flip, 0] = ord("N")                                               # half of them differ in mate 2 only
+    ids1 = [b"A00123:45:HXXXXXXX:%d:%d:%d:%d 1:N:0:ACGT" % (1 + k % 4, 1101 + (k // 4) % 60, 1000 + (k * 7) % 30000, 1000 + k) for k in range(n)]
+    ids2 = [i[:-10] + b"2:N:0:ACGT" for i in ids1]
+    keep1 = np.ones(n, bool); keep1[rng.integers(0, n, 60000)] = False           # orphans on both sides
+    keep2 = np.ones(n, bool); keep2[rng.integers(0, n, 60000)] = False
+    keep1[-1] = keep2[-1] = True                                                  # both files end on the largest ID (SURVEY A.5)
+    i1 = np.nonzero(keep1)[0]; i2 = np.nonzero(keep2)[0]
+    i2 = i2[rng.permutation(len(i2))]                                             # file 2 in another order
+    f1, f2 = tmp_path / "r1.fq.gz", tmp_path / "r2.fq.gz"
+    write_fastq_np(f1, [ids1[k] for k in i1], s1[i1], True)
+    write_fastq_np(f2, [ids2[k] for k in i2], s2[i2], True)
+    e1, e2 = tmp_path / "e1.fq", tmp_path / "e2.fq"
+    g1, g2 = tmp_path / "g1.fq.gz", tmp_path / "g2.fq.gz"
+    tot, dup, un = oracle.filter_paired(f1, f2, e1, e2, FASTQ, unordered=True, tail_rule=True)
+    assert tot >= 2_000_000 and dup > 50_000 and un > 50_000
+    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", env={"FQD_GZ_LEVEL": "1"})
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
+                        f"{un} Non-matching entries from both files were skipped.\n")
+    for got, exp in ((g1, e1), (g2, e2)):
+        assert subprocess.run(["gzip", "-t", str(got)]).returncode == 0
+        with gzip.open(got, "rb") as a, open(exp, "rb") as b:
+            while True:
+                x, y = a.read(1 << 24), b.read(1 << 24)
+                assert x == y
+                if not x:
+                    break
+
+
 # ---------------------------------------------------------------- GPU: error behaviour (SURVEY Appendix A, C)
 
 def both(exe, oracle, tmp_path, data: bytes, fmt=FASTQ):

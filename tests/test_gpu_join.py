@@ -1,7 +1,7 @@
-"""GPU parity of the `--unordered` join primitives (fqd_sort_tags, fqd_match_sorted_tags)
-against the order and equality the reference defines (FastqViewWithId::cmp,
-fastqview.cpp:168-178 — pinned for the oracle in tests/test_oracle.py) and against the
-oracle's merge-join."""
+"""GPU parity of the `--unordered` join primitives (fqd_extract_tags, fqd_sort_tags, fqd_join_tags,
+fqd_gather_seqs: csrc/fqd_join.hip) against the order and equality the reference defines
+(FastqViewWithId::cmp / read_new, fastqview.cpp:168-204 — pinned for the oracle in
+tests/test_oracle.py) and against the oracle's merge-join (hash_dup_remover.hpp:279-340)."""
 import numpy as np
 import pytest
 import torch
@@ -9,6 +9,7 @@ import torch
 from fastq_dupaway_amd import Engine
 
 pytestmark = pytest.mark.gpu
+NONE = 0xFFFFFFFF
 
 
 def tag_arrays(tags):
@@ -30,12 +31,29 @@ def make_tags(rng, n, style):
         return [b"%d" % (k + 1) for k in range(n)]
     if style == "newline":
         return [b"read%07d\n" % k for k in range(n)]           # tags that run through the newline (no space in the ID)
+    if style == "wide":                                       # random bytes: every position needs 8 bits, keys of several words
+        return [bytes(rng.integers(1, 256, size=int(rng.integers(0, 30))).astype(np.uint8)) + b"|%d" % k for k in range(n)]
     # mixed lengths, shared prefixes, prefix-of-each-other cases
     base = [b"a", b"ab", b"abc", b"abcdefgh", b"abcdefghi", b"abcdefgh" * 3, b"abcdefgh" * 3 + b"x", b"b", b"", b"zz" * 20]
     return base + [bytes(rng.choice(list(b"abcXYZ019:"), size=int(rng.integers(0, 40))).astype(np.uint8)) + b"#%d" % k for k in range(n - len(base))]
 
 
-@pytest.mark.parametrize("style", ["illumina", "sra", "newline", "mixed"])
+def run_join(e, a, b):
+    """Full device join of two tag lists; returns host arrays."""
+    da, oa, la = tag_arrays(a); db, ob, lb = tag_arrays(b)
+    A = to_dev(da, oa, la); B = to_dev(db, ob, lb)
+    i32 = dict(dtype=torch.int32, device="cuda")
+    pa, ma = torch.empty(max(1, len(a)), **i32), torch.empty(max(1, len(a)), **i32)
+    pb, mb = torch.empty(max(1, len(b)), **i32), torch.empty(max(1, len(b)), **i32)
+    cap = max(1, min(len(a), len(b)))
+    qa, qb = torch.empty(cap, **i32), torch.empty(cap, **i32)
+    n_pairs = e.join_tags((*A, len(a)), (*B, len(b)), pa, pb, ma, mb, qa, qb)
+    h = lambda t, n: t.cpu().numpy().view(np.uint32)[:n]
+    return dict(perm_a=h(pa, len(a)), perm_b=h(pb, len(b)), match_a=h(ma, len(a)), match_b=h(mb, len(b)),
+                pair_a=h(qa, n_pairs), pair_b=h(qb, n_pairs), n_pairs=n_pairs)
+
+
+@pytest.mark.parametrize("style", ["illumina", "sra", "newline", "mixed", "wide"])
 def test_sort_tags_matches_reference_order(oracle, style):
     rng = np.random.default_rng(5)
     n = 20000
@@ -66,29 +84,141 @@ def test_sort_is_stable_for_equal_tags():
     assert perm.cpu().tolist() == [1, 3, 4, 0, 2, 5]
 
 
-@pytest.mark.parametrize("tail_rule", [False, True])
-def test_match_gives_the_oracles_join(oracle, tail_rule):
+@pytest.mark.parametrize("style", ["illumina", "wide"])
+def test_join_gives_the_oracles_full_join(oracle, style):
     rng = np.random.default_rng(9)
     n = 30000
-    ids = make_tags(rng, n, "illumina")
+    ids = make_tags(rng, n, style)
     a = [ids[i] for i in rng.permutation(n) if rng.random() < 0.9]
     b = [ids[i] for i in rng.permutation(n) if rng.random() < 0.8]
-    da, oa, la = tag_arrays(a); db, ob, lb = tag_arrays(b)
-    A = to_dev(da, oa, la); B = to_dev(db, ob, lb)
-    pa = torch.empty(len(a), dtype=torch.int32, device="cuda"); pb = torch.empty(len(b), dtype=torch.int32, device="cuda")
-    match = torch.empty(len(a), dtype=torch.int32, device="cuda")
     with Engine(segments=2) as e:
-        e.sort_tags(*A, len(a), pa); e.sort_tags(*B, len(b), pb)
-        e.match_sorted_tags((*A, len(a)), pa, (*B, len(b)), pb, match)
+        j = run_join(e, a, b)
+    pos_b = {b[r]: k for k, r in enumerate(j["perm_b"])}
+    pos_a = {a[r]: k for k, r in enumerate(j["perm_a"])}
+    assert all(j["match_a"][k] == pos_b.get(a[j["perm_a"][k]], NONE) for k in range(len(a)))
+    assert all(j["match_b"][k] == pos_a.get(b[j["perm_b"][k]], NONE) for k in range(len(b)))
+    i1, i2, un = oracle.join_tags(*tag_arrays(a), *tag_arrays(b), tail_rule=False)
+    assert list(zip(j["pair_a"].tolist(), j["pair_b"].tolist())) == list(zip(i1.tolist(), i2.tolist()))
+    assert un == len(a) + len(b) - 2 * j["n_pairs"]
+
+
+def test_join_pairs_repeated_ids_rank_by_rank(oracle):
+    """IDs repeated within a file (the reference's std::sort leaves their order unspecified; the
+    oracle's stable merge-join pairs the k-th with the k-th): runs longer than a scan tile included."""
+    rng = np.random.default_rng(17)
+    universe = [b"id%03d" % k for k in range(40)]
+    a = [universe[i] for i in rng.integers(0, 40, 3000)] + [b"hot"] * 5000 + [b"x", b"x", b"x"]
+    b = [universe[i] for i in rng.integers(0, 30, 2500)] + [b"hot"] * 7000 + [b"x"]
+    order_a, order_b = rng.permutation(len(a)), rng.permutation(len(b))
+    a = [a[i] for i in order_a]; b = [b[i] for i in order_b]
+    with Engine(segments=2) as e:
+        j = run_join(e, a, b)
+    i1, i2, un = oracle.join_tags(*tag_arrays(a), *tag_arrays(b), tail_rule=False)
+    assert list(zip(j["pair_a"].tolist(), j["pair_b"].tolist())) == list(zip(i1.tolist(), i2.tolist()))
+    assert un == len(a) + len(b) - 2 * j["n_pairs"]
+    # one-sided inputs
+    with Engine(segments=2) as e:
+        assert run_join(e, a, [])["n_pairs"] == 0
+        assert run_join(e, [], b)["n_pairs"] == 0
+        assert run_join(e, [b"same"] * 300, [b"same"] * 200)["n_pairs"] == 200
+        assert run_join(e, [b""] * 3, [b"", b"a"])["n_pairs"] == 1
+
+
+def ref_tag(line: bytes):
+    """FastqViewWithId::read_new (fastqview.cpp:190-204) restated: (offset, length) of the tag in the ID line."""
+    dot = line.find(b".")
+    start = dot + 1 if dot >= 0 else 1
+    sp = line.find(b" ", start)
+    return start, (sp if sp >= 0 else len(line)) - start
+
+
+def test_extract_tags_follows_the_reference_rule():
+    lines = [b"@r1\n", b"@SRR1.10 x y\n", b"@a:b:c 1:N:0\n", b"@\n", b"@x.\n", b"@x. y\n", b"@no_space_but.dot\n",
+             b"@two words.here z\n", b">fa.7 len=5\n", b"@M01:7:FC:1:1101:1000:2000 2:N:0:ACGT\n", b"@.\n", b"@. \n", b"@a b.c\n"]
+    rng = np.random.default_rng(3)
+    lines += [bytes(rng.choice(list(b"ab. :1"), size=int(rng.integers(0, 25))).astype(np.uint8)).replace(b"\n", b"") for _ in range(500)]
+    lines = [(l if l.startswith((b"@", b">")) else b"@" + l) for l in lines]
+    lines = [l if l.endswith(b"\n") else l + b"\n" for l in lines]
+    text = b"".join(l + b"ACGT\n+\nIIII\n" for l in lines)
+    starts, at = [], 0
+    for l in lines:
+        starts.append(at); at += len(l) + 12
+    d_text = torch.from_numpy(np.frombuffer(text + b"\0" * 16, dtype=np.uint8).copy()).cuda()
+    d_start = torch.tensor(starts, dtype=torch.int64, device="cuda")
+    d_len = torch.tensor([len(l) for l in lines], dtype=torch.int32, device="cuda")
+    off = torch.empty(len(lines), dtype=torch.int64, device="cuda"); ln = torch.empty(len(lines), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    with Engine(segments=2) as e:
+        e.extract_tags(d_text, d_start, d_len, len(lines), off, ln)
         e.sync()
-    pa_h = pa.cpu().numpy().view(np.uint32); pb_h = pb.cpu().numpy().view(np.uint32); m = match.cpu().numpy().view(np.uint32)
-    pos_b = {b[r]: k for k, r in enumerate(pb_h)}
-    for k in range(len(a)):
-        exp = pos_b.get(a[pa_h[k]], 0xFFFFFFFF)
-        assert m[k] == exp
-    # full join built from (perm, match) == the oracle's merge-join without the tail rule
-    if not tail_rule:
-        i1, i2, un = oracle.join_tags(da, oa, la, db, ob, lb, tail_rule=False)
-        got = [(int(pa_h[k]), int(pb_h[m[k]])) for k in range(len(a)) if m[k] != 0xFFFFFFFF]
-        assert got == list(zip(i1.tolist(), i2.tolist()))
-        assert un == len(a) + len(b) - 2 * len(got)
+    for k, l in enumerate(lines):
+        o, n = ref_tag(l)
+        assert (int(off[k]) - starts[k], int(ln[k])) == (o, n), l
+
+
+def digits(x, width):
+    """ASCII decimal, fixed width, of an int64 tensor -> uint8 [n, width]."""
+    cols = []
+    for _ in range(width):
+        cols.append((x % 10 + 48).to(torch.uint8)); x = x // 10
+    return torch.stack(cols[::-1], dim=1)
+
+
+@pytest.mark.parametrize("style", ["one_word", "two_words"])
+def test_join_at_50m_tags_per_side(style):
+    """configs[4] scale: ~50 M tags in each file, shuffled, ~10 % orphans on each side; expected order,
+    matches and pairs in closed form (torch sort of the numeric keys).  one_word: "r%09d\\n" (36 key
+    bits); two_words: a constant flow-cell prefix + 9 + 9 varying digits (72 key bits, two 64-bit
+    words, so the second word's pass re-gathers the tags through the permutation).
+    (Comparisons go through same(): a bare `assert torch.equal(...)` that fails makes pytest format two
+    50 M-element tensors, which looks like a hang.)"""
+    def same(x, y):
+        return bool(torch.equal(x, y))
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev); g.manual_seed(77)
+    n_ids = 56_000_000
+    ids = torch.arange(n_ids, dtype=torch.int64, device=dev)
+    if style == "one_word":
+        key = ids
+        body = torch.cat([torch.full((n_ids, 1), ord("r"), dtype=torch.uint8, device=dev), digits(ids, 9),
+                          torch.full((n_ids, 1), 10, dtype=torch.uint8, device=dev)], dim=1)
+    else:
+        f1 = (ids * 2654435761 + 12345) % 1_000_000_000      # 9 digits: f1 * 1e9 + ids stays inside int64
+        key = f1 * 1_000_000_000 + ids                       # fixed-width decimal fields: byte order = numeric order
+        prefix = torch.tensor(list(b"M01234:55:000000000-ABCDE:1:"), dtype=torch.uint8, device=dev).repeat(n_ids, 1)
+        body = torch.cat([prefix, digits(f1, 9), torch.full((n_ids, 1), ord("#"), dtype=torch.uint8, device=dev), digits(ids, 9)], dim=1)
+        del prefix, f1
+    width = body.shape[1]
+
+    def side(drop_mod, drop_rem):
+        keep = ids % drop_mod != drop_rem                    # ~10 % orphans, different ones per side
+        mine = ids[keep]
+        mine = mine[torch.randperm(mine.numel(), device=dev, generator=g)]
+        return mine
+    ida, idb = side(10, 3), side(10, 7)
+    na, nb = ida.numel(), idb.numel()
+    assert na > 50_000_000 and nb > 50_000_000
+    tags_a = body[ida].contiguous().view(-1); tags_b = body[idb].contiguous().view(-1)
+    del body
+    off_a = torch.arange(na, dtype=torch.int64, device=dev) * width; off_b = torch.arange(nb, dtype=torch.int64, device=dev) * width
+    len_a = torch.full((na,), width, dtype=torch.int32, device=dev); len_b = torch.full((nb,), width, dtype=torch.int32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    pa, ma, pb, mb = torch.empty(na, **i32), torch.empty(na, **i32), torch.empty(nb, **i32), torch.empty(nb, **i32)
+    qa, qb = torch.empty(min(na, nb), **i32), torch.empty(min(na, nb), **i32)
+    torch.cuda.synchronize()              # the engine runs on its own stream: torch's kernels that built the tags must be done
+    with Engine(segments=2) as e:
+        n_pairs = e.join_tags((tags_a, off_a, len_a, na), (tags_b, off_b, len_b, nb), pa, pb, ma, mb, qa, qb)
+    # expected: each side ordered by key; a record has a partner iff its id survives on the other side
+    exp_pa = torch.argsort(key[ida]); exp_pb = torch.argsort(key[idb])
+    assert same(pa.long(), exp_pa) and same(pb.long(), exp_pb)
+    common = (ids % 10 != 3) & (ids % 10 != 7)
+    assert n_pairs == int(common.sum())
+    sorted_ids_a = ida[exp_pa]; sorted_ids_b = idb[exp_pb]
+    has_a = common[sorted_ids_a]; has_b = common[sorted_ids_b]
+    assert same(ma.long() != -1, has_a)                                             # int32 view: -1 = none
+    # the k-th pair is the k-th common id in key order on both sides
+    assert same(ida[qa[:n_pairs].long()], sorted_ids_a[has_a])
+    assert same(idb[qb[:n_pairs].long()], sorted_ids_b[has_b])
+    # partners point at each other
+    k = torch.nonzero(has_a)[:, 0]
+    assert same(mb[ma[k].long()].long(), k)

@@ -78,7 +78,7 @@ class _Seg:
         self.bases = bases
 
 
-def _gloo_worker(rank, world, port, reads, result_dir):
+def _gloo_worker(rank, world, port, reads, result_dir, max_message=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -86,6 +86,8 @@ def _gloo_worker(rank, world, port, reads, result_dir):
     try:
         steps, _, n_per, _ = reads.shape
         sd = ShardedDedup(NumpyOps(), dist, torch.device("cpu"), n_max=n_per, len0=L)
+        if max_message:
+            sd.MAX_MESSAGE = max_message              # force the exchange into several passes of slices
         out = np.zeros((steps, n_per), np.uint8)
         for st in range(steps):
             keep = torch.zeros(n_per, dtype=torch.uint8)
@@ -103,12 +105,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_exchange_under_gloo(oracle, tmp_path, world):
+@pytest.mark.parametrize("world,max_message", [(2, None), (3, None), (2, 3000), (3, 1000)])
+def test_sharded_exchange_under_gloo(oracle, tmp_path, world, max_message):
+    """max_message: a rank-to-rank message is ~600/world records x 64 B here, so a cap of 1-3 kB cuts every
+    exchange (keys out, flags back) into 3-20 passes of slices (ShardedDedup._all_to_all)."""
     import torch.multiprocessing as mp
     n_per, steps = 600, 3
     reads = make_global_reads(world, n_per, steps, seed=world)
-    mp.spawn(_gloo_worker, args=(world, _free_port(), reads, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_gloo_worker, args=(world, _free_port(), reads, str(tmp_path), max_message), nprocs=world, join=True)
     got = np.stack([np.load(tmp_path / f"keep{r}.npy") for r in range(world)], axis=1)     # [step][rank][i]
     # the ragged step dropped the last 7 reads of rank 1 in step 1: remove them from the oracle's input too
     mask = np.ones((steps, world, n_per), bool); mask[1, 1, n_per - 7:] = False
@@ -156,6 +160,12 @@ class ThreadDist:
             pos += chunk.numel()
         torch.cuda.synchronize()
         self.barrier.wait()
+
+    def all_gather_into_tensor(self, output, input):
+        torch.cuda.synchronize()
+        parts = self._share(input.clone())
+        output.copy_(torch.cat([p.reshape(-1) for p in parts]))
+        torch.cuda.synchronize()
 
     def _share(self, obj):
         self.slots[self.local.rank] = obj

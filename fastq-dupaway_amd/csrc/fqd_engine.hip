@@ -54,6 +54,7 @@ struct fqd_engine {
     uint32_t tag_mask = 0;                           // slot tag = (hash >> 32) & tag_mask (slot_tag)
     const uint64_t* hashed_records = nullptr;        // fqd_encode_uniform's last output whose hashes still lie in `hashes`
     uint64_t hashed_n = 0; uint32_t hashed_rec_words = 0;
+    bool     table_exact = false;                    // sized once for a known total (capacity hint): may run denser than 50 %
     bool     table_clear = false;                    // every slot is EMPTY right now
     bool     table_stale = false;                    // contents are garbage: clear (or rebuild) before use
     DevBuf   bulk_recs, bulk_meta;                   // scratch of the bulk (partitioned) insert
@@ -245,8 +246,15 @@ uint32_t tag_mask_for(uint64_t slots, uint32_t seg_bits)
 // otherwise grow geometrically so rehashes stay rare.
 int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
 {
-    if (e->slots >= 2 * records_after && e->slots) return FQD_OK;
-    const uint64_t want = std::max<uint64_t>(pow2_at_least((exact ? 2 : 4) * records_after), 1ull << 16);
+    // Load limit: 50 % (a table grows 4x so rehashes stay rare).  A table sized for a KNOWN total
+    // (capacity hint) may run denser, FQD_TABLE_PCT slots per 100 records: segments are probed in
+    // LDS by the bulk path, where longer probe runs cost little and every slot not allocated is 8
+    // bytes of table the dedup kernel does not write back.
+    static const uint64_t exact_pct = [] { const char* v = std::getenv("FQD_TABLE_PCT"); const long x = v ? std::atol(v) : 200; return uint64_t(x < 115 ? 115 : (x > 400 ? 400 : x)); }();
+    const uint64_t min_slots = e->table_exact ? (records_after * exact_pct + 99) / 100 : 2 * records_after;
+    if (e->slots >= min_slots && e->slots) return FQD_OK;
+    e->table_exact = exact;
+    const uint64_t want = std::max<uint64_t>(pow2_at_least(exact ? (records_after * exact_pct + 99) / 100 : 4 * records_after), 1ull << 16);
     void* nt = nullptr;
     HIP_TRY(e, hipMalloc(&nt, want * sizeof(uint64_t)));
     const uint32_t new_seg_bits = seg_bits_for(want);

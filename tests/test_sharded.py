@@ -294,6 +294,60 @@ def test_sharded_on_gpu_with_virtual_ranks(oracle, monkeypatch, world, paired, w
 
 
 @pytest.mark.gpu
+def test_config3_shape_8_virtual_ranks_100m_reads(oracle):
+    """BASELINE configs[3] as far as one card goes: 8 virtual ranks (threads sharing the GPU, the
+    all-to-all emulated in-process) with the real kernels behind HipOps, 104 M reads in all = 13 M per
+    rank in 4 pipelined-order rounds.  Global input order is (round, rank, position); the generator's
+    closed-form flags must come out on every rank, and the first 4 M reads in that order must equal the
+    CPU oracle's flags."""
+    from fastq_dupaway_amd import Engine, Reads
+    from fastq_dupaway_amd.sharded import HipOps
+    world, rounds, n_round, LL = 8, 4, 3_250_000, 150
+    dev = torch.device("cuda", 0)
+    gen = Engine(segments=1)
+    bases = [[torch.empty(n_round * LL + 16, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(rounds)]
+    expect = [[torch.empty(n_round, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(rounds)]
+    for k in range(rounds):
+        for r in range(world):
+            gen.synth_reads(99, (k * world + r) * n_round, n_round, LL, 200, 0, bases[k][r], expect[k][r])
+    gen.sync(); gen.close()
+    keeps = [[torch.zeros(n_round, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(rounds)]
+    tdist = ThreadDist(world)
+    errors = []
+
+    def worker(rank):
+        try:
+            tdist.bind(rank)
+            torch.cuda.set_device(0)
+            with Engine(segments=1, capacity_reads=int(rounds * n_round * 1.1)) as eng:
+                sd = ShardedDedup(HipOps(eng), tdist, dev, n_max=n_round, len0=LL)
+                for k in range(rounds):
+                    sd.dedup([Reads(bases[k][rank], uniform_len=LL, uniform_stride=LL)], n_round, keeps[k][rank])
+                    eng.sync()
+        except Exception as ex:                       # surface in the main thread
+            errors.append(ex)
+            tdist.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]; [t.join() for t in threads]
+    assert not errors, errors
+    total = rounds * world * n_round
+    assert total >= 100_000_000
+    dups = 0
+    for k in range(rounds):
+        for r in range(world):
+            assert bool(torch.equal(keeps[k][r], expect[k][r])), (k, r)
+            dups += int((expect[k][r] == 0).sum().item())
+    assert 0.15 * total < dups < 0.25 * total
+    # oracle on a prefix of the global order: round 0, ranks 0 and 1 (6.5 M reads) cut at 4 M
+    m = 4_000_000
+    host = torch.cat([bases[0][0][: n_round * LL], bases[0][1][: n_round * LL]])[: m * LL].cpu().numpy()
+    got = torch.cat([keeps[0][0], keeps[0][1]])[:m].cpu().numpy()
+    exp = oracle.dedup_single(np.concatenate([host, np.zeros(8, np.uint8)]), np.arange(m, dtype=np.uint64) * np.uint64(LL), np.full(m, LL, np.uint32))
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.gpu
 def test_partition_is_stable_and_complete():
     from fastq_dupaway_amd import Engine, Reads
     n, LL, parts = 100_003, 150, 8

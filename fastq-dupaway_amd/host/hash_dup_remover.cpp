@@ -15,6 +15,7 @@
 
 #include "fqdupaway.h"
 #include "id_join.hpp"
+#include "multi_gpu.hpp"
 
 namespace fqdhost {
 
@@ -76,7 +77,7 @@ struct Pinned {
         if (n <= cap) return;
         if (p) (void)hipHostFree(p);
         void* np = nullptr;
-        HIP_OK(hipHostMalloc(&np, std::max<size_t>(n, 1024) * sizeof(T), hipHostMallocDefault));
+        HIP_OK(hipHostMalloc(&np, std::max<size_t>(n, 1024) * sizeof(T), hipHostMallocPortable));
         p = static_cast<T*>(np); cap = std::max<size_t>(n, 1024);
     }
 };
@@ -196,8 +197,63 @@ struct Work {
     uint64_t emit_below = ~0ull;     // records at or beyond this pair index are not written
     bool stop = false;               // tells the writers to finish
     std::atomic<int> writers_left{0}; // one writer thread per output file
+    Channel<Work>* home = nullptr;   // pool the batch goes back to (multi-GPU runs: one pool per rank)
     Pinned<uint64_t> off[2]; Pinned<uint32_t> len[2]; Pinned<uint8_t> keep;
     Device<char> d_text[2]; Device<uint64_t> d_off[2]; Device<uint32_t> d_len[2]; Device<uint8_t> d_keep;
+};
+
+} // namespace
+
+namespace {
+
+// Writer threads (one per output file: gzip outputs deflate in parallel): survivors, verbatim, in
+// the order the batches are handed over.
+class SurvivorWriters {
+public:
+    SurvivorWriters(int S, std::unique_ptr<OutputFile>* sinks, Channel<Work>* recycle) : S_(S), sink_(sinks), recycle_(recycle)
+    {
+        for (int s = 0; s < S_; ++s) thread_[s] = std::thread([this, s] { body(s); });
+    }
+    void hand_over(Work* w) { w->writers_left.store(S_); for (int s = 0; s < S_; ++s) queue_[s].push(w); }
+    // `w`: a free Work used as the stop marker.
+    void stop(Work* w) { w->stop = true; hand_over(w); for (int s = 0; s < S_; ++s) thread_[s].join(); }
+    void rethrow() { for (int s = 0; s < S_; ++s) if (error_[s]) std::rethrow_exception(error_[s]); }
+private:
+    void body(int s)
+    {
+        bool failed_already = false;
+        std::vector<OutputFile::Piece> pieces;
+        for (;;) {
+            Work* w;
+            { StageClock::Scope t("writer: wait for a batch"); w = queue_[s].pop(); }
+            const bool stop = w->stop;
+            if (!stop && !failed_already) {
+                StageClock::Scope t("writer: write survivors");
+                try {
+                    const Block& b = *w->blk[s];
+                    pieces.clear();                          // runs of adjacent survivors, written where they lie
+                    const char* run_from = nullptr; size_t run_len = 0;
+                    for (size_t k = 0; k < w->n; ++k) {
+                        const RecordRef& r = b.recs[w->begin[s] + k];
+                        const bool keep = w->keep.p[k] != 0 && w->first_index + k < w->emit_below;
+                        if (keep) {
+                            const char* p = b.text.p + r.start;
+                            if (run_from && run_from + run_len == p) run_len += r.size;
+                            else { if (run_len) pieces.push_back({run_from, run_len}); run_from = p; run_len = r.size; }
+                        }
+                    }
+                    if (run_len) pieces.push_back({run_from, run_len});
+                    sink_[s]->write_pieces(pieces.data(), pieces.size());
+                } catch (...) { error_[s] = std::current_exception(); failed_already = true; }
+            }
+            if (!stop) w->blk[s]->release();
+            Channel<Work>* home = w->home ? w->home : recycle_;
+            if (w->writers_left.fetch_sub(1) == 1) home->push(w);
+            if (stop) break;
+        }
+    }
+    int S_; std::unique_ptr<OutputFile>* sink_; Channel<Work>* recycle_;
+    Channel<Work> queue_[2]; std::thread thread_[2]; std::exception_ptr error_[2];
 };
 
 } // namespace
@@ -236,49 +292,9 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
     Channel<Work> free_works;
     for (int k = 0; k < kWorks; ++k) { works.emplace_back(new Work()); works.back()->S = S; free_works.push(works.back().get()); }
 
-    // ---- writer threads (one per output file: gzip outputs deflate in parallel): survivors,
-    //      verbatim, in input order ----------------------------------------------------------
-    Channel<Work> to_write[2];
-    std::exception_ptr writer_error[2];
-    std::vector<OutputFile::Piece> pieces[2];
-    auto writer_body = [&](int s) {
-        bool failed_already = false;
-        for (;;) {
-            Work* w;
-            { StageClock::Scope t("writer: wait for a batch"); w = to_write[s].pop(); }
-            const bool stop = w->stop;
-            if (!stop && !failed_already) {
-                StageClock::Scope t("writer: write survivors");
-                try {
-                    const Block& b = *w->blk[s];
-                    pieces[s].clear();                       // runs of adjacent survivors, written where they lie
-                    const char* run_from = nullptr; size_t run_len = 0;
-                    for (size_t k = 0; k < w->n; ++k) {
-                        const RecordRef& r = b.recs[w->begin[s] + k];
-                        const bool keep = w->keep.p[k] != 0 && w->first_index + k < w->emit_below;
-                        if (keep) {
-                            const char* p = b.text.p + r.start;
-                            if (run_from && run_from + run_len == p) run_len += r.size;
-                            else { if (run_len) pieces[s].push_back({run_from, run_len}); run_from = p; run_len = r.size; }
-                        }
-                    }
-                    if (run_len) pieces[s].push_back({run_from, run_len});
-                    sink[s]->write_pieces(pieces[s].data(), pieces[s].size());
-                } catch (...) { writer_error[s] = std::current_exception(); failed_already = true; }
-            }
-            if (!stop) w->blk[s]->release();
-            if (w->writers_left.fetch_sub(1) == 1) free_works.push(w);
-            if (stop) break;
-        }
-    };
-    std::thread writers[2];
-    for (int s = 0; s < S; ++s) writers[s] = std::thread(writer_body, s);
-    auto hand_to_writers = [&](Work* w) { w->writers_left.store(S); for (int s = 0; s < S; ++s) to_write[s].push(w); };
-    auto stop_writer = [&] {
-        Work* w = free_works.pop(); w->stop = true;
-        hand_to_writers(w);
-        for (int s = 0; s < S; ++s) writers[s].join();
-    };
+    SurvivorWriters writers(S, sink, &free_works);
+    auto hand_to_writers = [&](Work* w) { writers.hand_over(w); };
+    auto stop_writer = [&] { writers.stop(free_works.pop()); };
 
     uint64_t next_index = 0;
     bool bad_base = false; uint8_t bad_byte = 0; uint64_t bad_record = 0;
@@ -358,7 +374,7 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
         throw;
     }
     { StageClock::Scope t("main: drain writers"); stop_writer(); }
-    for (int s = 0; s < S; ++s) if (writer_error[s]) std::rethrow_exception(writer_error[s]);
+    writers.rethrow();
     { StageClock::Scope t("main: close outputs"); for (int s = 0; s < S; ++s) sink[s]->close(); }
     StageClock::report();
 
@@ -384,9 +400,197 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same ordered runs over several GPUs (FQD_DEVICES): multi_gpu.hpp.  Needs fixed-length reads in
+// equally spaced records (what a sequencer writes), because what travels between the GPUs are
+// fixed-size keys; anything else is refused with a clear message.
+void HashDupRemover::run_ordered_multi(int S, const std::string* in, const std::string* out)
+{
+    const std::vector<int>& devs = tuning_.devices;
+    const int N = static_cast<int>(devs.size());
+    std::unique_ptr<OutputFile> sink[2];
+    for (int s = 0; s < S; ++s) sink[s] = std::make_unique<OutputFile>(out[s]);
+
+    Side side[2];
+    for (int s = 0; s < S; ++s) {
+        side[s].open_file(in[s], format_, S == 2, tuning_.block_bytes);
+        HIP_OK(hipSetDevice(devs[0]));
+        side[s].prime(4, devs[0]);
+        if (side[s].available() == 0 && side[s].failed && !side[s].held_back) {
+            std::cerr << side[s].failure.diag;
+            throw std::runtime_error(side[s].failure.what);
+        }
+    }
+
+    // one rank per listed GPU: stream, engine, exchange buffers, its own pool of batches
+    struct Rank {
+        int device = 0; hipStream_t stream = nullptr; std::unique_ptr<EngineHandle> eng;
+        Device<uint64_t> records, grouped, counts; Device<uint32_t> origin; Device<uint8_t> keep_recv, keep_back;
+        Pinned<uint64_t> h_counts;
+        Channel<Work> pool; std::vector<std::unique_ptr<Work>> works;
+        uint64_t* slot = nullptr;                              // where this round's keys are received (tail of the key store)
+        ~Rank() { eng.reset(); if (stream) { (void)hipSetDevice(device); (void)hipStreamDestroy(stream); } }
+    };
+    std::vector<std::unique_ptr<Rank>> rank;
+    std::vector<hipStream_t> streams;
+    for (int r = 0; r < N; ++r) {
+        rank.emplace_back(new Rank());
+        Rank& k = *rank.back();
+        k.device = devs[r];
+        HIP_OK(hipSetDevice(k.device));
+        HIP_OK(hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking));
+        k.eng = std::make_unique<EngineHandle>(S, k.device, k.stream);
+        k.h_counts.reserve(static_cast<size_t>(N));
+        for (int w = 0; w < 2; ++w) { k.works.emplace_back(new Work()); k.works.back()->S = S; k.works.back()->home = &k.pool; k.pool.push(k.works.back().get()); }
+        streams.push_back(k.stream);
+    }
+    std::unique_ptr<Exchange> exchange = Exchange::create(devs, streams, tuning_.use_rccl);
+    auto sync_all = [&] { for (auto& k : rank) { HIP_OK(hipSetDevice(k->device)); HIP_OK(hipStreamSynchronize(k->stream)); } };
+    auto engine_ok = [&](Rank& k, int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(k.eng->e)); };
+
+    Channel<Work> spare;                                       // only the stop marker lives here
+    Work stop_marker; stop_marker.S = S; stop_marker.home = &spare;
+    SurvivorWriters writers(S, sink, &spare);
+
+    uint64_t next_index = 0, total_dups = 0;
+    bool bad_base = false; uint8_t bad_byte = 0;
+    uint32_t len0 = 0, len1 = 0, key_words = 0; bool have_shape = false;
+    constexpr size_t kMaxBatch = 8u << 20;
+    std::vector<Work*> round;
+    try {
+        while (!bad_base) {
+            // ---- deal the next batches to the ranks, in file order ----------------------------------
+            round.clear();
+            for (int r = 0; r < N; ++r) {
+                size_t n = kMaxBatch;
+                for (int s = 0; s < S; ++s) n = std::min(n, side[s].available());
+                if (n == 0) break;
+                Rank& k = *rank[r];
+                Work* w = k.pool.pop();
+                w->stop = false; w->n = n; w->first_index = next_index; w->emit_below = ~0ull;
+                HIP_OK(hipSetDevice(k.device));
+                w->keep.reserve(n); w->d_keep.reserve(n);
+                fqd_reads seg[2] = {};
+                for (int s = 0; s < S; ++s) {
+                    PooledBlock* b = side[s].cur;
+                    b->acquire();
+                    w->blk[s] = b; w->begin[s] = side[s].pos;
+                    const RecordRef* rr = &b->recs[side[s].pos];
+                    const uint64_t text_lo = rr[0].start, text_hi = rr[n - 1].start + rr[n - 1].size;
+                    const uint64_t stride = n > 1 ? rr[1].seq_start() - rr[0].seq_start() : rr[0].size;
+                    bool uniform = stride <= 0xFFFFFFFFull;
+                    for (size_t i = 1; i < n && uniform; ++i)
+                        uniform = rr[i].seq_len == rr[0].seq_len && rr[i].seq_start() - rr[i - 1].seq_start() == stride;
+                    const uint32_t L = rr[0].seq_len;
+                    if (!have_shape && s == S - 1) { /* set below */ }
+                    if (!uniform || (have_shape && L != (s ? len1 : len0))) {
+                        for (int q = 0; q <= s; ++q) w->blk[q]->release();
+                        k.pool.push(w);
+                        throw std::runtime_error("FQD_DEVICES: sharding over several GPUs needs reads of one fixed length in equally "
+                                                 "spaced records; this input is not (run it on one GPU: unset FQD_DEVICES)");
+                    }
+                    if (!have_shape) (s ? len1 : len0) = L;
+                    w->d_text[s].reserve(text_hi - text_lo + 32);
+                    HIP_OK(hipMemcpyAsync(w->d_text[s].p, b->text.p + text_lo, text_hi - text_lo, hipMemcpyHostToDevice, k.stream));
+                    seg[s].bases = reinterpret_cast<const uint8_t*>(w->d_text[s].p) + (rr[0].seq_start() - text_lo);
+                    seg[s].uniform_len = L; seg[s].uniform_stride = static_cast<uint32_t>(stride);
+                    side[s].pos += n;
+                }
+                if (!have_shape) { have_shape = true; key_words = fqd_key_words(len0, S == 2 ? len1 : 0); }
+                // encode + group by owner on this rank's GPU
+                k.records.reserve(n * (key_words + 1)); k.grouped.reserve(n * size_t(key_words)); k.origin.reserve(n); k.counts.reserve(static_cast<size_t>(N));
+                engine_ok(k, fqd_encode_uniform(k.eng->e, seg, n, k.records.p));
+                engine_ok(k, fqd_partition_keys(k.eng->e, k.records.p, n, key_words, static_cast<uint32_t>(N), k.grouped.p, k.counts.p, k.origin.p));
+                HIP_OK(hipMemcpyAsync(k.h_counts.p, k.counts.p, N * sizeof(uint64_t), hipMemcpyDeviceToHost, k.stream));
+                round.push_back(w);
+                next_index += n;
+            }
+            if (round.empty()) break;
+            const int R = static_cast<int>(round.size());     // ranks with a batch this round (the last round may be short)
+            // a byte outside {A,C,G,T,N} is noticed by the encoder of the rank that holds it
+            uint64_t bad_at = ~0ull;
+            for (int r = 0; r < R; ++r) {
+                const int rc = fqd_engine_sync(rank[r]->eng->e);
+                if (rc == FQD_ERR_BAD_BASE) {
+                    uint64_t rec; uint32_t sg, pos; uint8_t byte;
+                    fqd_bad_base(rank[r]->eng->e, &rec, &sg, &pos, &byte);
+                    if (round[r]->first_index + rec < bad_at) { bad_at = round[r]->first_index + rec; bad_byte = byte; }
+                } else engine_ok(*rank[r], rc);
+            }
+            if (bad_at != ~0ull) bad_base = true;             // the round is still finished: flags before the bad record are valid
+            // ---- keys to their owners: ONE all-to-all -----------------------------------------------
+            ExchangePlan plan(N);
+            for (int r = 0; r < R; ++r) for (int d = 0; d < N; ++d) plan.send[size_t(r) * N + d] = rank[r]->h_counts.p[d];
+            plan.finish();
+            std::vector<const void*> grouped(N, nullptr); std::vector<void*> received(N, nullptr);
+            for (int d = 0; d < N; ++d) {
+                Rank& k = *rank[d];
+                HIP_OK(hipSetDevice(k.device));
+                engine_ok(k, fqd_reserve_keys(k.eng->e, plan.n_recv[d], len0, S == 2 ? len1 : 0, &k.slot));
+                k.keep_recv.reserve(std::max<uint64_t>(1, plan.n_recv[d]));
+                grouped[d] = k.grouped.p; received[d] = k.slot;
+            }
+            sync_all();                                        // reserve may have regrown a key store on its stream
+            exchange->run(forward_transfers(plan, grouped, received, size_t(key_words) * sizeof(uint64_t)));
+            sync_all();
+            // ---- owners insert in (source rank, position) order; flags travel back ---------------------
+            std::vector<const void*> at_owner(N, nullptr); std::vector<void*> at_source(N, nullptr);
+            for (int d = 0; d < N; ++d) {
+                Rank& k = *rank[d];
+                HIP_OK(hipSetDevice(k.device));
+                if (plan.n_recv[d]) engine_ok(k, fqd_insert_keys(k.eng->e, k.slot, plan.n_recv[d], len0, S == 2 ? len1 : 0, k.keep_recv.p));
+                k.keep_back.reserve(std::max<uint64_t>(1, plan.n_send[d]));
+                at_owner[d] = k.keep_recv.p; at_source[d] = k.keep_back.p;
+            }
+            for (int d = 0; d < N; ++d) {
+                const int rc = fqd_engine_sync(rank[d]->eng->e);
+                if (!(rc == FQD_ERR_BAD_BASE && bad_base)) engine_ok(*rank[d], rc);      // an encoder's finding stays on its engine
+            }
+            exchange->run(backward_transfers(plan, at_owner, at_source, 1));
+            sync_all();
+            for (int r = 0; r < R; ++r) {
+                Rank& k = *rank[r]; Work* w = round[r];
+                HIP_OK(hipSetDevice(k.device));
+                engine_ok(k, fqd_scatter_flags(k.eng->e, k.keep_back.p, k.origin.p, w->n, w->d_keep.p));
+                HIP_OK(hipMemcpyAsync(w->keep.p, w->d_keep.p, w->n, hipMemcpyDeviceToHost, k.stream));
+            }
+            sync_all();
+            for (int r = 0; r < R; ++r) {
+                Work* w = round[r];
+                if (bad_base) w->emit_below = bad_at;
+                writers.hand_over(w);
+            }
+            round.clear();
+        }
+    } catch (...) {
+        for (Work* w : round) { for (int s = 0; s < S; ++s) if (w->blk[s]) w->blk[s]->release(); w->home->push(w); }
+        try { sync_all(); } catch (...) {}
+        writers.stop(&stop_marker);
+        throw;
+    }
+    { StageClock::Scope t("main: drain writers"); writers.stop(&stop_marker); }
+    writers.rethrow();
+    for (int s = 0; s < S; ++s) sink[s]->close();
+    StageClock::report();
+    for (auto& k : rank) { fqd_stats st{}; fqd_get_stats(k->eng->e, &st); total_dups += st.duplicates; }
+    if (bad_base) throw_unknown_base(bad_byte);
+    for (int s = 0; s < S; ++s) {
+        if (side[s].available() == 0 && side[s].failed && side[s].held_back) {
+            bool other_has = true;
+            if (S == 2) other_has = side[1 - s].has_record_here();
+            if (other_has) { std::cerr << side[s].failure.diag; throw std::runtime_error(side[s].failure.what); }
+        }
+    }
+    summary_.total = next_index; summary_.duplicates = total_dups; summary_.unmatched = 0;
+    if (verbose_) {
+        if (S == 1) std::cout << summary_.total << " reads processed, out of which " << summary_.duplicates << " duplicates were removed.\n";
+        else        std::cout << summary_.total << " read pairs processed, out of which " << summary_.duplicates << " duplicates were removed.\n";
+    }
+}
+
 void HashDupRemover::filterSE(const std::string& infile, const std::string& outfile)
 {
-    try { run_ordered(1, &infile, &outfile); }
+    try { if (tuning_.devices.empty()) run_ordered(1, &infile, &outfile); else run_ordered_multi(1, &infile, &outfile); }
     catch (const DiagnosedError& e) { std::cerr << e.diag; throw; }
 }
 
@@ -396,7 +600,8 @@ void HashDupRemover::filterPE(const std::string& infile1, const std::string& inf
     const std::string in[2] = {infile1, infile2}, out[2] = {outfile1, outfile2};
     try {
         if (unordered) run_unordered(in, out);
-        else           run_ordered(2, in, out);
+        else if (tuning_.devices.empty()) run_ordered(2, in, out);
+        else           run_ordered_multi(2, in, out);
     } catch (const DiagnosedError& e) { std::cerr << e.diag; throw; }
 }
 

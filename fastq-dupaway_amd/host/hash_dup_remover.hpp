@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <string>
 #include <sys/types.h>
+#include <vector>
 
 #include "records.hpp"
 
@@ -40,6 +41,11 @@ struct Tuning {
     // --unordered: true = the reference's merge-join including its end-of-file rule
     // (hash_dup_remover.hpp:281,317-340), false = full inner join.
     bool   reference_tail_rule = true;
+    // FQD_DEVICES=0,1,...: one engine per listed GPU, reads sharded by hash prefix with one all-to-all per
+    // round (multi_gpu.hpp).  Empty: the single-engine path on `device`.  use_rccl = false (FQD_EXCHANGE=copy):
+    // peer copies instead of RCCL.
+    std::vector<int> devices;
+    bool   use_rccl = true;
 };
 
 class HashDupRemover {
@@ -52,6 +58,7 @@ public:
     const Summary& summary() const { return summary_; }
 private:
     void run_ordered(int n_files, const std::string* in, const std::string* out);
+    void run_ordered_multi(int n_files, const std::string* in, const std::string* out);
     void run_unordered(const std::string* in, const std::string* out);
     Format              format_;
     ssize_t             memlimit_;

@@ -5,7 +5,8 @@
 // Sequence-based modes are not part of this build and are refused with a clear message.
 // Environment (extensions, none needed): FQD_DEVICE=<ordinal>, FQD_FULL_JOIN=1 (intended
 // full inner join for --unordered instead of the reference's end-of-file rule),
-// FQD_BLOCK_MB=<input block size>.
+// FQD_BLOCK_MB=<input block size>, FQD_DEVICES=<ordinal,ordinal,...> (one engine per listed GPU, reads
+// sharded by hash prefix with an RCCL all-to-all; FQD_EXCHANGE=copy: peer copies instead).
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -15,6 +16,7 @@
 #include <vector>
 
 #include "hash_dup_remover.hpp"
+#include "multi_gpu.hpp"
 
 namespace {
 
@@ -220,6 +222,8 @@ int main(int argc, char** argv)                                // main.cpp:181-2
                                      "run the sequence-based modes with the reference fastq-dupaway");
         fqdhost::Tuning tune;
         if (const char* d = std::getenv("FQD_DEVICE")) tune.device = std::atoi(d);
+        tune.devices = fqdhost::devices_from_env();
+        if (const char* x = std::getenv("FQD_EXCHANGE")) tune.use_rccl = std::string(x) != "copy";
         if (const char* j = std::getenv("FQD_FULL_JOIN")) tune.reference_tail_rule = !(j[0] == '1');
         if (const char* b = std::getenv("FQD_BLOCK_MB")) { const long mb = std::atol(b); if (mb > 0) tune.block_bytes = static_cast<size_t>(mb) << 20; }
         fqdhost::TemporaryDirectory tempdir;                   // main.cpp:192 (created lazily here)

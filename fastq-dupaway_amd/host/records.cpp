@@ -218,7 +218,7 @@ void PinnedBuffer::reserve(size_t bytes)
     if (bytes <= cap) return;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     void* np = nullptr;
-    if (hipHostMalloc(&np, bytes, hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc(&np, bytes, hipHostMallocPortable) != hipSuccess)
         throw std::runtime_error("cannot allocate pinned host memory for an input block");
     p = static_cast<char*>(np); cap = bytes;
 }

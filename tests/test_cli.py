@@ -359,6 +359,72 @@ def test_config4_shape_gz_unordered_2m_pairs(exe, oracle, tmp_path):
                     break
 
 
+# ---------------------------------------------------------------- GPU: several engines in one run (FQD_DEVICES)
+
+def uniform_fastq(rnd, n, L, pool, ident):
+    seqs = [bytes(rnd.choice(b"ACGTN") for _ in range(L)) for _ in range(pool)]
+    return fastq([(ident(k), rnd.choice(seqs)) for k in range(n)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,exchange", [("0,0", "copy"), ("0,0,0,0", "copy"), ("0", "rccl"), ("0", "copy")])
+def test_multi_gpu_cli_single_end_matches_oracle(exe, oracle, tmp_path, devices, exchange):
+    """The C++ driver's sharded path (host/multi_gpu.cpp): several ranks — here virtual ranks on the one
+    card, or one rank under real RCCL — batches dealt round-robin (FQD_BLOCK_MB=1 gives many rounds),
+    keys exchanged by hash prefix, flags back, survivors written in input order: same bytes and -v line
+    as the oracle."""
+    rnd = random.Random(81)
+    src = tmp_path / "in.fq"
+    src.write_bytes(uniform_fastq(rnd, 60000, 100, 9000, lambda k: b"r%07d" % k))
+    exp, got = tmp_path / "exp.fq", tmp_path / "got.fq"
+    tot, dup = oracle.filter_single(src, exp, FASTQ)
+    r = run(exe, "-i", src, "-o", got, "--fast", "-v", env={"FQD_DEVICES": devices, "FQD_EXCHANGE": exchange, "FQD_BLOCK_MB": "1"})
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(got, exp, shallow=False)
+    assert r.stdout == f"{tot} reads processed, out of which {dup} duplicates were removed.\n"
+    assert dup > 10000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,0,0", "0"])
+def test_multi_gpu_cli_paired_matches_oracle(exe, oracle, tmp_path, devices):
+    rnd = random.Random(82)
+    f1, f2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    f1.write_bytes(uniform_fastq(rnd, 40000, 80, 3000, lambda k: b"p%06d/1" % k))
+    f2.write_bytes(uniform_fastq(rnd, 40000, 60, 40, lambda k: b"p%06d/2" % k))
+    e1, e2, g1, g2 = (tmp_path / x for x in ("e1.fq", "e2.fq", "g1.fq", "g2.fq"))
+    tot, dup, _ = oracle.filter_paired(f1, f2, e1, e2, FASTQ)
+    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "-v", env={"FQD_DEVICES": devices, "FQD_BLOCK_MB": "1"})
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(g1, e1, shallow=False) and filecmp.cmp(g2, e2, shallow=False)
+    assert r.stdout == f"{tot} read pairs processed, out of which {dup} duplicates were removed.\n"
+    assert dup > 1000
+
+
+@pytest.mark.gpu
+def test_multi_gpu_cli_errors(exe, oracle, tmp_path):
+    rnd = random.Random(83)
+    # an unknown base in the middle: output cut at that record, the reference's two lines, exit 1
+    recs = [(b"r%05d" % k, bytes(rnd.choice(b"ACGT") for _ in range(50))) for k in range(30000)]
+    recs[17017] = (recs[17017][0], recs[17017][1][:20] + b"x" + recs[17017][1][21:])
+    src = tmp_path / "bad.fq"; src.write_bytes(fastq(recs))
+    exp, got = tmp_path / "exp.fq", tmp_path / "got.fq"
+    with pytest.raises(RuntimeError):
+        oracle.filter_single(src, exp, FASTQ)
+    r = run(exe, "-i", src, "-o", got, "--fast", env={"FQD_DEVICES": "0,0", "FQD_BLOCK_MB": "1"})
+    assert r.returncode == 1
+    assert r.stderr == ("Error: unknown character in DNA sequence: x\nAn error occured during fastq-dupaway execution:\n"
+                        "Supported sequence character set: {A, N, C, G, T}!\n")
+    assert got.read_bytes() == exp.read_bytes()
+    # reads of several lengths cannot be sharded: refused, not mangled
+    rag = tmp_path / "ragged.fq"
+    rag.write_bytes(fastq([(b"a", b"ACGT"), (b"b", b"ACGTA"), (b"c", b"ACG")]))
+    r = run(exe, "-i", rag, "-o", tmp_path / "o.fq", "--fast", env={"FQD_DEVICES": "0,0"})
+    assert r.returncode == 1 and "FQD_DEVICES" in r.stderr and "fixed length" in r.stderr
+    r = run(exe, "-i", rag, "-o", tmp_path / "o.fq", "--fast", env={"FQD_DEVICES": "0,x"})
+    assert r.returncode == 1 and "FQD_DEVICES" in r.stderr
+
+
 # ---------------------------------------------------------------- GPU: error behaviour (SURVEY Appendix A, C)
 
 def both(exe, oracle, tmp_path, data: bytes, fmt=FASTQ):

@@ -593,6 +593,120 @@ void gather_seq_kernel(const uint32_t* __restrict__ idx, uint64_t n, const uint6
 }
 
 // ---------------------------------------------------------------------------------------------
+// Support kernels of the bounded-memory `--unordered` run (host/hash_dup_remover.cpp,
+// run_unordered_streaming): the host streams both files through small pinned blocks; what the join
+// and the dedup need of every record — its tag and its sequence — is copied out of the uploaded block
+// into stores that stay in HBM, and where every surviving record goes in the output is computed here.
+
+// dst[dst_off[i] .. +len[i]) = src[src_off[i] .. +len[i]): 8 bytes at a time where both sides allow.
+__global__ __launch_bounds__(kBlock)
+void copy_spans_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ len,
+                       uint64_t n, uint8_t* __restrict__ dst, const uint64_t* __restrict__ dst_off)
+{
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
+        const uint8_t* __restrict__ a = src + src_off[i];
+        uint8_t* __restrict__ b = dst + dst_off[i];
+        const uint32_t L = len[i];
+        uint32_t k = 0;
+        for (; k + 8u <= L; k += 8u) { uint64_t w; __builtin_memcpy(&w, a + k, 8); __builtin_memcpy(b + k, &w, 8); }
+        for (; k < L; ++k) b[k] = a[k];
+    }
+}
+
+// Number of tags of `t` that are <= the tag `probe` (FastqViewWithId::cmp order).
+__global__ __launch_bounds__(kBlock)
+void count_le_kernel(fqd_tags t, const uint8_t* __restrict__ probe, uint32_t probe_len, unsigned long long* __restrict__ count)
+{
+    uint32_t c = 0;
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < t.n; i += uint64_t(gridDim.x) * kBlock) {
+        const uint8_t* __restrict__ a = t.bytes + t.offsets[i];
+        const uint32_t L = t.lengths[i], m = L < probe_len ? L : probe_len;
+        uint32_t k = 0;
+        while (k < m && a[k] == probe[k]) ++k;
+        const bool le = k < m ? a[k] < probe[k] : L <= probe_len;
+        c += le ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, static_cast<unsigned long long>(c));
+}
+
+// Output offsets: pair k (tag order) is written iff keep[k]; its record idx[k] of this file then
+// starts at the sum of the sizes of the kept records before it.  dest[] (per record of the file) is
+// preset to ~0 by the host code.
+constexpr int kOffTile = kBlock * 8;
+__global__ __launch_bounds__(kBlock)
+void out_sizes_kernel(const uint8_t* __restrict__ keep, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ sizes,
+                      unsigned long long* __restrict__ tile_sum)
+{
+    __shared__ unsigned long long ws[4];
+    const uint64_t base = uint64_t(blockIdx.x) * kOffTile + uint64_t(threadIdx.x) * 8u;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const uint64_t k = base + uint32_t(e); if (k < n && keep[k]) s += sizes[idx[k]]; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(1024)
+void u64_scan_kernel(unsigned long long* __restrict__ data, uint32_t n, unsigned long long* __restrict__ total)
+{
+    __shared__ unsigned long long wt[16];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t t0 = 0; t0 < n; t0 += 1024u) {
+        const uint32_t i = t0 + threadIdx.x;
+        const unsigned long long v = i < n ? data[i] : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(inc, d, 64); if (int(lane) >= d) inc += up; }
+        if (lane == 63u) wt[wave] = inc;
+        __syncthreads();
+        unsigned long long before = carry;
+        for (uint32_t w = 0; w < wave; ++w) before += wt[w];
+        if (i < n) data[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023u) carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(kBlock)
+void out_offsets_kernel(const uint8_t* __restrict__ keep, const uint32_t* __restrict__ idx, uint64_t n, const uint32_t* __restrict__ sizes,
+                        const unsigned long long* __restrict__ tile_start, unsigned long long* __restrict__ dest)
+{
+    __shared__ unsigned long long ws[4];
+    const uint64_t base = uint64_t(blockIdx.x) * kOffTile + uint64_t(threadIdx.x) * 8u;
+    uint32_t sz[8]; uint32_t rec[8];
+    unsigned long long s = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint64_t k = base + uint32_t(e);
+        sz[e] = 0; rec[e] = 0;
+        if (k < n && keep[k]) { rec[e] = idx[k]; sz[e] = sizes[rec[e]]; s += sz[e]; }
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(inc, d, 64); if (int(lane) >= d) inc += up; }
+    if (lane == 63u) ws[wave] = inc;
+    __syncthreads();
+    unsigned long long at = tile_start[blockIdx.x] + inc - s;
+    for (uint32_t w = 0; w < wave; ++w) at += ws[w];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint64_t k = base + uint32_t(e);
+        if (k < n && keep[k]) { dest[rec[e]] = at; at += sz[e]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 struct Carver {                                       // 256-byte aligned pieces of one scratch block
     char* p; size_t used = 0;
     template <class T> T* take(size_t count)
@@ -777,6 +891,71 @@ int fqd_join_tags(fqd_engine* e, const fqd_tags* a, const fqd_tags* b, const fqd
     if (out->n_pairs) *out->n_pairs = 0;
     if (a->n + b->n == 0) return FQD_OK;
     return run_join(e, a, b, out, nullptr);
+}
+
+int fqd_copy_spans(fqd_engine* e, const uint8_t* src, const uint64_t* src_off, const uint32_t* len, uint64_t n,
+                   uint8_t* dst, const uint64_t* dst_off)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (n && (!src || !src_off || !len || !dst || !dst_off)) return fqd_internal_fail(e, FQD_ERR_ARG, "fqd_copy_spans: bad arguments");
+    if (n == 0) return FQD_OK;
+    JOIN_TRY(e, hipSetDevice(fqd_internal_device(e)));
+    hipLaunchKernelGGL(copy_spans_kernel, dim3(grid_for(n, kBlock, 4096)), dim3(kBlock), 0, fqd_internal_stream(e), src, src_off, len, n, dst, dst_off);
+    JOIN_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+int fqd_count_tags_le(fqd_engine* e, const fqd_tags* t, const fqd_tags* other, uint64_t other_index, uint64_t* count)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!t || !other || !count || other_index >= other->n || (t->n && (!t->offsets || !t->lengths)))
+        return fqd_internal_fail(e, FQD_ERR_ARG, "fqd_count_tags_le: bad arguments");
+    *count = 0;
+    if (t->n == 0) return FQD_OK;
+    JOIN_TRY(e, hipSetDevice(fqd_internal_device(e)));
+    hipStream_t stream = fqd_internal_stream(e);
+    void* base = nullptr;
+    int rc = fqd_internal_scratch(e, 1, 4096, &base);
+    if (rc) return rc;
+    unsigned long long* d_count = static_cast<unsigned long long*>(base);
+    uint64_t off = 0; uint32_t len = 0;
+    JOIN_TRY(e, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream));
+    JOIN_TRY(e, hipMemcpyAsync(&off, other->offsets + other_index, sizeof off, hipMemcpyDeviceToHost, stream));
+    JOIN_TRY(e, hipMemcpyAsync(&len, other->lengths + other_index, sizeof len, hipMemcpyDeviceToHost, stream));
+    JOIN_TRY(e, hipStreamSynchronize(stream));
+    hipLaunchKernelGGL(count_le_kernel, dim3(grid_for(t->n, kBlock, 2048)), dim3(kBlock), 0, stream, *t, other->bytes + off, len, d_count);
+    unsigned long long got = 0;
+    JOIN_TRY(e, hipMemcpyAsync(&got, d_count, sizeof got, hipMemcpyDeviceToHost, stream));
+    JOIN_TRY(e, hipStreamSynchronize(stream));
+    *count = got;
+    return FQD_OK;
+}
+
+int fqd_output_offsets(fqd_engine* e, const uint8_t* keep, const uint32_t* idx, uint64_t n, const uint32_t* sizes,
+                       uint64_t* dest, uint64_t* total)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!total || (n && (!keep || !idx || !sizes || !dest))) return fqd_internal_fail(e, FQD_ERR_ARG, "fqd_output_offsets: bad arguments");
+    *total = 0;
+    if (n == 0) return FQD_OK;
+    JOIN_TRY(e, hipSetDevice(fqd_internal_device(e)));
+    hipStream_t stream = fqd_internal_stream(e);
+    const uint32_t tiles = uint32_t((n + kOffTile - 1) / kOffTile);
+    void* base = nullptr;
+    int rc = fqd_internal_scratch(e, 1, (size_t(tiles) + 2) * sizeof(unsigned long long), &base);
+    if (rc) return rc;
+    unsigned long long* tile = static_cast<unsigned long long*>(base);
+    unsigned long long* d_total = tile + tiles;
+    hipLaunchKernelGGL(out_sizes_kernel, dim3(tiles), dim3(kBlock), 0, stream, keep, idx, n, sizes, tile);
+    hipLaunchKernelGGL(u64_scan_kernel, dim3(1), dim3(1024), 0, stream, tile, tiles, d_total);
+    hipLaunchKernelGGL(out_offsets_kernel, dim3(tiles), dim3(kBlock), 0, stream, keep, idx, n, sizes,
+                       static_cast<const unsigned long long*>(tile), reinterpret_cast<unsigned long long*>(dest));
+    JOIN_TRY(e, hipGetLastError());
+    unsigned long long got = 0;
+    JOIN_TRY(e, hipMemcpyAsync(&got, d_total, sizeof got, hipMemcpyDeviceToHost, stream));
+    JOIN_TRY(e, hipStreamSynchronize(stream));
+    *total = got;
+    return FQD_OK;
 }
 
 int fqd_gather_seqs(fqd_engine* e, const uint32_t* idx, uint64_t n, const uint64_t* off_table, const uint32_t* len_table,

@@ -266,6 +266,25 @@ int  fqd_join_tags(fqd_engine* e, const fqd_tags* a, const fqd_tags* b, const fq
 int  fqd_gather_seqs(fqd_engine* e, const uint32_t* idx, uint64_t n, const uint64_t* off_table,
                      const uint32_t* len_table, uint64_t* off_out, uint32_t* len_out);
 
+/* ---- device halves of the bounded-memory `--unordered` run (host streams both files twice) ------
+ * dst[dst_off[i] .. +len[i]) = src[src_off[i] .. +len[i]) for i < n: copies what the join and the
+ * dedup need of every record (tag, sequence) out of an uploaded block into stores that stay in HBM. */
+int  fqd_copy_spans(fqd_engine* e, const uint8_t* src, const uint64_t* src_off, const uint32_t* len, uint64_t n,
+                    uint8_t* dst, const uint64_t* dst_off);
+
+/* *count (host) = number of records of t whose tag is <= the tag of record other_index of `other`, in
+ * the order of FastqViewWithId::cmp (fastqview.cpp:168-178): where the merge-join's other cursor
+ * stands when a record without a partner is consumed (the end-of-file rule needs it, hpp:281,317-340). */
+int  fqd_count_tags_le(fqd_engine* e, const fqd_tags* t, const fqd_tags* other, uint64_t other_index, uint64_t* count);
+
+/* Where the survivors go: pair k (tag order, k < n) is written iff keep[k]; dest[idx[k]] = sum of
+ * sizes[idx[j]] over the kept pairs j < k (byte offset of record idx[k] in this file's output), entries
+ * of records that are not written keep what the caller preset; *total (host) = output size in bytes.
+ * Replaces the sorted temporary files of the reference as the way records reach their place
+ * (external_sort.hpp:107-112,209-215). */
+int  fqd_output_offsets(fqd_engine* e, const uint8_t* keep, const uint32_t* idx, uint64_t n, const uint32_t* sizes,
+                        uint64_t* dest, uint64_t* total);
+
 /* keep_out[origin[k]] = flags[k] for k < n: puts the flags that came back from the
  * owners (in partition order) into input order.  All device pointers. */
 int  fqd_scatter_flags(fqd_engine* e, const uint8_t* flags, const uint32_t* origin, uint64_t n, uint8_t* keep_out);

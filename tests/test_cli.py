@@ -139,12 +139,13 @@ def test_paired_fast(exe, golden_dir, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["shuffled", "skewed", "deletion", "interleaved", "not_overlapped"])
 @pytest.mark.parametrize("full_join", ["0", "1"])
-def test_unordered(exe, golden_dir, tmp_path, name, full_join):
-    # reference test/test_unordered.py:7-48 (both join rules reproduce the fixtures)
+@pytest.mark.parametrize("mode", ["memory", "stream"])
+def test_unordered(exe, golden_dir, tmp_path, name, full_join, mode):
+    # reference test/test_unordered.py:7-48 (both join rules, and both ways of running the join, reproduce the fixtures)
     fx = golden_dir / "reference_fixtures"
     o1, o2 = tmp_path / "r1.fa", tmp_path / "r2.fa"
     r = run(exe, "-i", fx / "inputs" / f"unordered_{name}_r1.fa", "-u", fx / "inputs" / f"unordered_{name}_r2.fa",
-            "-o", o1, "-p", o2, *FAST, "--unordered", env={"FQD_FULL_JOIN": full_join})
+            "-o", o1, "-p", o2, *FAST, "--unordered", env={"FQD_FULL_JOIN": full_join, "FQD_UNORDERED_MODE": mode}, cwd=tmp_path)
     assert r.returncode == 0, r.stderr
     assert filecmp.cmp(o1, fx / "expected" / f"unordered_{name}_r1.fa", shallow=False)
     assert filecmp.cmp(o2, fx / "expected" / f"unordered_{name}_r2.fa", shallow=False)
@@ -214,10 +215,17 @@ def test_pe_fastq_matches_oracle_bytes(exe, oracle, tmp_path):
     assert r.stdout == f"{tot} read pairs processed, out of which {dup} duplicates were removed.\n"   # hpp:253-254
 
 
+STREAM_ENV = {"memory": {"FQD_UNORDERED_MODE": "memory"},
+              # the bounded-memory way: both files streamed twice in 1 MiB blocks, outputs assembled in 64 KiB windows
+              # through temporary files (hash_dup_remover.cpp: run_unordered_streaming)
+              "stream": {"FQD_UNORDERED_MODE": "stream", "FQD_BLOCK_MB": "1", "FQD_STREAM_WINDOW_KB": "64"}}
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["memory", "stream"])
 @pytest.mark.parametrize("style", ["illumina", "sra", "slash"])
 @pytest.mark.parametrize("full_join", ["0", "1"])
-def test_unordered_fastq_matches_oracle_bytes(exe, oracle, tmp_path, style, full_join):
+def test_unordered_fastq_matches_oracle_bytes(exe, oracle, tmp_path, style, full_join, mode):
     rnd = random.Random(51)
     n = 3000
     seqs1 = random_reads(rnd, n, 400, 20, 60); seqs2 = random_reads(rnd, n, 10, 20, 60)
@@ -237,11 +245,13 @@ def test_unordered_fastq_matches_oracle_bytes(exe, oracle, tmp_path, style, full
     e1, e2, g1, g2 = (tmp_path / x for x in ("e1.fq", "e2.fq", "g1.fq", "g2.fq"))
     tail = full_join == "0"
     tot, dup, un = oracle.filter_paired(f1, f2, e1, e2, FASTQ, unordered=True, tail_rule=tail)
-    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", env={"FQD_FULL_JOIN": full_join})
+    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", env={"FQD_FULL_JOIN": full_join, **STREAM_ENV[mode]},
+            cwd=tmp_path)
     assert r.returncode == 0, r.stderr
     assert filecmp.cmp(g1, e1, shallow=False) and filecmp.cmp(g2, e2, shallow=False)
     assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
                         f"{un} Non-matching entries from both files were skipped.\n")                # hpp:342-346
+    assert [p.name for p in tmp_path.iterdir() if p.is_dir()] == []                                  # the temporary directory is gone
     if style == "slash":
         assert tot == 0
     else:
@@ -276,8 +286,9 @@ def test_gz_in_and_out(exe, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["memory", "stream"])
 @pytest.mark.parametrize("full_join", ["0", "1"])
-def test_unordered_repeated_ids_pair_rank_by_rank(exe, oracle, tmp_path, full_join):
+def test_unordered_repeated_ids_pair_rank_by_rank(exe, oracle, tmp_path, full_join, mode):
     """IDs repeated inside one file and inside both (every copy used to pair with the same
     partner): the k-th copy in file 1 pairs with the k-th in file 2, leftovers are counted as
     non-matching — the oracle's stable merge-join, byte for byte, -v lines included."""
@@ -291,7 +302,8 @@ def test_unordered_repeated_ids_pair_rank_by_rank(exe, oracle, tmp_path, full_jo
     f2.write_bytes(fastq([(i + b" 2", seqs[(7 * k) % 400]) for k, i in enumerate(ids2)]))
     e1, e2, g1, g2 = (tmp_path / x for x in ("e1.fq", "e2.fq", "g1.fq", "g2.fq"))
     tot, dup, un = oracle.filter_paired(f1, f2, e1, e2, FASTQ, unordered=True, tail_rule=(full_join == "0"))
-    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", env={"FQD_FULL_JOIN": full_join})
+    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", env={"FQD_FULL_JOIN": full_join, **STREAM_ENV[mode]},
+            cwd=tmp_path)
     assert r.returncode == 0, r.stderr
     assert filecmp.cmp(g1, e1, shallow=False) and filecmp.cmp(g2, e2, shallow=False)
     assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
@@ -345,18 +357,26 @@ def test_config4_shape_gz_unordered_2m_pairs(exe, oracle, tmp_path):
     g1, g2 = tmp_path / "g1.fq.gz", tmp_path / "g2.fq.gz"
     tot, dup, un = oracle.filter_paired(f1, f2, e1, e2, FASTQ, unordered=True, tail_rule=True)
     assert tot >= 2_000_000 and dup > 50_000 and un > 50_000
-    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", env={"FQD_GZ_LEVEL": "1"})
-    assert r.returncode == 0, r.stderr
-    assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
-                        f"{un} Non-matching entries from both files were skipped.\n")
-    for got, exp in ((g1, e1), (g2, e2)):
-        assert subprocess.run(["gzip", "-t", str(got)]).returncode == 0
-        with gzip.open(got, "rb") as a, open(exp, "rb") as b:
-            while True:
-                x, y = a.read(1 << 24), b.read(1 << 24)
-                assert x == y
-                if not x:
-                    break
+    # in memory (the inputs inflate to ~1 GB: above the smallest --mem-limit, so "-m 500" alone would stream),
+    # then the bounded-memory way: "-m 500" = two passes over the .gz inputs, 125 MB output windows through
+    # temporary files in a directory created in the working directory (main.cpp:192) and removed at exit
+    for env, extra in (({"FQD_UNORDERED_MODE": "memory"}, []), ({}, ["-m", "500"])):
+        for g in (g1, g2):
+            g.unlink(missing_ok=True)
+        r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", *extra, env={"FQD_GZ_LEVEL": "1", "FQD_HOST_TIMING": "1", **env}, cwd=tmp_path)
+        assert r.returncode == 0, r.stderr
+        assert ("unordered/stream: pass 2" in r.stderr) == bool(extra), r.stderr
+        assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
+                            f"{un} Non-matching entries from both files were skipped.\n")
+        assert [p.name for p in tmp_path.iterdir() if p.is_dir()] == []
+        for got, exp in ((g1, e1), (g2, e2)):
+            assert subprocess.run(["gzip", "-t", str(got)]).returncode == 0
+            with gzip.open(got, "rb") as a, open(exp, "rb") as b:
+                while True:
+                    x, y = a.read(1 << 24), b.read(1 << 24)
+                    assert x == y
+                    if not x:
+                        break
 
 
 # ---------------------------------------------------------------- GPU: several engines in one run (FQD_DEVICES)

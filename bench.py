@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--pe-cpu-sample", type=int, default=2_000_000, help="pairs of the pe run checked against the CPU oracle")
-    ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads of the end-to-end CLI run (0 = skip)")
+    ap.add_argument("--e2e-reads", type=int, default=30_000_000, help="reads of the end-to-end CLI run (0 = skip)")
     ap.add_argument("--e2e-dir", default="", help="where the end-to-end FASTQ files go (default: a temp dir under /tmp)")
     ap.add_argument("--no-verify", action="store_true")
     return ap.parse_args()

@@ -6,6 +6,7 @@
 #include <fcntl.h>
 #include <algorithm>
 #include <iostream>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/uio.h>
 #include <thread>
@@ -307,6 +308,8 @@ OutputFile::OutputFile(const std::string& name) : gz_(has_gz_extension(name)), n
     } else {
         fd_ = ::open(name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
         if (fd_ < 0) throw_cannot_open(name);
+        struct stat st;
+        regular_ = ::fstat(fd_, &st) == 0 && S_ISREG(st.st_mode);
         plain_buf_.reserve(256 * 1024);
     }
 }
@@ -367,10 +370,48 @@ void OutputFile::write(const char* p, size_t n)
     }
 }
 
-void OutputFile::write_pieces(const Piece* pieces, size_t count)
+void OutputFile::write_pieces(const Piece* pieces, size_t count, unsigned threads)
 {
     if (gz_) { for (size_t k = 0; k < count; ++k) write(pieces[k].p, pieces[k].n); return; }
     flush_plain();
+    // A large batch into a regular file.  write()/pwrite() calls on ONE file are serialised by the
+    // kernel (the inode lock), so several writer threads gain nothing that way — measured: slower.  The
+    // batch's place in the file is known, though: reserve it (posix_fallocate: a full disk is reported
+    // here, as an error), map it, and let several threads copy their share of the pieces into the mapping;
+    // page-cache pages are then filled in parallel (measured on the GPU box, 5.4 GB of survivors: 1.26 s
+    // against 1.4-1.5 s for one writev stream; leaving the reservation out — ftruncate — was no faster).
+    // Anything that does not support this falls through to the plain writev below.
+    if (threads > 1 && regular_ && count >= 64) {
+        uint64_t total = 0;
+        for (size_t k = 0; k < count; ++k) total += pieces[k].n;
+        const off_t at = total >= (8u << 20) ? ::lseek(fd_, 0, SEEK_CUR) : off_t(-1);
+        if (at >= 0 && ::posix_fallocate(fd_, at, static_cast<off_t>(total)) == 0) {
+            static const uint64_t page = static_cast<uint64_t>(::sysconf(_SC_PAGESIZE));
+            const uint64_t lo = static_cast<uint64_t>(at) / page * page, lead = static_cast<uint64_t>(at) - lo;
+            void* map = ::mmap(nullptr, lead + total, PROT_READ | PROT_WRITE, MAP_SHARED, fd_, static_cast<off_t>(lo));
+            if (map != MAP_FAILED) {
+                char* dst = static_cast<char*>(map) + lead;
+                const unsigned T = static_cast<unsigned>(std::min<uint64_t>(threads, total >> 21));
+                std::vector<size_t> first(T + 1, count); std::vector<uint64_t> off(T + 1, total);
+                uint64_t run = 0; unsigned t = 0;
+                for (size_t k = 0; k < count && t < T; ++k) {
+                    if (run >= total / T * t) { first[t] = k; off[t] = run; ++t; }
+                    run += pieces[k].n;
+                }
+                auto part = [&](unsigned p) {
+                    char* q = dst + off[p];
+                    for (size_t k = first[p]; k < first[p + 1]; ++k) { std::memcpy(q, pieces[k].p, pieces[k].n); q += pieces[k].n; }
+                };
+                std::vector<std::thread> pool;
+                for (unsigned p = 1; p < T; ++p) pool.emplace_back(part, p);
+                part(0);
+                for (std::thread& th : pool) th.join();
+                ::munmap(map, lead + total);
+                if (::lseek(fd_, at + static_cast<off_t>(total), SEEK_SET) < 0) throw std::runtime_error("write failed: " + name_);
+                return;
+            }
+        }
+    }
     constexpr size_t kBatch = 1024;                          // IOV_MAX
     struct iovec iov[kBatch];
     size_t k = 0;
@@ -394,16 +435,18 @@ void OutputFile::close()
     if (!gz_) {
         if (fd_ < 0) return;
         flush_plain();
-        ::close(fd_);
+        const int fd = fd_;
         fd_ = -1;
+        if (::close(fd) != 0) throw std::runtime_error("write failed: " + name_);      // a full disk may only show here
         return;
     }
     if (!f_) return;
     submit_block();
     drain(0);
-    if (std::fwrite(kBgzfEof, 1, sizeof kBgzfEof, f_) != sizeof kBgzfEof) throw std::runtime_error("write failed: " + name_);
-    std::fclose(f_);
+    FILE* f = f_;
     f_ = nullptr;
+    const bool ok = std::fwrite(kBgzfEof, 1, sizeof kBgzfEof, f) == sizeof kBgzfEof && std::fflush(f) == 0;
+    if (std::fclose(f) != 0 || !ok) throw std::runtime_error("write failed: " + name_);   // the last buffer and the EOF member go out here
 }
 
 } // namespace fqdhost

@@ -70,7 +70,8 @@ public:
     void write(const char* p, size_t n);
     // Several pieces in one go: plain files hand them to writev() as they lie (no staging copy).
     struct Piece { const char* p; size_t n; };
-    void write_pieces(const Piece* pieces, size_t count);
+    // threads > 1: a large batch into a regular plain file is written by that many threads at once (pwritev).
+    void write_pieces(const Piece* pieces, size_t count, unsigned threads = 1);
     void close();
 private:
     void submit_block();
@@ -79,6 +80,7 @@ private:
     void put_plain(const char* p, size_t n);
     bool gz_; FILE* f_ = nullptr; std::string name_;
     int fd_ = -1;                                         // plain: raw descriptor + own 256 KiB buffer
+    bool regular_ = false;                                // plain: a regular file (seekable: parallel pwritev allowed)
     std::string plain_buf_;
     std::string block_;                                   // gz: bytes of the member being filled
     std::deque<std::future<std::string>> in_flight_;      // gz: members being deflated, oldest first

@@ -119,9 +119,9 @@ struct PooledBlock : Block {
 // scan) ahead of the consumer, which walks them with a cursor.
 struct Side {
     std::unique_ptr<RecordStream> stream;
-    Channel<PooledBlock> pool, ready;
+    Channel<PooledBlock> pool, raw, ready;
     std::vector<std::unique_ptr<PooledBlock>> storage;
-    std::thread reader;
+    std::thread reader, scanner;
     std::atomic<bool> stop{false};
     int device = 0;
     PooledBlock* cur = nullptr;      // block being consumed (holds one "feeder" reference)
@@ -142,6 +142,7 @@ struct Side {
             storage.back()->home = &pool;
             pool.push(storage.back().get());
         }
+        // two stages on two threads: `reader` fetches block k+1 from the file while `scanner` scans block k
         reader = std::thread([this] {
             (void)hipSetDevice(device);
             for (;;) {
@@ -150,9 +151,23 @@ struct Side {
                 if (!b || stop.load()) break;
                 b->error = nullptr; b->stream_end = false;
                 bool more = false;
-                try { more = stream->fill(*b); }
+                try { more = stream->read_raw(*b); }
+                catch (...) { b->error = std::current_exception(); raw.push(b); break; }
+                if (!more) { b->stream_end = true; raw.push(b); break; }
+                const bool last = b->raw_eof;
+                raw.push(b);
+                if (last) break;
+            }
+        });
+        scanner = std::thread([this] {
+            (void)hipSetDevice(device);
+            for (;;) {
+                PooledBlock* b;
+                { StageClock::Scope t("scanner: wait for a raw block"); b = raw.pop(); }
+                if (!b) break;
+                if (b->error || b->stream_end) { ready.push(b); break; }
+                try { stream->finish(*b); }
                 catch (...) { b->error = std::current_exception(); ready.push(b); break; }
-                if (!more) { b->stream_end = true; ready.push(b); break; }
                 const bool last = b->last;
                 ready.push(b);
                 if (last) break;
@@ -163,6 +178,7 @@ struct Side {
     void shutdown()
     {
         if (reader.joinable()) { stop.store(true); pool.push(nullptr); reader.join(); }
+        if (scanner.joinable()) { raw.push(nullptr); scanner.join(); }
     }
     // Makes `cur` a block with unread records, or marks the side ended.
     void advance()
@@ -208,6 +224,12 @@ namespace {
 
 // Writer threads (one per output file: gzip outputs deflate in parallel): survivors, verbatim, in
 // the order the batches are handed over.
+unsigned write_threads()
+{
+    static const unsigned t = [] { const char* v = std::getenv("FQD_WRITE_THREADS"); const int x = v ? std::atoi(v) : 0; return x > 0 ? unsigned(x) : std::min(4u, host_threads()); }();
+    return t;
+}
+
 class SurvivorWriters {
 public:
     SurvivorWriters(int S, std::unique_ptr<OutputFile>* sinks, Channel<Work>* recycle) : S_(S), sink_(sinks), recycle_(recycle)
@@ -243,7 +265,7 @@ private:
                         }
                     }
                     if (run_len) pieces.push_back({run_from, run_len});
-                    sink_[s]->write_pieces(pieces.data(), pieces.size());
+                    sink_[s]->write_pieces(pieces.data(), pieces.size(), write_threads());
                 } catch (...) { error_[s] = std::current_exception(); failed_already = true; }
             }
             if (!stop) w->blk[s]->release();

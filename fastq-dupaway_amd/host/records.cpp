@@ -27,7 +27,7 @@ namespace {
 
 // The scanner proper; emit(record) receives every complete, well-formed record in order.
 template <class Emit>
-size_t scan_core(Format f, bool want_tag, const char* text, size_t n, Emit&& emit, ParseFailure& fail)
+size_t scan_core(Format f, bool want_tag, const char* text, size_t n, Emit&& emit, ParseFailure& fail, uint64_t start_base = 0)
 {
     const char* const base = text;
     const char* const end = text + n;
@@ -63,7 +63,7 @@ size_t scan_core(Format f, bool want_tag, const char* text, size_t n, Emit&& emi
             break;
         }
         RecordRef r;
-        r.start = static_cast<uint64_t>(p - base);
+        r.start = static_cast<uint64_t>(p - base) + start_base;
         r.size = static_cast<uint32_t>(size);
         r.id_len = static_cast<uint32_t>(len[0]);
         r.seq_len = static_cast<uint32_t>(len[1] - 1);
@@ -85,9 +85,9 @@ size_t scan_core(Format f, bool want_tag, const char* text, size_t n, Emit&& emi
 } // namespace
 
 size_t scan_records(Format f, bool want_tag, const char* text, size_t n,
-                    std::vector<RecordRef>& out, ParseFailure& fail)
+                    std::vector<RecordRef>& out, ParseFailure& fail, uint64_t start_base)
 {
-    return scan_core(f, want_tag, text, n, [&](const RecordRef& r) { out.push_back(r); }, fail);
+    return scan_core(f, want_tag, text, n, [&](const RecordRef& r) { out.push_back(r); }, fail, start_base);
 }
 
 namespace {
@@ -141,14 +141,14 @@ size_t count_newlines(const char* b, const char* e)
 } // namespace
 
 size_t scan_records_parallel(Format f, bool want_tag, const char* text, size_t n,
-                             std::vector<RecordRef>& out, ParseFailure& fail, unsigned threads)
+                             std::vector<RecordRef>& out, ParseFailure& fail, unsigned threads, uint64_t start_base)
 {
     static const size_t kMinSlice = [] {                   // FQD_SCAN_MIN_SLICE: test hook
         const char* v = std::getenv("FQD_SCAN_MIN_SLICE");
         return v ? static_cast<size_t>(std::max(1L, std::atol(v))) : size_t(4u << 20);
     }();
     const unsigned parts = static_cast<unsigned>(std::min<size_t>(threads, n / kMinSlice));
-    if (parts <= 1) return scan_records(f, want_tag, text, n, out, fail);
+    if (parts <= 1) return scan_records(f, want_tag, text, n, out, fail, start_base);
     const size_t n_lines = f == Format::Fastq ? 4 : 2;
 
     // 1. newlines per slice -> index of the line each slice starts in
@@ -190,7 +190,7 @@ size_t scan_records_parallel(Format f, bool want_tag, const char* text, size_t n
         const size_t room = first_rec[p + 1] - first_rec[p], off = start[p];
         size_t k = 0;
         consumed[p] = scan_core(f, want_tag, text + off, start[p + 1] - off,
-                                [&](const RecordRef& r) { if (k < room) { dst[k] = r; dst[k].start += off; } ++k; }, failed[p]);
+                                [&](const RecordRef& r) { if (k < room) dst[k] = r; ++k; }, failed[p], start_base + off);
         found[p] = k;
     });
     for (unsigned p = 0; p < parts; ++p) {
@@ -226,31 +226,54 @@ void PinnedBuffer::reserve(size_t bytes)
 RecordStream::RecordStream(const std::string& name, Format f, bool want_tag, size_t block_bytes)
     : file_(name), fmt_(f), want_tag_(want_tag), block_bytes_(block_bytes) {}
 
-bool RecordStream::fill(Block& b)
+// Stage 1: the next raw bytes of the file, behind kHeadroom bytes left free for what the block
+// before it carries over.  Touches only the file, so it can run ahead of stage 2.
+bool RecordStream::read_raw(Block& b)
 {
-    if (done_) return false;
-    b.recs.clear(); b.used = 0; b.last = false; b.failure = ParseFailure(); b.held_back = false; b.first_record = n_records_;
-    const size_t want = std::max(block_bytes_, carry_.size() + block_bytes_ / 2);
-    { StageClock::Scope t("reader: pinned alloc"); b.text.reserve(want + 16); }
-    size_t have = carry_.size();
-    if (have) std::memcpy(b.text.p, carry_.data(), have);
+    if (raw_done_) return false;
+    b.recs.clear(); b.used = 0; b.last = false; b.failure = ParseFailure(); b.held_back = false;
+    { StageClock::Scope t("reader: pinned alloc"); b.text.reserve(kHeadroom + block_bytes_ + 16); }
+    { StageClock::Scope t("reader: file read"); b.raw_len = file_.read(b.text.p + kHeadroom, block_bytes_, host_threads()); }
+    b.raw_eof = file_.eof();
+    if (b.raw_eof) raw_done_ = true;
+    return true;
+}
+
+// Stage 2, block after block in file order: the carried-over tail of the previous block goes in
+// front of the raw bytes, the whole is scanned, the incomplete tail is carried on.
+void RecordStream::finish(Block& b)
+{
+    b.first_record = n_records_;
+    if (done_) { b.last = true; return; }                                   // a block read ahead of a failure: nothing in it counts
+    size_t carry = carry_.size();
+    if (carry > kHeadroom) {                                                // a record of more than a MiB: make room the slow way
+        PinnedBuffer bigger;
+        bigger.reserve(carry + b.raw_len + 16);
+        std::memcpy(bigger.p + carry, b.text.p + kHeadroom, b.raw_len);
+        std::swap(bigger.p, b.text.p); std::swap(bigger.cap, b.text.cap);
+        std::memcpy(b.text.p, carry_.data(), carry);
+    } else if (carry) {
+        std::memcpy(b.text.p + kHeadroom - carry, carry_.data(), carry);
+    }
+    const size_t off = carry > kHeadroom ? 0 : kHeadroom - carry;
+    const char* text = b.text.p + off;
+    const size_t have = carry + b.raw_len;
     carry_.clear();
-    { StageClock::Scope t("reader: file read"); have += file_.read(b.text.p + have, want - have, host_threads()); }
     size_t consumed;
-    { StageClock::Scope t("reader: record scan"); consumed = scan_records_parallel(fmt_, want_tag_, b.text.p, have, b.recs, b.failure, host_threads()); }
+    { StageClock::Scope t("reader: record scan"); consumed = scan_records_parallel(fmt_, want_tag_, text, have, b.recs, b.failure, host_threads(), off); }
     if (b.failure.set) {
         b.last = true; done_ = true;
         if (!b.recs.empty()) { b.recs.pop_back(); b.held_back = true; }      // fetched by the lookahead, never processed
-    } else if (file_.eof()) {
+    } else if (b.raw_eof) {
         b.last = true; done_ = true;                                        // a trailing partial record is dropped
     } else {
         if (b.recs.size() < 2)                                              // one record larger than a whole block
             throw std::runtime_error("Not enough memory to read a single object!");
-        consumed = b.recs.back().start;                                     // re-scan the last record with the next block
+        consumed = b.recs.back().start - off;                               // re-scan the last record with the next block
         b.recs.pop_back();
-        carry_.assign(b.text.p + consumed, b.text.p + have);
+        carry_.assign(text + consumed, text + have);
     }
-    b.used = consumed;
+    b.used = off + consumed;
     n_records_ += b.recs.size();
     if (first_) {
         first_ = false;
@@ -259,6 +282,12 @@ bool RecordStream::fill(Block& b)
         if (b.recs.empty() && !b.failure.set)
             throw std::runtime_error("Not enough memory to read a single object!");
     }
+}
+
+bool RecordStream::fill(Block& b)
+{
+    if (done_ || !read_raw(b)) return false;
+    finish(b);
     return true;
 }
 

@@ -40,8 +40,9 @@ struct ParseFailure {
 
 // Scans complete records in text[0,n).  Appends to `out`, returns the bytes consumed
 // (start of the first incomplete record).  Stops at a malformed record and fills `fail`.
+// start_base is added to every RecordRef::start (text lies that far into its block).
 size_t scan_records(Format f, bool want_tag, const char* text, size_t n,
-                    std::vector<RecordRef>& out, ParseFailure& fail);
+                    std::vector<RecordRef>& out, ParseFailure& fail, uint64_t start_base = 0);
 
 // The same scan on several threads, with the same result: lines are counted per slice first, so
 // every slice knows which of its line starts begin a record (every 4th / 2nd line of the file),
@@ -49,7 +50,7 @@ size_t scan_records(Format f, bool want_tag, const char* text, size_t n,
 // malformed record wins, exactly as when scanning from the front.  Falls back to scan_records
 // for small inputs or threads <= 1.
 size_t scan_records_parallel(Format f, bool want_tag, const char* text, size_t n,
-                             std::vector<RecordRef>& out, ParseFailure& fail, unsigned threads);
+                             std::vector<RecordRef>& out, ParseFailure& fail, unsigned threads, uint64_t start_base = 0);
 
 // FQD_HOST_TIMING=1: wall time per host stage, summed over the run and printed to stderr at exit.
 struct StageClock {
@@ -96,7 +97,9 @@ struct PinnedBuffer {
 // One block of input: raw text of complete records + their index.
 struct Block {
     PinnedBuffer           text;
-    size_t                 used = 0;       // bytes of complete records in text
+    size_t                 used = 0;       // end of the complete records in text (they start at recs[0].start, not at 0)
+    size_t                 raw_len = 0;    // RecordStream stage 1: raw bytes read behind the headroom, and whether the file ended
+    bool                   raw_eof = false;
     std::vector<RecordRef> recs;
     uint64_t               first_record = 0;   // index of recs[0] within the file
     bool                   last = false;       // nothing follows (end of file or failure)
@@ -120,6 +123,12 @@ public:
     RecordStream(const std::string& name, Format f, bool want_tag, size_t block_bytes);
     // Fills b (reusing its memory); returns false when the stream had already ended.
     bool fill(Block& b);
+    // The same in two stages, so that a reader thread can fetch block k+1 from the file while another
+    // scans block k: read_raw (file only; false when the file had already ended) then finish (in file
+    // order: joins the block to its predecessor's carried-over tail and scans it).
+    static constexpr size_t kHeadroom = 1u << 20;
+    bool read_raw(Block& b);
+    void finish(Block& b);
     uint64_t records_so_far() const { return n_records_; }
 private:
     InputFile         file_;
@@ -128,7 +137,7 @@ private:
     size_t            block_bytes_;
     std::vector<char> carry_;              // incomplete record left over from the previous block
     uint64_t          n_records_ = 0;
-    bool              first_ = true, done_ = false;
+    bool              first_ = true, done_ = false, raw_done_ = false;
 };
 
 } // namespace fqdhost

@@ -87,6 +87,7 @@ struct fqd_engine {
     int fail_hip(const char* what, hipError_t err)
     {
         last_error = std::string(what) + ": " + hipGetErrorString(err);
+        (void)hipGetLastError();       // the runtime remembers the failure: a later launch check must not find it again
         return FQD_ERR_HIP;
     }
 };
@@ -613,6 +614,7 @@ int fqd_engine_create(const fqd_config* cfg, fqd_engine** out)
     e->cap_hint_reads = cfg->capacity_reads; e->cap_hint_bases = cfg->capacity_bases;
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        (void)hipGetLastError();
         delete e; return FQD_ERR_HIP;
     };
     hipError_t err;

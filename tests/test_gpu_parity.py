@@ -469,3 +469,29 @@ def test_ragged_tiles_that_do_and_do_not_fit_the_staged_span(oracle, paired):
         exp = oracle.dedup_single(*host[0])
     assert np.array_equal(keep, exp)
     assert 0 < int((exp == 0).sum()) < n
+
+
+# ---- limits and failures around growth ---------------------------------------------------------------
+
+def test_capacity_limit_and_allocation_failure_are_errors_not_crashes(oracle):
+    """An engine holds at most 2^32-2 records (slot = tag:32 | index:32): one more is FQD_ERR_CAPACITY,
+    reported before anything is touched.  A table that cannot be allocated is an error carrying the HIP
+    text; the library stays usable."""
+    from fastq_dupaway_amd import _lib
+    rng = np.random.default_rng(1)
+    reads = [bytes(rng.choice(list(b"ACGT"), size=30).astype(np.uint8)) for _ in range(1000)]
+    data, offs, lens = ragged_arrays(reads)
+    with Engine(segments=1) as e:
+        keep = e.submit([Reads(data, offs, lens)], len(reads))
+        assert np.array_equal(keep, oracle.dedup_single(data, offs, lens))
+        with pytest.raises(fqd.FqdError) as err:
+            e.submit([Reads(data, uniform_len=1, uniform_stride=1)], 0xFFFFFFFF - 500)       # 1000 + n > 2^32 - 2
+        assert err.value.code == _lib.ERR_CAPACITY
+        # the engine is still good for more records
+        keep2 = e.submit([Reads(data, offs, lens)], len(reads))
+        assert int(keep2.sum()) == 0
+    with pytest.raises(fqd.FqdError) as err:
+        Engine(segments=1, capacity_reads=1 << 40)                                          # a 16 TiB table
+    assert err.value.code == _lib.ERR_HIP and "hipMalloc" in err.value.message
+    with Engine(segments=1) as e:
+        assert np.array_equal(e.submit([Reads(data, offs, lens)], len(reads)), oracle.dedup_single(data, offs, lens))

@@ -315,7 +315,8 @@ StagedChoice choose_staged(const fqd_engine* e, const fqd_reads* seg, bool unifo
 {
     StagedChoice c{false, 0, 0, 0, 0};
     if (!uniform || (e->flags & FQD_FLAG_NO_STAGE)) return c;
-    for (uint32_t R = 256; R >= 64; R -= 64) {
+    static const uint32_t r_max = [] { const char* v = std::getenv("FQD_STAGE_R"); const int x = v ? std::atoi(v) : 256; return uint32_t(x >= 64 && x <= 256 ? x / 64 * 64 : 256); }();
+    for (uint32_t R = r_max; R >= 64; R -= 64) {
         const uint32_t per_tile = e->S == 2 ? R / 2 : R;     // paired: one lane per mate, R/2 pairs per tile
         uint64_t t0 = (uint64_t(per_tile) * seg[0].uniform_stride + 32 + 15) & ~15ull;
         uint64_t t1 = (e->S == 2) ? ((uint64_t(per_tile) * seg[1].uniform_stride + 32 + 15) & ~15ull) : 0;

@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--pe-cpu-sample", type=int, default=2_000_000, help="pairs of the pe run checked against the CPU oracle")
     ap.add_argument("--e2e-reads", type=int, default=30_000_000, help="reads of the end-to-end CLI run (0 = skip)")
+    ap.add_argument("--e2e-pairs", type=int, default=4_000_000, help="pairs of the end-to-end --unordered CLI run (0 = skip)")
     ap.add_argument("--e2e-dir", default="", help="where the end-to-end FASTQ files go (default: a temp dir under /tmp)")
     ap.add_argument("--no-verify", action="store_true")
     return ap.parse_args()
@@ -312,6 +313,63 @@ def end_to_end(a, torch, bases, expect, L):
     return res
 
 
+def end_to_end_unordered(a, torch, bases, L):
+    """The CLI on the configs[4] SHAPE at a size the oracle checks in seconds: paired FASTQ, file 2 shuffled,
+    --unordered; outputs and -v lines compared byte for byte with the CPU oracle's file driver."""
+    import filecmp
+    import numpy as np
+    from fastq_dupaway_amd import _lib
+    from oracle import binding
+    n = min(a.e2e_pairs, a.reads // 2)
+    seqs = bases[: 2 * n * L].cpu().numpy().reshape(2 * n, L)
+    d = Path(a.e2e_dir) if a.e2e_dir else Path(tempfile.mkdtemp(prefix="fqd_e2e_un_", dir="/tmp"))
+    d.mkdir(parents=True, exist_ok=True)
+    rng = np.random.default_rng(a.seed)
+    files = []
+    for mate in range(2):
+        idl = 18                                              # "@r%09d 1:N:0\n"
+        rec = np.empty((n, idl + L + 1 + 2 + L + 1), dtype=np.uint8)
+        rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+        idx = np.arange(n, dtype=np.int64)
+        for p in range(9):
+            rec[:, 10 - p] = 48 + (idx % 10); idx //= 10
+        rec[:, 11:18] = np.frombuffer(b" %d:N:0\n" % (mate + 1), dtype=np.uint8)
+        rec[:, idl:idl + L] = seqs[mate * n:(mate + 1) * n]
+        rec[:, idl + L] = 10; rec[:, idl + L + 1] = ord("+"); rec[:, idl + L + 2] = 10
+        rec[:, idl + L + 3:idl + 2 * L + 3] = ord("I"); rec[:, idl + 2 * L + 3] = 10
+        if mate == 1:
+            rec = rec[rng.permutation(n)]                      # file 2 in another order
+        f = d / f"r{mate + 1}.fq"
+        rec.tofile(f)
+        files.append(f)
+    outs = [d / "o1.fq", d / "o2.fq"]; exps = [d / "e1.fq", d / "e2.fq"]
+    runs = []
+    r = None
+    for _ in range(2):
+        for o in outs:
+            o.unlink(missing_ok=True)
+        t0 = time.perf_counter()
+        r = subprocess.run([str(_lib.CLI_PATH), "-i", str(files[0]), "-u", str(files[1]), "-o", str(outs[0]), "-p", str(outs[1]),
+                            "--fast", "--unordered", "-v"], capture_output=True, text=True, cwd=str(d))
+        runs.append(time.perf_counter() - t0)
+        if r.returncode != 0:
+            break
+    t0 = time.perf_counter()
+    tot, dup, un = binding.load_oracle().filter_paired(files[0], files[1], exps[0], exps[1], binding.FASTQ, unordered=True, tail_rule=True)
+    t_oracle = time.perf_counter() - t0
+    line = f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n{un} Non-matching entries from both files were skipped.\n"
+    ok = r.returncode == 0 and r.stdout == line and all(filecmp.cmp(o, e, shallow=False) for o, e in zip(outs, exps))
+    size = sum(f.stat().st_size for f in files)
+    res = {"value": round(n / min(runs) / 1e6, 3), "unit": "Mpairs/s", "seconds": [round(t, 3) for t in runs],
+           "what": f"fastq-dupaway -i r1.fq -u r2.fq -o o1.fq -p o2.fq --fast --unordered -v on {n} pairs ({size / 1e9:.2f} GB of FASTQ, file 2 shuffled; "
+                   f"{'streamed twice: above' if size > (2 << 30) else 'held in memory: within'} the default --mem-limit), plain files on {d}, page cache warm; best of 2 runs",
+           "cpu_oracle_seconds": round(t_oracle, 2),
+           "parity": "output bytes and -v lines == CPU oracle's file driver" if ok else f"MISMATCH rc={r.returncode} {r.stdout!r} {r.stderr[-300:]!r}"}
+    if not a.e2e_dir:
+        shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
 def main():
     a = parse()
     import torch
@@ -351,6 +409,8 @@ def main():
         out["pcie_inclusive"] = pcie_inclusive(torch, eng, bases[0], expect, keep, a.reads, L)
         if a.e2e_reads > 0:
             out["end_to_end"] = end_to_end(a, torch, bases[0], expect, L)
+        if a.e2e_pairs > 0:
+            out["end_to_end_unordered"] = end_to_end_unordered(a, torch, bases[0], L)
         eng.close()
         del bases, expect, keep
         torch.cuda.empty_cache()

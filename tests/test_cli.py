@@ -636,6 +636,59 @@ def test_differential_fuzz_single_and_paired_with_injected_errors(exe, oracle, t
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["memory", "stream"])
+def test_unordered_differential_fuzz_with_injected_errors(exe, oracle, tmp_path, mode):
+    """--unordered on random small paired inputs — clean, or with one defect in either file (unknown base,
+    bad lead byte, quality of another length, a line missing, empty file) — through the CLI (held in memory
+    / streamed twice) and the oracle's driver: same exit status, same exception text, same output files.
+    (With an unknown base the reference has already written the pairs before it in tag order.)"""
+    rnd = random.Random(77)
+
+    def render(ids, seqs, mate, defect):
+        parts = [b"@" + i + b" %d\n" % mate + s + b"\n+\n" + b"I" * len(s) + b"\n" for i, s in zip(ids, seqs)]
+        if not parts:
+            return b""
+        k = rnd.randrange(len(parts))
+        if defect == "base":
+            s = seqs[k]; s = s[: len(s) // 2] + b"x" + s[len(s) // 2 + 1:]
+            parts[k] = b"@" + ids[k] + b" %d\n" % mate + s + b"\n+\n" + b"I" * len(s) + b"\n"
+        elif defect == "lead":
+            parts[k] = b"?" + parts[k][1:]
+        elif defect == "qual":
+            parts[k] = parts[k][:-1] + b"I\n"
+        elif defect == "line":
+            parts[k] = parts[k].split(b"\n", 1)[1]
+        elif defect == "empty":
+            return b""
+        return b"".join(parts)
+
+    defects = [None, None, None, "base", "lead", "qual", "line", "empty"]
+    pool = [bytes(rnd.choice(b"ACGTN") for _ in range(rnd.randrange(1, 50))) for _ in range(12)]
+    for case in range(36):
+        d = tmp_path / f"c{case}"; d.mkdir()
+        universe = [b"q%03d" % k for k in range(rnd.randrange(2, 30))]
+        ids1 = rnd.sample(universe, rnd.randrange(1, len(universe) + 1)); ids2 = rnd.sample(universe, rnd.randrange(1, len(universe) + 1))
+        f1, f2 = d / "r1.fq", d / "r2.fq"
+        f1.write_bytes(render(ids1, [rnd.choice(pool) for _ in ids1], 1, rnd.choice(defects)))
+        f2.write_bytes(render(ids2, [rnd.choice(pool) for _ in ids2], 2, rnd.choice(defects)))
+        e1, e2, g1, g2 = (d / x for x in ("e1", "e2", "g1", "g2"))
+        err = None
+        try:
+            oracle.filter_paired(f1, f2, e1, e2, FASTQ, unordered=True, tail_rule=True)
+        except RuntimeError as ex:
+            err = str(ex)
+        r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", env=STREAM_ENV[mode], cwd=d)
+        what = (case, f1.read_bytes()[:150], f2.read_bytes()[:150])
+        assert (r.returncode != 0) == (err is not None), (what, r.stderr, err)
+        if err is not None:
+            assert r.stderr.endswith("An error occured during fastq-dupaway execution:\n" + err + "\n"), (what, r.stderr, err)
+        for g, e in ((g1, e1), (g2, e2)):
+            assert g.exists() == e.exists(), what
+            if e.exists():
+                assert g.read_bytes() == e.read_bytes(), what
+
+
+@pytest.mark.gpu
 def test_pipes_as_input_and_output(exe, oracle, tmp_path):
     """Not regular files: the input comes through /dev/stdin (no size, no pread), the output goes
     to /dev/stdout."""

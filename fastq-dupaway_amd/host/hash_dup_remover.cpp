@@ -1022,6 +1022,7 @@ void HashDupRemover::run_unordered_streaming(const std::string* in, const std::s
                 const std::string name = tmp + "/out" + std::to_string(s) + "." + std::to_string(w) + ".tmp";
                 spill[w] = std::fopen(name.c_str(), "wb+");
                 if (!spill[w]) throw std::runtime_error("Cannot open temporary file " + name);
+                std::setvbuf(spill[w], nullptr, _IOFBF, 1u << 20);
             }
             RecordStream rs(in[s], format_, false, block_bytes);
             Block b; Pinned<uint64_t> h_dest;

@@ -265,6 +265,7 @@ private:
                         }
                     }
                     if (run_len) pieces.push_back({run_from, run_len});
+                    StageClock::Scope t2("writer: copy out");
                     sink_[s]->write_pieces(pieces.data(), pieces.size(), write_threads());
                 } catch (...) { error_[s] = std::current_exception(); failed_already = true; }
             }

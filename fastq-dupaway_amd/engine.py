@@ -233,6 +233,21 @@ class Engine:
     def gather_seqs(self, idx, n: int, off_table, len_table, off_out, len_out):
         self._check(self._L.fqd_gather_seqs(self._h, _addr(idx), n, _addr(off_table), _addr(len_table), _addr(off_out), _addr(len_out)))
 
+    def copy_spans(self, src, src_off, lens, n: int, dst, dst_off):
+        self._check(self._L.fqd_copy_spans(self._h, _addr(src), _addr(src_off), _addr(lens), n, _addr(dst), _addr(dst_off)))
+
+    def count_tags_le(self, t, other, other_index: int) -> int:
+        """Records of t = (bytes, offsets, lengths, n) whose tag is <= the tag of record other_index of `other`."""
+        tt, to = self._tags(*t), self._tags(*other)
+        count = C.c_uint64(0)
+        self._check(self._L.fqd_count_tags_le(self._h, C.byref(tt), C.byref(to), other_index, C.byref(count)))
+        return int(count.value)
+
+    def output_offsets(self, keep, idx, n: int, sizes, dest) -> int:
+        total = C.c_uint64(0)
+        self._check(self._L.fqd_output_offsets(self._h, _addr(keep), _addr(idx), n, _addr(sizes), _addr(dest), C.byref(total)))
+        return int(total.value)
+
     def scatter_flags(self, flags, origin, n: int, keep_out):
         self._check(self._L.fqd_scatter_flags(self._h, _addr(flags), _addr(origin), n, _addr(keep_out)))
 

@@ -222,3 +222,47 @@ def test_join_at_50m_tags_per_side(style):
     # partners point at each other
     k = torch.nonzero(has_a)[:, 0]
     assert same(mb[ma[k].long()].long(), k)
+
+
+def test_device_halves_of_the_streaming_run():
+    """fqd_copy_spans, fqd_count_tags_le, fqd_output_offsets (the bounded-memory --unordered run) against numpy."""
+    rng = np.random.default_rng(21)
+    n = 50000
+    src = rng.integers(0, 256, size=4_000_000, dtype=np.uint8)
+    lens = rng.integers(0, 70, size=n).astype(np.uint32); lens[:5] = [0, 1, 7, 8, 9]
+    src_off = rng.integers(0, len(src) - 80, size=n).astype(np.uint64)
+    dst_off = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+    total = int(lens.sum())
+    d_src, d_so, d_ln, d_do = to_dev(src, src_off, lens, dst_off)
+    d_dst = torch.zeros(total + 16, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with Engine(segments=2) as e:
+        e.copy_spans(d_src, d_so, d_ln, n, d_dst, d_do)
+        e.sync()
+        got = d_dst.cpu().numpy()
+        exp = np.concatenate([src[int(o):int(o) + int(l)] for o, l in zip(src_off, lens)])
+        assert np.array_equal(got[:total], exp) and not got[total:].any()
+
+        # tag counts: how many tags of t are <= one tag of `other`, in the reference's order
+        tags = make_tags(rng, 3000, "mixed") + [b"dup", b"dup", b""]
+        other = [b"abc", b"", b"zz", b"dup", b"abcdefgh", b"M", tags[100], tags[2000]]
+        T = to_dev(*tag_arrays(tags)); O = to_dev(*tag_arrays(other))
+        torch.cuda.synchronize()
+        for k, probe in enumerate(other):
+            assert e.count_tags_le((*T, len(tags)), (*O, len(other)), k) == sum(t <= probe for t in tags), probe
+
+        # output offsets: kept pairs' record sizes, running sum in pair order, scattered to the records
+        n_rec, n_pairs = 70000, 60000
+        sizes = rng.integers(20, 400, size=n_rec).astype(np.uint32)
+        idx = rng.permutation(n_rec)[:n_pairs].astype(np.uint32)
+        keep = (rng.random(n_pairs) < 0.8).astype(np.uint8)
+        d_sz, d_idx = to_dev(sizes, idx); d_keep = torch.from_numpy(keep).cuda()
+        d_dest = torch.full((n_rec,), -1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        tot = e.output_offsets(d_keep, d_idx, n_pairs, d_sz, d_dest)
+        kept_sizes = np.where(keep == 1, sizes[idx], 0).astype(np.int64)
+        starts = np.concatenate([[0], np.cumsum(kept_sizes)[:-1]])
+        exp_dest = np.full(n_rec, -1, dtype=np.int64)
+        exp_dest[idx[keep == 1]] = starts[keep == 1]
+        assert tot == int(kept_sizes.sum())
+        assert np.array_equal(d_dest.cpu().numpy(), exp_dest)

@@ -31,6 +31,9 @@ def make_tags(rng, n, style):
         return [b"%d" % (k + 1) for k in range(n)]
     if style == "newline":
         return [b"read%07d\n" % k for k in range(n)]           # tags that run through the newline (no space in the ID)
+    if style == "long":                                       # 200-400 bytes, shared 180-byte prefix, differences far beyond the LDS census range
+        prefix = b"instrument:run:flowcell:" * 8
+        return [prefix[:180] + bytes(rng.choice(list(b"ACGT0123456789:"), size=int(rng.integers(20, 220))).astype(np.uint8)) + b"/%d" % k for k in range(n)]
     if style == "wide":                                       # random bytes: every position needs 8 bits, keys of several words
         return [bytes(rng.integers(1, 256, size=int(rng.integers(0, 30))).astype(np.uint8)) + b"|%d" % k for k in range(n)]
     # mixed lengths, shared prefixes, prefix-of-each-other cases
@@ -53,10 +56,10 @@ def run_join(e, a, b):
                 pair_a=h(qa, n_pairs), pair_b=h(qb, n_pairs), n_pairs=n_pairs)
 
 
-@pytest.mark.parametrize("style", ["illumina", "sra", "newline", "mixed", "wide"])
+@pytest.mark.parametrize("style", ["illumina", "sra", "newline", "mixed", "wide", "long"])
 def test_sort_tags_matches_reference_order(oracle, style):
     rng = np.random.default_rng(5)
-    n = 20000
+    n = 20000 if style != "long" else 4000
     tags = make_tags(rng, n, style)
     order = rng.permutation(n)
     tags = [tags[i] for i in order]
@@ -84,10 +87,10 @@ def test_sort_is_stable_for_equal_tags():
     assert perm.cpu().tolist() == [1, 3, 4, 0, 2, 5]
 
 
-@pytest.mark.parametrize("style", ["illumina", "wide"])
+@pytest.mark.parametrize("style", ["illumina", "wide", "long"])
 def test_join_gives_the_oracles_full_join(oracle, style):
     rng = np.random.default_rng(9)
-    n = 30000
+    n = 30000 if style != "long" else 5000
     ids = make_tags(rng, n, style)
     a = [ids[i] for i in rng.permutation(n) if rng.random() < 0.9]
     b = [ids[i] for i in rng.permutation(n) if rng.random() < 0.8]

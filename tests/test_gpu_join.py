@@ -269,3 +269,25 @@ def test_device_halves_of_the_streaming_run():
         exp_dest[idx[keep == 1]] = starts[keep == 1]
         assert tot == int(kept_sizes.sum())
         assert np.array_equal(d_dest.cpu().numpy(), exp_dest)
+
+
+def test_join_fuzz_small_cases_against_the_oracle(oracle):
+    """Many small joins — tags drawn from tiny alphabets so that repeats, prefixes of each other, empty tags
+    and one-sided runs are the rule — against the oracle's stable merge-join (full join)."""
+    rng = np.random.default_rng(123)
+    with Engine(segments=2) as e:
+        for case in range(250):
+            alphabet = [b"a", b"b", b"ab", b"", b"a\n", b"b:1", b"b:10", b"b:2", b"zzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzz", b"\xff", b"\x01"]
+            k = int(rng.integers(1, len(alphabet) + 1))
+            pick = [alphabet[i] for i in rng.permutation(len(alphabet))[:k]]
+            a = [pick[int(i)] for i in rng.integers(0, k, size=int(rng.integers(0, 40)))]
+            b = [pick[int(i)] for i in rng.integers(0, k, size=int(rng.integers(0, 40)))]
+            j = run_join(e, a, b)
+            if a and b:
+                i1, i2, un = oracle.join_tags(*tag_arrays(a), *tag_arrays(b), tail_rule=False)
+                exp = list(zip(i1.tolist(), i2.tolist()))
+            else:
+                exp = []
+            got = list(zip(j["pair_a"].tolist(), j["pair_b"].tolist()))
+            assert got == exp, (case, a, b)
+            assert sorted(j["perm_a"].tolist()) == list(range(len(a))) and sorted(j["perm_b"].tolist()) == list(range(len(b)))

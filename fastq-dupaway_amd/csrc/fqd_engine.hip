@@ -417,7 +417,11 @@ bool bulk_applies(const fqd_engine* e, uint64_t n)
 {
     if (n < e->bulk_min || e->slots < (1ull << 13)) return false;
     const bool empty = e->n_records == 0;
-    return empty || n * 8 >= e->slots;
+    // Against a table that already holds records the bulk path pays one read and one write of the whole
+    // table (0.76 ms for 2 GiB) on top of 2.9 ms per 100 M records; the atomic path costs 6.3 ms per
+    // 100 M.  Measured break-even (tools/split_probe.py): about slots / 14 records.
+    static const uint64_t ratio = [] { const char* v = std::getenv("FQD_BULK_RATIO"); const long x = v ? std::atol(v) : 12; return uint64_t(x > 0 ? x : 12); }();
+    return empty || n * ratio >= e->slots;
 }
 
 struct BulkPlan {

@@ -689,6 +689,24 @@ def test_unordered_differential_fuzz_with_injected_errors(exe, oracle, tmp_path,
 
 
 @pytest.mark.gpu
+def test_records_longer_than_the_reader_headroom(exe, oracle, tmp_path):
+    """Records of ~1.3 MB with 4 MiB input blocks: what a block carries over to the next one (the record cut
+    by the block end plus the one before it) exceeds the 1 MiB the two-stage reader leaves free in front of
+    the raw bytes, so the slow re-allocation path of RecordStream::finish runs; output == the oracle's."""
+    rnd = random.Random(91)
+    seqs = [bytes(rnd.choice(b"ACGT") for _ in range(1000)) * 1300 for _ in range(3)]
+    recs = [(b"big%d" % k, seqs[k % 3][: 1_300_000 - 7 * (k % 2)]) for k in range(9)]
+    src = tmp_path / "big.fa"
+    src.write_bytes(b"".join(b">" + i + b"\n" + s + b"\n" for i, s in recs))
+    exp, got = tmp_path / "exp.fa", tmp_path / "got.fa"
+    tot, dup = oracle.filter_single(src, exp, FASTA)
+    r = run(exe, "-i", src, "-o", got, "--fast", "--format", "fasta", "-v", env={"FQD_BLOCK_MB": "4"})
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(got, exp, shallow=False)
+    assert r.stdout == f"{tot} reads processed, out of which {dup} duplicates were removed.\n" and dup > 0
+
+
+@pytest.mark.gpu
 def test_pipes_as_input_and_output(exe, oracle, tmp_path):
     """Not regular files: the input comes through /dev/stdin (no size, no pread), the output goes
     to /dev/stdout."""

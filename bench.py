@@ -193,7 +193,7 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
         per_launch = prof[f"{dom}_reads"] / prof[f"{dom}_launches"]
         dom_gbps = per_launch * bytes_per_unit / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
         step_gbps = value * 1e6 / world * bytes_per_unit / 1e9
-        traffic, source = None, None
+        traffic, source, step_traffic = None, None, None
         if world == 1 and not sharded_mode and n == 100_000_000 and L == 150 and not paired:
             per_kernel, source = committed_traffic()
             if per_kernel:
@@ -202,13 +202,15 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
                         if name.split("<")[0] == names[k].split("<")[0].split(" ")[0]:
                             kernels[k]["hbm_bytes_from_committed_profile"] = rec["hbm_traffic"]
                 traffic = kernels[dom].get("hbm_bytes_from_committed_profile")
+                step_traffic = sum(rec["hbm_traffic"] for name, rec in per_kernel.items() if "synth" not in name)
         # SURVEY §8(d) defines the contract figure over the whole device phase: reads/s x 150 B / 8 TB/s.
         # That is `frac`; the dominant kernel's own figure stands beside it.
         roofline = {"bound": "hbm", "achieved": round(step_gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(step_gbps / HBM_PEAK_GBS, 4),
                     "frac_of_measured_copy_ceiling": round(step_gbps / HBM_COPY_GBS, 4),
                     "scope": "whole device phase (all kernels of a step): algorithmic bytes / step time",
-                    "traffic": traffic, "traffic_source": (source + " (committed rocprofv3 --pmc passes of this command; not measured in this run)") if traffic else None,
+                    "traffic": traffic, "traffic_scope": "dominant kernel, per launch" if traffic else None,
+                    "traffic_whole_step": step_traffic, "traffic_source": (source + " (committed rocprofv3 --pmc passes of this command; not measured in this run)") if traffic else None,
                     "algorithmic_bytes_per_unit": bytes_per_unit,
                     "dominant_kernel": {"name": names[dom], "avg_ms": kernels[dom]["avg_ms"], "achieved": round(dom_gbps, 1),
                                         "frac": round(dom_gbps / HBM_PEAK_GBS, 4),

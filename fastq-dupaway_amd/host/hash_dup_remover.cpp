@@ -236,6 +236,13 @@ public:
     {
         for (int s = 0; s < S_; ++s) thread_[s] = std::thread([this, s] { body(s); });
     }
+    ~SurvivorWriters()
+    {
+        if (!thread_[0].joinable()) return;                    // stopped the regular way
+        last_resort_.stop = true; last_resort_.home = &nowhere_;   // an exception is unwinding past us: end the threads
+        hand_over(&last_resort_);
+        for (int s = 0; s < S_; ++s) thread_[s].join();
+    }
     void hand_over(Work* w) { w->writers_left.store(S_); for (int s = 0; s < S_; ++s) queue_[s].push(w); }
     // `w`: a free Work used as the stop marker.
     void stop(Work* w) { w->stop = true; hand_over(w); for (int s = 0; s < S_; ++s) thread_[s].join(); }
@@ -277,6 +284,7 @@ private:
     }
     int S_; std::unique_ptr<OutputFile>* sink_; Channel<Work>* recycle_;
     Channel<Work> queue_[2]; std::thread thread_[2]; std::exception_ptr error_[2];
+    Work last_resort_; Channel<Work> nowhere_;
 };
 
 } // namespace

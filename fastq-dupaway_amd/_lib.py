@@ -112,6 +112,7 @@ def load_library():
     L.fqd_copy_spans.argtypes = [vp, vp, vp, vp, u64, vp, vp]
     L.fqd_count_tags_le.argtypes = [vp, C.POINTER(TagsDesc), C.POINTER(TagsDesc), u64, C.POINTER(u64)]
     L.fqd_output_offsets.argtypes = [vp, vp, vp, u64, vp, vp, C.POINTER(u64)]
+    L.fqd_output_plan.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, vp, C.POINTER(u64)]
     L.fqd_scatter_flags.argtypes = [vp, vp, vp, u64, vp]
     L.fqd_partition_keys.argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
     L.fqd_reserve_keys.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]

@@ -721,6 +721,55 @@ void out_offsets_kernel(const uint8_t* __restrict__ keep, const uint32_t* __rest
     }
 }
 
+// Output plan of a run whose text stays in HBM: for pair k (tag order) the record idx[k] of this file is
+// copied from src_out[k] (its place in the text) to dst_out[k] (its place in the output) when keep[k];
+// len_out[k] = its size, or 0 for a pair that is not written.
+__global__ __launch_bounds__(kBlock)
+void plan_gather_kernel(const uint8_t* __restrict__ keep, const uint32_t* __restrict__ idx, uint64_t n,
+                        const uint64_t* __restrict__ starts, const uint32_t* __restrict__ sizes,
+                        uint64_t* __restrict__ src_out, uint32_t* __restrict__ len_out, unsigned long long* __restrict__ tile_sum)
+{
+    __shared__ unsigned long long ws[4];
+    const uint64_t base = uint64_t(blockIdx.x) * kOffTile + uint64_t(threadIdx.x) * 8u;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint64_t k = base + uint32_t(e);
+        if (k < n) {
+            const uint32_t r = idx[k];
+            const uint32_t L = keep[k] ? sizes[r] : 0u;
+            src_out[k] = starts[r]; len_out[k] = L; s += L;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(kBlock)
+void plan_offsets_kernel(const uint32_t* __restrict__ len, uint64_t n, const unsigned long long* __restrict__ tile_start,
+                         unsigned long long* __restrict__ dst_out)
+{
+    __shared__ unsigned long long ws[4];
+    const uint64_t base = uint64_t(blockIdx.x) * kOffTile + uint64_t(threadIdx.x) * 8u;
+    uint32_t L[8];
+    unsigned long long s = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const uint64_t k = base + uint32_t(e); L[e] = k < n ? len[k] : 0u; s += L[e]; }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(inc, d, 64); if (int(lane) >= d) inc += up; }
+    if (lane == 63u) ws[wave] = inc;
+    __syncthreads();
+    unsigned long long at = tile_start[blockIdx.x] + inc - s;
+    for (uint32_t w = 0; w < wave; ++w) at += ws[w];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const uint64_t k = base + uint32_t(e); if (k < n) { dst_out[k] = at; at += L[e]; } }
+}
+
 // ---------------------------------------------------------------------------------------------
 struct Carver {                                       // 256-byte aligned pieces of one scratch block
     char* p; size_t used = 0;
@@ -965,6 +1014,34 @@ int fqd_output_offsets(fqd_engine* e, const uint8_t* keep, const uint32_t* idx, 
     hipLaunchKernelGGL(u64_scan_kernel, dim3(1), dim3(1024), 0, stream, tile, tiles, d_total);
     hipLaunchKernelGGL(out_offsets_kernel, dim3(tiles), dim3(kBlock), 0, stream, keep, idx, n, sizes,
                        static_cast<const unsigned long long*>(tile), reinterpret_cast<unsigned long long*>(dest));
+    JOIN_TRY(e, hipGetLastError());
+    unsigned long long got = 0;
+    JOIN_TRY(e, hipMemcpyAsync(&got, d_total, sizeof got, hipMemcpyDeviceToHost, stream));
+    JOIN_TRY(e, hipStreamSynchronize(stream));
+    *total = got;
+    return FQD_OK;
+}
+
+int fqd_output_plan(fqd_engine* e, const uint8_t* keep, const uint32_t* idx, uint64_t n, const uint64_t* starts, const uint32_t* sizes,
+                    uint64_t* src_off, uint32_t* len, uint64_t* dst_off, uint64_t* total)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!total || (n && (!keep || !idx || !starts || !sizes || !src_off || !len || !dst_off)))
+        return fqd_internal_fail(e, FQD_ERR_ARG, "fqd_output_plan: bad arguments");
+    *total = 0;
+    if (n == 0) return FQD_OK;
+    JOIN_TRY(e, hipSetDevice(fqd_internal_device(e)));
+    hipStream_t stream = fqd_internal_stream(e);
+    const uint32_t tiles = uint32_t((n + kOffTile - 1) / kOffTile);
+    void* base = nullptr;
+    int rc = fqd_internal_scratch(e, 1, (size_t(tiles) + 2) * sizeof(unsigned long long), &base);
+    if (rc) return rc;
+    unsigned long long* tile = static_cast<unsigned long long*>(base);
+    unsigned long long* d_total = tile + tiles;
+    hipLaunchKernelGGL(plan_gather_kernel, dim3(tiles), dim3(kBlock), 0, stream, keep, idx, n, starts, sizes, src_off, len, tile);
+    hipLaunchKernelGGL(u64_scan_kernel, dim3(1), dim3(1024), 0, stream, tile, tiles, d_total);
+    hipLaunchKernelGGL(plan_offsets_kernel, dim3(tiles), dim3(kBlock), 0, stream, static_cast<const uint32_t*>(len), n,
+                       static_cast<const unsigned long long*>(tile), reinterpret_cast<unsigned long long*>(dst_off));
     JOIN_TRY(e, hipGetLastError());
     unsigned long long got = 0;
     JOIN_TRY(e, hipMemcpyAsync(&got, d_total, sizeof got, hipMemcpyDeviceToHost, stream));

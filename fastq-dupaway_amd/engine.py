@@ -248,6 +248,12 @@ class Engine:
         self._check(self._L.fqd_output_offsets(self._h, _addr(keep), _addr(idx), n, _addr(sizes), _addr(dest), C.byref(total)))
         return int(total.value)
 
+    def output_plan(self, keep, idx, n: int, starts, sizes, src_off, lens, dst_off) -> int:
+        total = C.c_uint64(0)
+        self._check(self._L.fqd_output_plan(self._h, _addr(keep), _addr(idx), n, _addr(starts), _addr(sizes),
+                                            _addr(src_off), _addr(lens), _addr(dst_off), C.byref(total)))
+        return int(total.value)
+
     def scatter_flags(self, flags, origin, n: int, keep_out):
         self._check(self._L.fqd_scatter_flags(self._h, _addr(flags), _addr(origin), n, _addr(keep_out)))
 

@@ -723,6 +723,10 @@ void join_and_dedup(fqd_engine* e, hipStream_t stream, const DeviceSide (&side)[
     } else engine_ok(rc);
 }
 
+// A device allocation failed while the inputs were still being read: the caller may fall back to a
+// way of running that needs less HBM.
+struct DeviceOutOfMemory : std::runtime_error { using std::runtime_error::runtime_error; };
+
 // Device memory that grows and keeps its contents.
 template <class T>
 struct GrowDevice {
@@ -733,7 +737,10 @@ struct GrowDevice {
         if (used + more <= cap) return;
         const size_t want = std::max<size_t>(used + more, std::max<size_t>(cap + cap / 2, 1u << 20));
         void* np = nullptr;
-        HIP_OK(hipMalloc(&np, want * sizeof(T) + 64));
+        if (hipMalloc(&np, want * sizeof(T) + 64) != hipSuccess) {
+            (void)hipGetLastError();
+            throw DeviceOutOfMemory("--unordered: the inputs do not fit in GPU memory (" + std::to_string((want * sizeof(T)) >> 20) + " MiB more needed)");
+        }
         if (used) HIP_OK(hipMemcpyAsync(np, p, used * sizeof(T), hipMemcpyDeviceToDevice, s));
         HIP_OK(hipStreamSynchronize(s));
         if (p) (void)hipFree(p);
@@ -760,12 +767,15 @@ bool is_regular_file(const std::string& name, uint64_t& size)
 // external_sort.hpp:95): sorted chunk files on disk, merged.  This build has two ways:
 //   * inputs that fit --mem-limit (or cannot be read twice: pipes) are held in pinned memory and
 //     handled in one pass (run_unordered_in_memory);
-//   * anything larger is streamed TWICE through a few pinned blocks (run_unordered_streaming): the
-//     first pass leaves every record's tag and sequence in HBM, the device decides everything
-//     (pairs, survivors, where every surviving record starts in the output), the second pass puts the
-//     records there.  Host memory stays within the limit whatever the input size; the big state
-//     lives in the 288 GB of HBM (about 190 bytes per 150-bp record).
-// FQD_UNORDERED_MODE=memory|stream forces one of them.
+//   * anything larger is streamed ONCE through a few pinned blocks into HBM, where the whole text of both
+//     files stays (run_unordered_resident; configs[4]: 2 x 32 GB of 288): the device joins, dedups and then
+//     assembles the outputs window by window in output order; the host only reads, and writes what comes back;
+//   * what not even HBM can hold is streamed TWICE (run_unordered_streaming): the first pass leaves every
+//     record's tag and sequence in HBM (about 190 bytes per 150-bp record), the device decides everything
+//     (pairs, survivors, where every surviving record starts in the output), the second pass puts the records
+//     there through window files in the temporary directory.
+// Host memory stays within the limit whatever the input size.  FQD_UNORDERED_MODE=memory|resident|twopass
+// forces one of them.
 void HashDupRemover::run_unordered(const std::string* in, const std::string* out)
 {
     uint64_t sz[2] = {0, 0};
@@ -773,12 +783,20 @@ void HashDupRemover::run_unordered(const std::string* in, const std::string* out
     uint64_t estimate = 0;
     for (int s = 0; s < 2; ++s) estimate += has_gz_extension(in[s]) ? sz[s] * 4 : sz[s];     // FASTQ deflates to about a quarter
     bool stream = regular && memlimit_ > 0 && estimate > static_cast<uint64_t>(memlimit_);
-    if (const char* m = std::getenv("FQD_UNORDERED_MODE")) {
-        if (std::string(m) == "stream" && regular) stream = true;
-        if (std::string(m) == "memory") stream = false;
+    std::string forced;
+    if (const char* m = std::getenv("FQD_UNORDERED_MODE")) forced = m;
+    if (forced == "memory") stream = false;
+    if (forced == "stream" || forced == "resident") stream = true;                  // one pass: pipes qualify too
+    if (forced == "twopass") { if (regular) run_unordered_streaming(in, out); else run_unordered_in_memory(in, out); return; }
+    if (!stream) { run_unordered_in_memory(in, out); return; }
+    // Above the limit: the text of both files goes to HBM block by block and stays there (one pass, nothing
+    // kept on the host).  Only when 288 GB cannot hold it are tags and sequences alone kept and the inputs
+    // read a second time.
+    try { run_unordered_resident(in, out); }
+    catch (const DeviceOutOfMemory&) {
+        if (!regular) throw;
+        run_unordered_streaming(in, out);
     }
-    if (stream) run_unordered_streaming(in, out);
-    else        run_unordered_in_memory(in, out);
 }
 
 void HashDupRemover::run_unordered_in_memory(const std::string* in, const std::string* out)
@@ -901,6 +919,164 @@ void HashDupRemover::run_unordered_in_memory(const std::string* in, const std::s
             sinks[s]->write_pieces(pieces.data(), pieces.size());
             sinks[s]->close();
         });
+    }
+    StageClock::report();
+    if (jp.bad) throw_unknown_base(jp.bad_byte);
+    summary_.total = n_proc; summary_.duplicates = dups; summary_.unmatched = jp.unmatched;
+    if (verbose_) {
+        std::cout << summary_.total << " valid read pairs processed, out of which " << summary_.duplicates << " duplicates were removed.\n";
+        std::cout << summary_.unmatched << " Non-matching entries from both files were skipped.\n";
+    }
+}
+
+// One pass, text resident in HBM (see run_unordered).
+void HashDupRemover::run_unordered_resident(const std::string* in, const std::string* out)
+{
+    HIP_OK(hipSetDevice(tuning_.device));
+    hipStream_t stream = nullptr;
+    HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+    EngineHandle eng(2, tuning_.device, stream);
+    auto engine_ok = [&](int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng.e)); };
+    const size_t block_bytes = std::max<size_t>(1u << 20, std::min<size_t>(tuning_.block_bytes, static_cast<size_t>(memlimit_ > 0 ? memlimit_ / 16 : tuning_.block_bytes)));
+
+    struct FileOnDevice {
+        GrowDevice<char> text;
+        GrowDevice<uint64_t> start, seq_off; GrowDevice<uint32_t> id_len, seq_len, size;
+        Device<uint64_t> tag_off; Device<uint32_t> tag_len;
+        uint64_t n = 0;
+    } dev[2];
+
+    // ---- the one pass: every block to the tail of the file's text in HBM -------------------------------
+    {
+        StageClock::Scope t("unordered/resident: read, scan, text to HBM");
+        Pinned<uint64_t> h_start, h_seq; Pinned<uint32_t> h_idl, h_sql, h_size;
+        for (int s = 0; s < 2; ++s) {                          // file 1 completely before file 2 is touched (hpp:161-173)
+            FileOnDevice& f = dev[s];
+            uint64_t known = 0;
+            if (is_regular_file(in[s], known) && !has_gz_extension(in[s])) f.text.room_for(known + 64, stream);   // no regrowth for plain files
+            Side side;
+            side.open_file(in[s], format_, true, block_bytes);
+            side.prime(3, tuning_.device);
+            while (side.available() > 0) {
+                PooledBlock* b = side.cur;
+                const size_t from = side.pos, nb = b->recs.size() - from;
+                const RecordRef* r = &b->recs[from];
+                const uint64_t text_lo = r[0].start, bytes = r[nb - 1].start + r[nb - 1].size - text_lo;
+                f.text.room_for(bytes + 64, stream);
+                HIP_OK(hipMemcpyAsync(f.text.p + f.text.used, b->text.p + text_lo, bytes, hipMemcpyHostToDevice, stream));
+                h_start.reserve(nb); h_seq.reserve(nb); h_idl.reserve(nb); h_sql.reserve(nb); h_size.reserve(nb);
+                for (size_t k = 0; k < nb; ++k) {
+                    h_start.p[k] = f.text.used + (r[k].start - text_lo); h_seq.p[k] = h_start.p[k] + r[k].id_len;
+                    h_idl.p[k] = r[k].id_len; h_sql.p[k] = r[k].seq_len; h_size.p[k] = r[k].size;
+                }
+                f.start.room_for(nb, stream); f.seq_off.room_for(nb, stream); f.id_len.room_for(nb, stream); f.seq_len.room_for(nb, stream); f.size.room_for(nb, stream);
+                HIP_OK(hipMemcpyAsync(f.start.p + f.n, h_start.p, nb * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+                HIP_OK(hipMemcpyAsync(f.seq_off.p + f.n, h_seq.p, nb * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+                HIP_OK(hipMemcpyAsync(f.id_len.p + f.n, h_idl.p, nb * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                HIP_OK(hipMemcpyAsync(f.seq_len.p + f.n, h_sql.p, nb * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                HIP_OK(hipMemcpyAsync(f.size.p + f.n, h_size.p, nb * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                HIP_OK(hipStreamSynchronize(stream));            // the block and the staging arrays are reused
+                f.text.used += bytes;
+                f.start.used = f.seq_off.used = f.id_len.used = f.seq_len.used = f.size.used = f.n + nb;
+                f.n += nb;
+                side.pos += nb;
+            }
+            if (side.failed) { std::cerr << side.failure.diag; throw std::runtime_error(side.failure.what); }
+            f.tag_off.reserve(f.n); f.tag_len.reserve(f.n);
+            engine_ok(fqd_extract_tags(eng.e, reinterpret_cast<const uint8_t*>(f.text.p), f.start.p, f.id_len.p, f.n, f.tag_off.p, f.tag_len.p));
+        }
+    }
+
+    // outputs are opened after the sort phase (hpp:265-266)
+    OutputFile sink0(out[0]), sink1(out[1]);
+    OutputFile* sinks[2] = {&sink0, &sink1};
+
+    DeviceSide side[2];
+    for (int s = 0; s < 2; ++s) {
+        side[s].tag_bytes = side[s].seq_bytes = reinterpret_cast<const uint8_t*>(dev[s].text.p);
+        side[s].tag_off = dev[s].tag_off.p; side[s].tag_len = dev[s].tag_len.p;
+        side[s].seq_off = dev[s].seq_off.p; side[s].seq_len = dev[s].seq_len.p; side[s].n = dev[s].n;
+    }
+    JoinedPairs jp;
+    join_and_dedup(eng.e, stream, side, tuning_.reference_tail_rule, jp);
+    const uint64_t n_proc = jp.n_proc, upto = std::min<uint64_t>(n_proc, jp.written_below);
+    uint64_t dups = 0;
+    {
+        std::vector<uint8_t> keep(upto);
+        if (upto) HIP_OK(hipMemcpyAsync(keep.data(), jp.keep.p, upto, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        for (uint64_t k = 0; k < upto; ++k) dups += keep[k] == 0;
+    }
+
+    // ---- outputs: the device assembles windows of survivors in output order, the host writes them -----
+    {
+        StageClock::Scope t("unordered/resident: survivors out of HBM");
+        uint64_t window = std::max<uint64_t>(4u << 20, static_cast<uint64_t>(memlimit_ > 0 ? memlimit_ : (2ll << 30)) / 16);   // bytes per buffer, two per file
+        if (const char* v = std::getenv("FQD_STREAM_WINDOW_KB")) { const long kb = std::atol(v); if (kb > 0) window = static_cast<uint64_t>(kb) << 10; }
+        struct Out {
+            Device<uint64_t> src_off, dst_off; Device<uint32_t> len; uint64_t total = 0;
+            Pinned<char> buf[2]; Device<char> d_win;
+            Channel<int> free_bufs, full_bufs; int slot_id[2] = {0, 1}; size_t bytes[2] = {0, 0};
+            std::thread writer; std::exception_ptr error;
+        } o[2];
+        static int kStop = -1;
+        for (int s = 0; s < 2; ++s) {
+            o[s].src_off.reserve(upto); o[s].dst_off.reserve(upto + 1); o[s].len.reserve(upto);
+            engine_ok(fqd_output_plan(eng.e, jp.keep.p, jp.pair[s].p, upto, dev[s].start.p, dev[s].size.p,
+                                      o[s].src_off.p, o[s].len.p, o[s].dst_off.p, &o[s].total));
+            o[s].free_bufs.push(&o[s].slot_id[0]); o[s].free_bufs.push(&o[s].slot_id[1]);
+            o[s].writer = std::thread([&, s] {
+                for (;;) {
+                    int* id = o[s].full_bufs.pop();
+                    if (*id < 0) break;
+                    try { if (!o[s].error) sinks[s]->write(o[s].buf[*id].p, o[s].bytes[*id]); }
+                    catch (...) { o[s].error = std::current_exception(); }
+                    o[s].free_bufs.push(id);
+                }
+            });
+        }
+        auto peek_u64 = [&](const uint64_t* d, uint64_t k) {
+            uint64_t v = 0;
+            HIP_OK(hipMemcpyAsync(&v, d + k, sizeof v, hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+            return v;
+        };
+        std::exception_ptr failure;
+        try {
+            uint64_t at[2] = {0, 0};
+            while (at[0] < upto || at[1] < upto) {
+                for (int s = 0; s < 2; ++s) {
+                    if (at[s] >= upto) continue;
+                    // as many pairs as fill a window: from the average record size, halved until the bytes fit
+                    const uint64_t avg = std::max<uint64_t>(1, o[s].total / std::max<uint64_t>(1, upto - dups));
+                    uint64_t take = std::min<uint64_t>(upto - at[s], std::max<uint64_t>(1, window / avg));
+                    const uint64_t lo = peek_u64(o[s].dst_off.p, at[s]);
+                    uint64_t hi;
+                    for (;;) {
+                        hi = at[s] + take == upto ? o[s].total : peek_u64(o[s].dst_off.p, at[s] + take);
+                        if (hi - lo <= 2 * window || take == 1) break;
+                        take = std::max<uint64_t>(1, take / 2);
+                    }
+                    const uint64_t bytes = hi - lo;
+                    if (bytes) {
+                        int* id = o[s].free_bufs.pop();
+                        o[s].d_win.reserve(bytes + 64); o[s].buf[*id].reserve(bytes + 64);
+                        // dst_off is absolute in the output: the window's buffer starts `lo` bytes in
+                        engine_ok(fqd_copy_spans(eng.e, reinterpret_cast<const uint8_t*>(dev[s].text.p), o[s].src_off.p + at[s], o[s].len.p + at[s], take,
+                                                 reinterpret_cast<uint8_t*>(o[s].d_win.p) - lo, o[s].dst_off.p + at[s]));
+                        HIP_OK(hipMemcpyAsync(o[s].buf[*id].p, o[s].d_win.p, bytes, hipMemcpyDeviceToHost, stream));
+                        HIP_OK(hipStreamSynchronize(stream));
+                        o[s].bytes[*id] = bytes;
+                        o[s].full_bufs.push(id);
+                    }
+                    at[s] += take;
+                }
+            }
+        } catch (...) { failure = std::current_exception(); }
+        for (int s = 0; s < 2; ++s) { o[s].full_bufs.push(&kStop); o[s].writer.join(); }
+        if (failure) std::rethrow_exception(failure);
+        for (int s = 0; s < 2; ++s) { if (o[s].error) std::rethrow_exception(o[s].error); sinks[s]->close(); }
     }
     StageClock::report();
     if (jp.bad) throw_unknown_base(jp.bad_byte);

@@ -61,6 +61,7 @@ private:
     void run_ordered_multi(int n_files, const std::string* in, const std::string* out);
     void run_unordered(const std::string* in, const std::string* out);
     void run_unordered_in_memory(const std::string* in, const std::string* out);
+    void run_unordered_resident(const std::string* in, const std::string* out);
     void run_unordered_streaming(const std::string* in, const std::string* out);
     Format              format_;
     ssize_t             memlimit_;

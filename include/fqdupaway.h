@@ -285,6 +285,13 @@ int  fqd_count_tags_le(fqd_engine* e, const fqd_tags* t, const fqd_tags* other, 
 int  fqd_output_offsets(fqd_engine* e, const uint8_t* keep, const uint32_t* idx, uint64_t n, const uint32_t* sizes,
                         uint64_t* dest, uint64_t* total);
 
+/* The same for a run whose text stays in HBM, per PAIR instead of per record: for pair k (tag order, k < n)
+ * src_off[k] = starts[idx[k]] (where record idx[k] lies in the text), len[k] = sizes[idx[k]] if keep[k] else 0,
+ * dst_off[k] = sum of len[j], j < k (where it goes in the output); *total (host) = output size.  A window
+ * [a, b) of pairs is then assembled in output order by one fqd_copy_spans over src_off+a, len+a, dst_off+a. */
+int  fqd_output_plan(fqd_engine* e, const uint8_t* keep, const uint32_t* idx, uint64_t n, const uint64_t* starts,
+                     const uint32_t* sizes, uint64_t* src_off, uint32_t* len, uint64_t* dst_off, uint64_t* total);
+
 /* keep_out[origin[k]] = flags[k] for k < n: puts the flags that came back from the
  * owners (in partition order) into input order.  All device pointers. */
 int  fqd_scatter_flags(fqd_engine* e, const uint8_t* flags, const uint32_t* origin, uint64_t n, uint8_t* keep_out);

@@ -139,7 +139,7 @@ def test_paired_fast(exe, golden_dir, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["shuffled", "skewed", "deletion", "interleaved", "not_overlapped"])
 @pytest.mark.parametrize("full_join", ["0", "1"])
-@pytest.mark.parametrize("mode", ["memory", "stream"])
+@pytest.mark.parametrize("mode", ["memory", "resident", "twopass"])
 def test_unordered(exe, golden_dir, tmp_path, name, full_join, mode):
     # reference test/test_unordered.py:7-48 (both join rules, and both ways of running the join, reproduce the fixtures)
     fx = golden_dir / "reference_fixtures"
@@ -216,13 +216,15 @@ def test_pe_fastq_matches_oracle_bytes(exe, oracle, tmp_path):
 
 
 STREAM_ENV = {"memory": {"FQD_UNORDERED_MODE": "memory"},
-              # the bounded-memory way: both files streamed twice in 1 MiB blocks, outputs assembled in 64 KiB windows
-              # through temporary files (hash_dup_remover.cpp: run_unordered_streaming)
-              "stream": {"FQD_UNORDERED_MODE": "stream", "FQD_BLOCK_MB": "1", "FQD_STREAM_WINDOW_KB": "64"}}
+              # the bounded-memory ways (hash_dup_remover.cpp), in 1 MiB blocks and 64 KiB output windows:
+              # resident = one pass, the text of both files stays in HBM, outputs assembled there window by window;
+              # twopass  = only tags + sequences stay in HBM, the inputs are read again, windows go through temporary files
+              "resident": {"FQD_UNORDERED_MODE": "resident", "FQD_BLOCK_MB": "1", "FQD_STREAM_WINDOW_KB": "64"},
+              "twopass": {"FQD_UNORDERED_MODE": "twopass", "FQD_BLOCK_MB": "1", "FQD_STREAM_WINDOW_KB": "64"}}
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["memory", "stream"])
+@pytest.mark.parametrize("mode", ["memory", "resident", "twopass"])
 @pytest.mark.parametrize("style", ["illumina", "sra", "slash"])
 @pytest.mark.parametrize("full_join", ["0", "1"])
 def test_unordered_fastq_matches_oracle_bytes(exe, oracle, tmp_path, style, full_join, mode):
@@ -286,7 +288,7 @@ def test_gz_in_and_out(exe, oracle, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["memory", "stream"])
+@pytest.mark.parametrize("mode", ["memory", "resident", "twopass"])
 @pytest.mark.parametrize("full_join", ["0", "1"])
 def test_unordered_repeated_ids_pair_rank_by_rank(exe, oracle, tmp_path, full_join, mode):
     """IDs repeated inside one file and inside both (every copy used to pair with the same
@@ -357,15 +359,17 @@ def test_config4_shape_gz_unordered_2m_pairs(exe, oracle, tmp_path):
     g1, g2 = tmp_path / "g1.fq.gz", tmp_path / "g2.fq.gz"
     tot, dup, un = oracle.filter_paired(f1, f2, e1, e2, FASTQ, unordered=True, tail_rule=True)
     assert tot >= 2_000_000 and dup > 50_000 and un > 50_000
-    # in memory (the inputs inflate to ~1 GB: above the smallest --mem-limit, so "-m 500" alone would stream),
-    # then the bounded-memory way: "-m 500" = two passes over the .gz inputs, 125 MB output windows through
-    # temporary files in a directory created in the working directory (main.cpp:192) and removed at exit
-    for env, extra in (({"FQD_UNORDERED_MODE": "memory"}, []), ({}, ["-m", "500"])):
+    # in memory (the inputs inflate to ~1 GB: above the smallest --mem-limit, so "-m 500" alone streams them),
+    # then the bounded-memory ways under "-m 500": one pass with the text resident in HBM (the default), and the
+    # two-pass fallback with 125 MB output windows through temporary files in a directory created in the working
+    # directory (main.cpp:192) and removed at exit
+    for env, extra in (({"FQD_UNORDERED_MODE": "memory"}, []), ({}, ["-m", "500"]), ({"FQD_UNORDERED_MODE": "twopass"}, ["-m", "500"])):
         for g in (g1, g2):
             g.unlink(missing_ok=True)
         r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", *extra, env={"FQD_GZ_LEVEL": "1", "FQD_HOST_TIMING": "1", **env}, cwd=tmp_path)
         assert r.returncode == 0, r.stderr
-        assert ("unordered/stream: pass 2" in r.stderr) == bool(extra), r.stderr
+        assert ("unordered/resident: survivors out of HBM" in r.stderr) == (bool(extra) and not env), r.stderr
+        assert ("unordered/stream: pass 2" in r.stderr) == (env.get("FQD_UNORDERED_MODE") == "twopass"), r.stderr
         assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
                             f"{un} Non-matching entries from both files were skipped.\n")
         assert [p.name for p in tmp_path.iterdir() if p.is_dir()] == []
@@ -636,7 +640,7 @@ def test_differential_fuzz_single_and_paired_with_injected_errors(exe, oracle, t
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["memory", "stream"])
+@pytest.mark.parametrize("mode", ["memory", "resident", "twopass"])
 def test_unordered_differential_fuzz_with_injected_errors(exe, oracle, tmp_path, mode):
     """--unordered on random small paired inputs — clean, or with one defect in either file (unknown base,
     bad lead byte, quality of another length, a line missing, empty file) — through the CLI (held in memory

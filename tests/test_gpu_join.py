@@ -270,6 +270,29 @@ def test_device_halves_of_the_streaming_run():
         assert tot == int(kept_sizes.sum())
         assert np.array_equal(d_dest.cpu().numpy(), exp_dest)
 
+        # the same per pair (text resident in HBM): source offset, length (0 when dropped), destination offset;
+        # then one window of the output assembled by fqd_copy_spans
+        rec_start = np.concatenate([[0], np.cumsum(sizes[:-1], dtype=np.uint64)]).astype(np.uint64)
+        text = rng.integers(32, 127, size=int(sizes.sum()) + 16, dtype=np.uint8)
+        d_start, d_text = to_dev(rec_start, text)
+        i64 = dict(dtype=torch.int64, device="cuda")
+        d_src, d_dst = torch.empty(n_pairs, **i64), torch.empty(n_pairs, **i64)
+        d_len = torch.empty(n_pairs, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        tot2 = e.output_plan(d_keep, d_idx, n_pairs, d_start, d_sz, d_src, d_len, d_dst)
+        assert tot2 == tot
+        assert np.array_equal(d_src.cpu().numpy().view(np.uint64), rec_start[idx])
+        assert np.array_equal(d_len.cpu().numpy().view(np.uint32), kept_sizes.astype(np.uint32))
+        assert np.array_equal(d_dst.cpu().numpy(), starts)
+        a, b = 10000, 30000                                   # pairs [a, b) -> bytes [starts[a], starts[b])
+        lo, hi = int(starts[a]), int(starts[b])
+        d_win = torch.zeros(hi - lo + 16, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        e.copy_spans(d_text, d_src[a:], d_len[a:], b - a, d_win.data_ptr() - lo, d_dst[a:])
+        e.sync()
+        exp_win = np.concatenate([text[int(rec_start[idx[k]]):int(rec_start[idx[k]]) + int(sizes[idx[k]])] for k in range(a, b) if keep[k]])
+        assert np.array_equal(d_win.cpu().numpy()[: hi - lo], exp_win)
+
 
 def test_join_fuzz_small_cases_against_the_oracle(oracle):
     """Many small joins — tags drawn from tiny alphabets so that repeats, prefixes of each other, empty tags

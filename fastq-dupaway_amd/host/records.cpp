@@ -116,7 +116,7 @@ unsigned host_threads()
 {
     if (const char* v = std::getenv("FQD_HOST_THREADS")) return static_cast<unsigned>(std::max(1, std::atoi(v)));
     const unsigned hw = std::thread::hardware_concurrency();
-    return std::max(1u, std::min(8u, hw ? hw : 1u));
+    return std::max(1u, std::min(16u, hw ? hw : 1u));      // measured on the GPU box (BGZF inflate + scan of one file): 8 -> 16 threads = 2.1 -> 1.5 s per 6.3 GB
 }
 
 namespace {

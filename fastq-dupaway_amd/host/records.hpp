@@ -77,7 +77,7 @@ void run_parts(unsigned parts, Body&& body)
     for (unsigned p = 0; p < parts; ++p) if (err[p]) std::rethrow_exception(err[p]);
 }
 
-// Worker threads a host stage may use: FQD_HOST_THREADS, else min(8, hardware threads).
+// Worker threads a host stage may use: FQD_HOST_THREADS, else min(16, hardware threads).
 unsigned host_threads();
 
 // Order of two ID tags: strncmp over the shorter, then shorter first (fastqview.cpp:168-178).

@@ -764,34 +764,29 @@ bool is_regular_file(const std::string& name, uint64_t& size)
 // dedup the joined pairs in tag order, write survivors in tag order.
 //
 // The reference bounds its memory here with ExternalSorter(memlimit) (hpp:165,171;
-// external_sort.hpp:95): sorted chunk files on disk, merged.  This build has two ways:
-//   * inputs that fit --mem-limit (or cannot be read twice: pipes) are held in pinned memory and
-//     handled in one pass (run_unordered_in_memory);
-//   * anything larger is streamed ONCE through a few pinned blocks into HBM, where the whole text of both
-//     files stays (run_unordered_resident; configs[4]: 2 x 32 GB of 288): the device joins, dedups and then
-//     assembles the outputs window by window in output order; the host only reads, and writes what comes back;
+// external_sort.hpp:95): sorted chunk files on disk, merged.  This build:
+//   * streams both files ONCE through a few pinned blocks (each at most limit/16 bytes) into HBM, where the
+//     whole text of both files stays (run_unordered_resident; configs[4]: 2 x 32 GB of 288): the device joins,
+//     dedups and then assembles the outputs window by window in output order; the host only reads, and writes
+//     what comes back;
 //   * what not even HBM can hold is streamed TWICE (run_unordered_streaming): the first pass leaves every
 //     record's tag and sequence in HBM (about 190 bytes per 150-bp record), the device decides everything
 //     (pairs, survivors, where every surviving record starts in the output), the second pass puts the records
 //     there through window files in the temporary directory.
-// Host memory stays within the limit whatever the input size.  FQD_UNORDERED_MODE=memory|resident|twopass
-// forces one of them.
+//   * FQD_UNORDERED_MODE=memory: round 1's way — both files also held in pinned host memory, survivors written
+//     from there (run_unordered_in_memory); kept as a cross-check of the other two.
+// Host memory stays within the limit whatever the input size in the first two.
 void HashDupRemover::run_unordered(const std::string* in, const std::string* out)
 {
     uint64_t sz[2] = {0, 0};
     const bool regular = is_regular_file(in[0], sz[0]) && is_regular_file(in[1], sz[1]);
-    uint64_t estimate = 0;
-    for (int s = 0; s < 2; ++s) estimate += has_gz_extension(in[s]) ? sz[s] * 4 : sz[s];     // FASTQ deflates to about a quarter
-    bool stream = regular && memlimit_ > 0 && estimate > static_cast<uint64_t>(memlimit_);
     std::string forced;
     if (const char* m = std::getenv("FQD_UNORDERED_MODE")) forced = m;
-    if (forced == "memory") stream = false;
-    if (forced == "stream" || forced == "resident") stream = true;                  // one pass: pipes qualify too
-    if (forced == "twopass") { if (regular) run_unordered_streaming(in, out); else run_unordered_in_memory(in, out); return; }
-    if (!stream) { run_unordered_in_memory(in, out); return; }
-    // Above the limit: the text of both files goes to HBM block by block and stays there (one pass, nothing
-    // kept on the host).  Only when 288 GB cannot hold it are tags and sequences alone kept and the inputs
-    // read a second time.
+    if (forced == "memory") { run_unordered_in_memory(in, out); return; }
+    if (forced == "twopass" && regular) { run_unordered_streaming(in, out); return; }
+    // The text of both files goes to HBM block by block and stays there (one pass, nothing kept on the
+    // host: within any --mem-limit, pipes included).  Only when 288 GB cannot hold it are tags and
+    // sequences alone kept and the inputs read a second time.
     try { run_unordered_resident(in, out); }
     catch (const DeviceOutOfMemory&) {
         if (!regular) throw;

@@ -945,39 +945,59 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
     // ---- the one pass: every block to the tail of the file's text in HBM -------------------------------
     {
         StageClock::Scope t("unordered/resident: read, scan, text to HBM");
-        Pinned<uint64_t> h_start, h_seq; Pinned<uint32_t> h_idl, h_sql, h_size;
-        for (int s = 0; s < 2; ++s) {                          // file 1 completely before file 2 is touched (hpp:161-173)
-            FileOnDevice& f = dev[s];
-            uint64_t known = 0;
-            if (is_regular_file(in[s], known) && !has_gz_extension(in[s])) f.text.room_for(known + 64, stream);   // no regrowth for plain files
-            Side side;
-            side.open_file(in[s], format_, true, block_bytes);
-            side.prime(3, tuning_.device);
-            while (side.available() > 0) {
-                PooledBlock* b = side.cur;
-                const size_t from = side.pos, nb = b->recs.size() - from;
-                const RecordRef* r = &b->recs[from];
-                const uint64_t text_lo = r[0].start, bytes = r[nb - 1].start + r[nb - 1].size - text_lo;
-                f.text.room_for(bytes + 64, stream);
-                HIP_OK(hipMemcpyAsync(f.text.p + f.text.used, b->text.p + text_lo, bytes, hipMemcpyHostToDevice, stream));
-                h_start.reserve(nb); h_seq.reserve(nb); h_idl.reserve(nb); h_sql.reserve(nb); h_size.reserve(nb);
-                for (size_t k = 0; k < nb; ++k) {
-                    h_start.p[k] = f.text.used + (r[k].start - text_lo); h_seq.p[k] = h_start.p[k] + r[k].id_len;
-                    h_idl.p[k] = r[k].id_len; h_sql.p[k] = r[k].seq_len; h_size.p[k] = r[k].size;
+        // both files at the same time, each on its own thread and copy stream; what goes wrong is still
+        // reported in the reference's order: everything about file 1 before anything about file 2 (hpp:161-173)
+        std::exception_ptr err[2];
+        ParseFailure parse_failure[2];
+        auto load = [&](int s) {
+            try {
+                HIP_OK(hipSetDevice(tuning_.device));
+                hipStream_t up = nullptr;
+                HIP_OK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+                struct Guard { hipStream_t s; ~Guard() { (void)hipStreamDestroy(s); } } g{up};
+                Pinned<uint64_t> h_start, h_seq; Pinned<uint32_t> h_idl, h_sql, h_size;
+                FileOnDevice& f = dev[s];
+                uint64_t known = 0;
+                if (is_regular_file(in[s], known) && !has_gz_extension(in[s])) f.text.room_for(known + 64, up);   // no regrowth for plain files
+                Side side;
+                side.open_file(in[s], format_, true, block_bytes);
+                side.prime(3, tuning_.device);
+                while (side.available() > 0) {
+                    PooledBlock* b = side.cur;
+                    const size_t from = side.pos, nb = b->recs.size() - from;
+                    const RecordRef* r = &b->recs[from];
+                    const uint64_t text_lo = r[0].start, bytes = r[nb - 1].start + r[nb - 1].size - text_lo;
+                    f.text.room_for(bytes + 64, up);
+                    HIP_OK(hipMemcpyAsync(f.text.p + f.text.used, b->text.p + text_lo, bytes, hipMemcpyHostToDevice, up));
+                    h_start.reserve(nb); h_seq.reserve(nb); h_idl.reserve(nb); h_sql.reserve(nb); h_size.reserve(nb);
+                    for (size_t k = 0; k < nb; ++k) {
+                        h_start.p[k] = f.text.used + (r[k].start - text_lo); h_seq.p[k] = h_start.p[k] + r[k].id_len;
+                        h_idl.p[k] = r[k].id_len; h_sql.p[k] = r[k].seq_len; h_size.p[k] = r[k].size;
+                    }
+                    f.start.room_for(nb, up); f.seq_off.room_for(nb, up); f.id_len.room_for(nb, up); f.seq_len.room_for(nb, up); f.size.room_for(nb, up);
+                    HIP_OK(hipMemcpyAsync(f.start.p + f.n, h_start.p, nb * sizeof(uint64_t), hipMemcpyHostToDevice, up));
+                    HIP_OK(hipMemcpyAsync(f.seq_off.p + f.n, h_seq.p, nb * sizeof(uint64_t), hipMemcpyHostToDevice, up));
+                    HIP_OK(hipMemcpyAsync(f.id_len.p + f.n, h_idl.p, nb * sizeof(uint32_t), hipMemcpyHostToDevice, up));
+                    HIP_OK(hipMemcpyAsync(f.seq_len.p + f.n, h_sql.p, nb * sizeof(uint32_t), hipMemcpyHostToDevice, up));
+                    HIP_OK(hipMemcpyAsync(f.size.p + f.n, h_size.p, nb * sizeof(uint32_t), hipMemcpyHostToDevice, up));
+                    HIP_OK(hipStreamSynchronize(up));            // the block and the staging arrays are reused
+                    f.text.used += bytes;
+                    f.start.used = f.seq_off.used = f.id_len.used = f.seq_len.used = f.size.used = f.n + nb;
+                    f.n += nb;
+                    side.pos += nb;
                 }
-                f.start.room_for(nb, stream); f.seq_off.room_for(nb, stream); f.id_len.room_for(nb, stream); f.seq_len.room_for(nb, stream); f.size.room_for(nb, stream);
-                HIP_OK(hipMemcpyAsync(f.start.p + f.n, h_start.p, nb * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-                HIP_OK(hipMemcpyAsync(f.seq_off.p + f.n, h_seq.p, nb * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-                HIP_OK(hipMemcpyAsync(f.id_len.p + f.n, h_idl.p, nb * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-                HIP_OK(hipMemcpyAsync(f.seq_len.p + f.n, h_sql.p, nb * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-                HIP_OK(hipMemcpyAsync(f.size.p + f.n, h_size.p, nb * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-                HIP_OK(hipStreamSynchronize(stream));            // the block and the staging arrays are reused
-                f.text.used += bytes;
-                f.start.used = f.seq_off.used = f.id_len.used = f.seq_len.used = f.size.used = f.n + nb;
-                f.n += nb;
-                side.pos += nb;
-            }
-            if (side.failed) { std::cerr << side.failure.diag; throw std::runtime_error(side.failure.what); }
+                if (side.failed) parse_failure[s] = side.failure;
+            } catch (...) { err[s] = std::current_exception(); }
+        };
+        std::thread second(load, 1);
+        load(0);
+        second.join();
+        for (int s = 0; s < 2; ++s) {
+            if (err[s]) std::rethrow_exception(err[s]);
+            if (parse_failure[s].set) { std::cerr << parse_failure[s].diag; throw std::runtime_error(parse_failure[s].what); }
+        }
+        for (int s = 0; s < 2; ++s) {
+            FileOnDevice& f = dev[s];
             f.tag_off.reserve(f.n); f.tag_len.reserve(f.n);
             engine_ok(fqd_extract_tags(eng.e, reinterpret_cast<const uint8_t*>(f.text.p), f.start.p, f.id_len.p, f.n, f.tag_off.p, f.tag_len.p));
         }

@@ -257,27 +257,31 @@ constexpr size_t kGzMember = 16 * kBgzfInput;             // input bytes per def
 
 // The BGZF members (header with the 'BC' size field + raw deflate stream + CRC/length trailer)
 // for `raw`, one per kBgzfInput bytes.
-std::string deflate_member(std::string raw)
+std::string deflate_range(const char* raw, size_t raw_size);
+std::string deflate_member(std::string raw) { return deflate_range(raw.data(), raw.size()); }
+
+// The same over bytes that stay where they are (they must outlive the job).
+std::string deflate_range(const char* raw, size_t raw_size)
 {
     std::string out;
-    out.reserve(raw.size() / 3 + 1024);
+    out.reserve(raw_size / 3 + 1024);
     z_stream zs{};
     // zlib's default level, as the reference's Boost gzip filter uses; FQD_GZ_LEVEL=1..9 trades size for speed
     static const int level = [] { const char* v = std::getenv("FQD_GZ_LEVEL"); const int l = v ? std::atoi(v) : 0; return l >= 1 && l <= 9 ? l : Z_DEFAULT_COMPRESSION; }();
     if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK)
         throw std::runtime_error("zlib: deflateInit2 failed");
     unsigned char body[65536];
-    for (size_t at = 0; at < raw.size(); at += kBgzfInput) {
-        const size_t len = std::min(kBgzfInput, raw.size() - at);
+    for (size_t at = 0; at < raw_size; at += kBgzfInput) {
+        const size_t len = std::min(kBgzfInput, raw_size - at);
         deflateReset(&zs);
-        zs.next_in = reinterpret_cast<Bytef*>(&raw[at]);
+        zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(raw + at));
         zs.avail_in = static_cast<uInt>(len);
         zs.next_out = body;
         zs.avail_out = static_cast<uInt>(sizeof body - 26);
         if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); throw std::runtime_error("zlib: deflate failed"); }
         const size_t clen = sizeof body - 26 - zs.avail_out;
         const size_t total = 18 + clen + 8;
-        const uLong crc = crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(&raw[at]), static_cast<uInt>(len));
+        const uLong crc = crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(raw + at), static_cast<uInt>(len));
         const unsigned char head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0,
                                         static_cast<unsigned char>((total - 1) & 0xFF), static_cast<unsigned char>((total - 1) >> 8)};
         const unsigned char tail[8] = {static_cast<unsigned char>(crc), static_cast<unsigned char>(crc >> 8),
@@ -305,6 +309,7 @@ OutputFile::OutputFile(const std::string& name) : gz_(has_gz_extension(name)), n
         block_.reserve(kGzMember + 65536);
         const unsigned hw = std::thread::hardware_concurrency();
         max_in_flight_ = hw >= 32 ? 16 : (hw >= 16 ? 8 : (hw >= 4 ? hw / 2 : 1));    // deflate jobs in flight (16 BGZF members each)
+        if (const char* v = std::getenv("FQD_GZ_JOBS")) { const int x = std::atoi(v); if (x > 0) max_in_flight_ = static_cast<size_t>(x); }
     } else {
         fd_ = ::open(name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
         if (fd_ < 0) throw_cannot_open(name);
@@ -337,6 +342,19 @@ void OutputFile::submit_block()
     block_.reserve(kGzMember + 65536);
     in_flight_.push_back(std::async(std::launch::async, deflate_member, std::move(raw)));
     drain(max_in_flight_);
+}
+
+// A large buffer the caller lends until the call returns: gzip members are deflated straight out of it on
+// the worker threads (write() would first copy every byte into the member being filled).
+void OutputFile::write_borrowed(const char* p, size_t n)
+{
+    if (!gz_ || n < 4 * kGzMember) { write(p, n); return; }
+    submit_block();                                           // a member may be short: what was pending goes first
+    for (size_t at = 0; at < n; at += kGzMember) {
+        in_flight_.push_back(std::async(std::launch::async, deflate_range, p + at, std::min(kGzMember, n - at)));
+        drain(max_in_flight_);
+    }
+    drain(0);                                                 // nothing refers to the buffer any more
 }
 
 void OutputFile::put_plain(const char* p, size_t n)

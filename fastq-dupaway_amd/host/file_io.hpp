@@ -68,6 +68,8 @@ public:
     OutputFile(const OutputFile&) = delete;
     OutputFile& operator=(const OutputFile&) = delete;
     void write(const char* p, size_t n);
+    // The same for a large buffer lent until the call returns: .gz members are deflated straight out of it.
+    void write_borrowed(const char* p, size_t n);
     // Several pieces in one go: plain files hand them to writev() as they lie (no staging copy).
     struct Piece { const char* p; size_t n; };
     // threads > 1: a large batch into a regular plain file is written by that many threads at once (pwritev).

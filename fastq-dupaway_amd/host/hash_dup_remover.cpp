@@ -1045,7 +1045,7 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
                 for (;;) {
                     int* id = o[s].full_bufs.pop();
                     if (*id < 0) break;
-                    try { if (!o[s].error) sinks[s]->write(o[s].buf[*id].p, o[s].bytes[*id]); }
+                    try { if (!o[s].error) sinks[s]->write_borrowed(o[s].buf[*id].p, o[s].bytes[*id]); }
                     catch (...) { o[s].error = std::current_exception(); }
                     o[s].free_bufs.push(id);
                 }

@@ -808,6 +808,12 @@ int sort_union(fqd_engine* e, hipStream_t stream, const Union& u, const SortBuff
         JOIN_TRY(e, hipStreamSynchronize(stream));       // the key width decides how many passes are launched
     }
     const uint32_t B = info[0];
+    // Every 64 key bits cost an encode and up to eight radix passes over all records: tags that need tens of
+    // thousands of bits (IDs of kilobytes that differ all along) would keep the device busy for minutes to
+    // hours.  Refused with a clear message rather than left running; the reference has no such limit.
+    if (B > 32768u)
+        return fqd_internal_fail(e, FQD_ERR_ARG, "ID tags need more than 32768 key bits (tags of several kilobytes that differ "
+                                                 "throughout): not supported by the device join");
     const uint32_t W = (B + 63u) / 64u;
     int cur = 0;
     for (uint32_t word = 0; word < W; ++word) {        // least significant word first

@@ -3,6 +3,7 @@
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <algorithm>
 #include <iostream>
@@ -52,7 +53,46 @@ size_t bgzf_member_size(const unsigned char* p, size_t avail, size_t* data_off)
     return 0;
 }
 
+// libdeflate (the whole-buffer DEFLATE library htslib also uses for BGZF) when the system has it: two to
+// three times zlib's speed on 64 KB members, same format.  Looked up at run time by its soname — the image
+// ships the library without its header, so the handful of entry points used are declared here as its
+// documented C API has them.  Absent (or FQD_CODEC=zlib): zlib does the same work.
+struct FastCodec {
+    void* (*alloc_compressor)(int level) = nullptr;
+    size_t (*compress)(void*, const void* in, size_t in_n, void* out, size_t out_avail) = nullptr;    // 0: did not fit
+    void (*free_compressor)(void*) = nullptr;
+    void* (*alloc_decompressor)() = nullptr;
+    int (*decompress)(void*, const void* in, size_t in_n, void* out, size_t out_avail, size_t* actual) = nullptr;   // 0: ok
+    void (*free_decompressor)(void*) = nullptr;
+    uint32_t (*crc32)(uint32_t crc, const void* buf, size_t n) = nullptr;
+
+    static const FastCodec* get()
+    {
+        static const FastCodec* codec = []() -> const FastCodec* {
+            const char* pick = std::getenv("FQD_CODEC");
+            if (pick && std::strcmp(pick, "zlib") == 0) return nullptr;
+            void* h = ::dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+            if (!h) return nullptr;
+            static FastCodec c;
+            auto sym = [&](const char* name) { return ::dlsym(h, name); };
+            c.alloc_compressor = reinterpret_cast<decltype(c.alloc_compressor)>(sym("libdeflate_alloc_compressor"));
+            c.compress = reinterpret_cast<decltype(c.compress)>(sym("libdeflate_deflate_compress"));
+            c.free_compressor = reinterpret_cast<decltype(c.free_compressor)>(sym("libdeflate_free_compressor"));
+            c.alloc_decompressor = reinterpret_cast<decltype(c.alloc_decompressor)>(sym("libdeflate_alloc_decompressor"));
+            c.decompress = reinterpret_cast<decltype(c.decompress)>(sym("libdeflate_deflate_decompress"));
+            c.free_decompressor = reinterpret_cast<decltype(c.free_decompressor)>(sym("libdeflate_free_decompressor"));
+            c.crc32 = reinterpret_cast<decltype(c.crc32)>(sym("libdeflate_crc32"));
+            if (!c.alloc_compressor || !c.compress || !c.free_compressor || !c.alloc_decompressor || !c.decompress ||
+                !c.free_decompressor || !c.crc32) return nullptr;
+            return &c;
+        }();
+        return codec;
+    }
+};
+
 } // namespace
+
+const char* gz_codec_name() { return FastCodec::get() ? "libdeflate" : "zlib"; }
 
 InputFile::InputFile(const std::string& name) : gz_(has_gz_extension(name))
 {
@@ -162,7 +202,24 @@ size_t InputFile::read_bgzf(char* dst, size_t n, unsigned threads)
         batch.resize(used);
         const unsigned parts = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(threads, batch.size() / 8)));
         std::vector<int> bad(parts, 0);
+        const FastCodec* fast = FastCodec::get();
         auto work = [&](unsigned p) {
+            if (fast) {
+                void* d = fast->alloc_decompressor();
+                if (!d) { bad[p] = 1; return; }
+                for (size_t k = p; k < batch.size(); k += parts) {
+                    const Member& m = batch[k];
+                    if (m.isize == 0) continue;
+                    const unsigned char* src = comp_.data() + m.at;
+                    const unsigned char* t = src + m.total - 8;
+                    const uint32_t want_crc = t[0] | (uint32_t(t[1]) << 8) | (uint32_t(t[2]) << 16) | (uint32_t(t[3]) << 24);
+                    size_t actual = 0;
+                    if (fast->decompress(d, src + m.data_off, m.total - m.data_off - 8, target[k], m.isize, &actual) != 0 ||
+                        actual != m.isize || fast->crc32(0, target[k], m.isize) != want_crc) { bad[p] = 1; break; }
+                }
+                fast->free_decompressor(d);
+                return;
+            }
             z_stream zs{};
             if (inflateInit2(&zs, -15) != Z_OK) { bad[p] = 1; return; }
             for (size_t k = p; k < batch.size(); k += parts) {
@@ -268,20 +325,31 @@ std::string deflate_range(const char* raw, size_t raw_size)
     z_stream zs{};
     // zlib's default level, as the reference's Boost gzip filter uses; FQD_GZ_LEVEL=1..9 trades size for speed
     static const int level = [] { const char* v = std::getenv("FQD_GZ_LEVEL"); const int l = v ? std::atoi(v) : 0; return l >= 1 && l <= 9 ? l : Z_DEFAULT_COMPRESSION; }();
-    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK)
-        throw std::runtime_error("zlib: deflateInit2 failed");
+    const FastCodec* fast = FastCodec::get();
+    void* fc = fast ? fast->alloc_compressor(level == Z_DEFAULT_COMPRESSION ? 6 : level) : nullptr;
+    bool zs_ready = false;
     unsigned char body[65536];
     for (size_t at = 0; at < raw_size; at += kBgzfInput) {
         const size_t len = std::min(kBgzfInput, raw_size - at);
-        deflateReset(&zs);
-        zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(raw + at));
-        zs.avail_in = static_cast<uInt>(len);
-        zs.next_out = body;
-        zs.avail_out = static_cast<uInt>(sizeof body - 26);
-        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); throw std::runtime_error("zlib: deflate failed"); }
-        const size_t clen = sizeof body - 26 - zs.avail_out;
+        size_t clen = fc ? fast->compress(fc, raw + at, len, body, sizeof body - 26) : 0;
+        if (clen == 0) {                                         // no libdeflate, or its output did not fit a member
+            if (!zs_ready) {
+                if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+                    if (fc) fast->free_compressor(fc);
+                    throw std::runtime_error("zlib: deflateInit2 failed");
+                }
+                zs_ready = true;
+            }
+            deflateReset(&zs);
+            zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(raw + at));
+            zs.avail_in = static_cast<uInt>(len);
+            zs.next_out = body;
+            zs.avail_out = static_cast<uInt>(sizeof body - 26);
+            if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); if (fc) fast->free_compressor(fc); throw std::runtime_error("zlib: deflate failed"); }
+            clen = sizeof body - 26 - zs.avail_out;
+        }
         const size_t total = 18 + clen + 8;
-        const uLong crc = crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(raw + at), static_cast<uInt>(len));
+        const uLong crc = fast ? fast->crc32(0, raw + at, len) : crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(raw + at), static_cast<uInt>(len));
         const unsigned char head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0,
                                         static_cast<unsigned char>((total - 1) & 0xFF), static_cast<unsigned char>((total - 1) >> 8)};
         const unsigned char tail[8] = {static_cast<unsigned char>(crc), static_cast<unsigned char>(crc >> 8),
@@ -291,7 +359,8 @@ std::string deflate_range(const char* raw, size_t raw_size)
         out.append(reinterpret_cast<const char*>(body), clen);
         out.append(reinterpret_cast<const char*>(tail), sizeof tail);
     }
-    deflateEnd(&zs);
+    if (zs_ready) deflateEnd(&zs);
+    if (fc) fast->free_compressor(fc);
     return out;
 }
 

@@ -29,6 +29,9 @@ struct DiagnosedError : std::runtime_error {
 // (file_utils.hpp:111-121).
 [[noreturn]] void throw_cannot_open(const std::string& name);
 
+// "libdeflate" when the system library was found (and FQD_CODEC != zlib), else "zlib": what BGZF members go through.
+const char* gz_codec_name();
+
 class InputFile {
 public:
     explicit InputFile(const std::string& name);

@@ -1,4 +1,5 @@
 #include "records.hpp"
+#include "file_io.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -106,6 +107,7 @@ void StageClock::report()
 {
     if (!on()) return;
     std::lock_guard<std::mutex> g(g_clock_mutex);
+    std::fprintf(stderr, "[host timing] .gz members through %s\n", gz_codec_name());
     for (const auto& kv : g_clock) std::fprintf(stderr, "[host timing] %-28s %8.3f s  (%llu)\n", kv.first.c_str(), kv.second.first,
                                                 static_cast<unsigned long long>(kv.second.second));
 }

@@ -3,6 +3,7 @@
 inflated member by member on several threads, ordinary gzip inputs still go through zlib's
 gzread, plain files are read with several preads — always the same bytes."""
 import gzip
+import os
 import subprocess
 from pathlib import Path
 
@@ -23,17 +24,41 @@ def fnv(data: bytes) -> int:
 
 
 @pytest.fixture(scope="module")
-def io():
+def build():
     deps = [SRC, HOST / "file_io.cpp", HOST / "file_io.hpp"]
     if not EXE.exists() or EXE.stat().st_mtime < max(d.stat().st_mtime for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(EXE), str(SRC), str(HOST / "file_io.cpp"), "-lz", "-lpthread"],
                        check=True, capture_output=True)
+    return EXE
 
+
+def runner(codec):
     def run(*args, ok=True):
-        r = subprocess.run([str(EXE), *map(str, args)], capture_output=True, text=True)
+        r = subprocess.run([str(EXE), *map(str, args)], capture_output=True, text=True, env=dict(os.environ, FQD_CODEC=codec))
         assert (r.returncode == 0) == ok, r.stderr
         return r.stdout.split(), r.stderr
     return run
+
+
+# BGZF members go through libdeflate when the system has it and through zlib otherwise (FQD_CODEC=zlib
+# forces the latter): every test runs under both.
+@pytest.fixture(params=["zlib", "auto"])
+def io(build, request):
+    return runner(request.param)
+
+
+def test_codecs_read_each_other(build, tmp_path):
+    outs = {}
+    for codec in ("zlib", "auto"):
+        out = tmp_path / f"{codec}.fq.gz"
+        (length, h), _ = runner(codec)("w", out, 1_000_003, 7)
+        outs[codec] = (out, length, h)
+    assert outs["zlib"][1:] == outs["auto"][1:]
+    for writer, (out, length, h) in outs.items():
+        for reader in ("zlib", "auto"):
+            (l2, h2), _ = runner(reader)("r", out, 300_000, 4)
+            assert (l2, h2) == (length, h), (writer, reader)
+        assert len(gzip.open(out, "rb").read()) == int(length)
 
 
 @pytest.mark.parametrize("n", [0, 1, 65279, 65280, 65281, 3_000_001])

@@ -114,6 +114,9 @@ def load_library():
     L.fqd_output_offsets.argtypes = [vp, vp, vp, u64, vp, vp, C.POINTER(u64)]
     L.fqd_output_plan.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, vp, C.POINTER(u64)]
     L.fqd_scatter_flags.argtypes = [vp, vp, vp, u64, vp]
+    L.fqd_bgzf_bound.argtypes = [u64]
+    L.fqd_bgzf_bound.restype = u64
+    L.fqd_bgzf_deflate.argtypes = [vp, vp, u64, u32, vp, u64, C.POINTER(u64)]
     L.fqd_partition_keys.argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
     L.fqd_reserve_keys.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
     L.fqd_insert_keys.argtypes = [vp, vp, u64, u32, u32, vp]
@@ -129,7 +132,7 @@ def load_library():
     L.fqd_synth_reads.argtypes = [vp, u64, u64, u64, u32, u32, i32, vp, vp]
     for name in declared_symbols():
         fn = getattr(L, name)          # AttributeError here = header and library disagree
-        if name not in ("fqd_last_error", "fqd_key_words", "fqd_engine_stream"):
+        if name not in ("fqd_last_error", "fqd_key_words", "fqd_engine_stream", "fqd_bgzf_bound"):
             fn.restype = i32
     _lib = L
     return L

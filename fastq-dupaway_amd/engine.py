@@ -236,6 +236,16 @@ class Engine:
     def copy_spans(self, src, src_off, lens, n: int, dst, dst_off):
         self._check(self._L.fqd_copy_spans(self._h, _addr(src), _addr(src_off), _addr(lens), n, _addr(dst), _addr(dst_off)))
 
+    def bgzf_bound(self, n: int) -> int:
+        return int(self._L.fqd_bgzf_bound(n))
+
+    def bgzf_deflate(self, src, n: int, dst, lines_per_record: int = 4) -> int:
+        """BGZF members for the n bytes at src (device) written to dst (device, >= bgzf_bound(n) bytes);
+        returns their total size.  The end-of-file marker is the caller's to append."""
+        total = C.c_uint64(0)
+        self._check(self._L.fqd_bgzf_deflate(self._h, _addr(src), n, lines_per_record, _addr(dst), dst.numel(), C.byref(total)))
+        return int(total.value)
+
     def count_tags_le(self, t, other, other_index: int) -> int:
         """Records of t = (bytes, offsets, lengths, n) whose tag is <= the tag of record other_index of `other`."""
         tt, to = self._tags(*t), self._tags(*other)

@@ -292,6 +292,19 @@ int  fqd_output_offsets(fqd_engine* e, const uint8_t* keep, const uint32_t* idx,
 int  fqd_output_plan(fqd_engine* e, const uint8_t* keep, const uint32_t* idx, uint64_t n, const uint64_t* starts,
                      const uint32_t* sizes, uint64_t* src_off, uint32_t* len, uint64_t* dst_off, uint64_t* total);
 
+/* `.gz` output made in HBM: the n bytes at src (device; text of FASTQ/FASTA records, a record = `lines_per_record`
+ * lines: 4 or 2) become BGZF — gzip members (RFC 1952) of at most 65280 input bytes, each carrying its
+ * compressed size in a 'BC' extra field — written back to back at dst (device, dst_capacity >=
+ * fqd_bgzf_bound(n)); *out_bytes (host) = their total size.  The end-of-file marker member is the caller's to
+ * append.  One deflate block per member: literals, byte runs and matches against the same column one record up,
+ * under one pair of dynamic Huffman codes per call; a member that would not shrink is stored; CRC-32 computed on
+ * the device.  Any inflater reads it; the ratio is about that of zlib level 1-2.  Returns when dst is complete.
+ * Replaces the gzip compressor the reference pushes onto its output stream (file_utils.hpp:71-82) for outputs
+ * whose bytes are already on the device. */
+uint64_t fqd_bgzf_bound(uint64_t n);
+int  fqd_bgzf_deflate(fqd_engine* e, const uint8_t* src, uint64_t n, uint32_t lines_per_record,
+                      uint8_t* dst, uint64_t dst_capacity, uint64_t* out_bytes);
+
 /* keep_out[origin[k]] = flags[k] for k < n: puts the flags that came back from the
  * owners (in partition order) into input order.  All device pointers. */
 int  fqd_scatter_flags(fqd_engine* e, const uint8_t* flags, const uint32_t* origin, uint64_t n, uint8_t* keep_out);

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--dir", default="/dev/shm/fqd_c4")
     ap.add_argument("--gz-level", default="1", help="deflate level of inputs and outputs (the reference's default is 6)")
     ap.add_argument("--mem-limit", default="", help="-m value in MB (default: the CLI's 2048)")
+    ap.add_argument("--also", default="", help="further timed runs on the same inputs, each under extra environment settings: "
+                                               "'FQD_HOST_THREADS=8;FQD_HOST_THREADS=32,FQD_GZ_LEVEL=6' (only their -v lines are checked)")
     a = ap.parse_args()
     import torch
     from fastq_dupaway_amd import Engine, _lib
@@ -101,6 +103,15 @@ def main():
     ok = r.returncode == 0 and r.stdout == (f"{n} valid read pairs processed, out of which {dups} duplicates were removed.\n"
                                              f"0 Non-matching entries from both files were skipped.\n")
     log("-v lines == closed form:", ok)
+    for extra in filter(None, a.also.split(";")):
+        env = dict(os.environ, FQD_GZ_LEVEL=a.gz_level, FQD_HOST_TIMING="1")
+        env.update(kv.split("=", 1) for kv in extra.split(","))
+        t1 = time.perf_counter()
+        r2 = subprocess.run(cmd, capture_output=True, text=True, cwd=str(d), env=env)
+        dt2 = time.perf_counter() - t1
+        stages = "; ".join(l.split("] ", 1)[1].split("  (")[0] for l in r2.stderr.splitlines() if "unordered" in l)
+        log(f"also [{extra}]: rc={r2.returncode} {dt2:.1f} s = {n / dt2 / 1e6:.3f} M pairs/s, same -v lines: {r2.stdout == r.stdout} | {stages}")
+        ok &= r2.returncode == 0 and r2.stdout == r.stdout
     # outputs: ids of every record, in order
     want = np.nonzero(expect)[0]
     for k, o in enumerate(outs):

@@ -426,6 +426,14 @@ void OutputFile::write_borrowed(const char* p, size_t n)
     drain(0);                                                 // nothing refers to the buffer any more
 }
 
+void OutputFile::write_members(const char* p, size_t n)
+{
+    if (!gz_) throw std::logic_error("write_members: not a .gz output");
+    submit_block();
+    drain(0);
+    if (n && std::fwrite(p, 1, n, f_) != n) throw std::runtime_error("write failed: " + name_);
+}
+
 void OutputFile::put_plain(const char* p, size_t n)
 {
     while (n) {

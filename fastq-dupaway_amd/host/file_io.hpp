@@ -73,6 +73,10 @@ public:
     void write(const char* p, size_t n);
     // The same for a large buffer lent until the call returns: .gz members are deflated straight out of it.
     void write_borrowed(const char* p, size_t n);
+    // .gz only: whole gzip members made elsewhere (on the GPU: fqd_bgzf_deflate) go to the file as they are,
+    // after whatever write() still holds.
+    void write_members(const char* p, size_t n);
+    bool is_gz() const { return gz_; }
     // Several pieces in one go: plain files hand them to writev() as they lie (no staging copy).
     struct Piece { const char* p; size_t n; };
     // threads > 1: a large batch into a regular plain file is written by that many threads at once (pwritev).

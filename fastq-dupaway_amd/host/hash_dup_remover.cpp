@@ -925,6 +925,15 @@ void HashDupRemover::run_unordered_in_memory(const std::string* in, const std::s
 }
 
 // One pass, text resident in HBM (see run_unordered).
+// `.gz` outputs of the resident run: deflated on the GPU (fqd_bgzf_deflate; the size of zlib level 1-2 at a
+// small fraction of its time) unless a level was asked for — FQD_GZ_LEVEL=N means the host codec at level N —
+// or FQD_GZ_DEVICE=0/1 says otherwise.
+static bool deflate_on_device()
+{
+    if (const char* v = std::getenv("FQD_GZ_DEVICE")) return std::atoi(v) != 0;
+    return std::getenv("FQD_GZ_LEVEL") == nullptr;
+}
+
 void HashDupRemover::run_unordered_resident(const std::string* in, const std::string* out)
 {
     HIP_OK(hipSetDevice(tuning_.device));
@@ -1029,10 +1038,12 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
         StageClock::Scope t("unordered/resident: survivors out of HBM");
         uint64_t window = std::max<uint64_t>(4u << 20, static_cast<uint64_t>(memlimit_ > 0 ? memlimit_ : (2ll << 30)) / 16);   // bytes per buffer, two per file
         if (const char* v = std::getenv("FQD_STREAM_WINDOW_KB")) { const long kb = std::atol(v); if (kb > 0) window = static_cast<uint64_t>(kb) << 10; }
+        const uint32_t lines_per_record = format_ == Format::Fastq ? 4u : 2u;
         struct Out {
             Device<uint64_t> src_off, dst_off; Device<uint32_t> len; uint64_t total = 0;
-            Pinned<char> buf[2]; Device<char> d_win;
+            Pinned<char> buf[2]; Device<char> d_win, d_members;
             Channel<int> free_bufs, full_bufs; int slot_id[2] = {0, 1}; size_t bytes[2] = {0, 0};
+            bool on_device = false;                       // .gz: windows leave the device as finished BGZF members
             std::thread writer; std::exception_ptr error;
         } o[2];
         static int kStop = -1;
@@ -1041,11 +1052,17 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
             engine_ok(fqd_output_plan(eng.e, jp.keep.p, jp.pair[s].p, upto, dev[s].start.p, dev[s].size.p,
                                       o[s].src_off.p, o[s].len.p, o[s].dst_off.p, &o[s].total));
             o[s].free_bufs.push(&o[s].slot_id[0]); o[s].free_bufs.push(&o[s].slot_id[1]);
+            o[s].on_device = sinks[s]->is_gz() && deflate_on_device();
             o[s].writer = std::thread([&, s] {
                 for (;;) {
                     int* id = o[s].full_bufs.pop();
                     if (*id < 0) break;
-                    try { if (!o[s].error) sinks[s]->write_borrowed(o[s].buf[*id].p, o[s].bytes[*id]); }
+                    try {
+                        if (!o[s].error) {
+                            if (o[s].on_device) sinks[s]->write_members(o[s].buf[*id].p, o[s].bytes[*id]);
+                            else sinks[s]->write_borrowed(o[s].buf[*id].p, o[s].bytes[*id]);
+                        }
+                    }
                     catch (...) { o[s].error = std::current_exception(); }
                     o[s].free_bufs.push(id);
                 }
@@ -1080,9 +1097,18 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
                         // dst_off is absolute in the output: the window's buffer starts `lo` bytes in
                         engine_ok(fqd_copy_spans(eng.e, reinterpret_cast<const uint8_t*>(dev[s].text.p), o[s].src_off.p + at[s], o[s].len.p + at[s], take,
                                                  reinterpret_cast<uint8_t*>(o[s].d_win.p) - lo, o[s].dst_off.p + at[s]));
-                        HIP_OK(hipMemcpyAsync(o[s].buf[*id].p, o[s].d_win.p, bytes, hipMemcpyDeviceToHost, stream));
+                        uint64_t out_bytes = bytes;
+                        const char* from = o[s].d_win.p;
+                        if (o[s].on_device) {
+                            const uint64_t cap = fqd_bgzf_bound(bytes);
+                            o[s].d_members.reserve(cap);
+                            engine_ok(fqd_bgzf_deflate(eng.e, reinterpret_cast<const uint8_t*>(o[s].d_win.p), bytes, lines_per_record,
+                                                       reinterpret_cast<uint8_t*>(o[s].d_members.p), cap, &out_bytes));
+                            from = o[s].d_members.p;
+                        }
+                        HIP_OK(hipMemcpyAsync(o[s].buf[*id].p, from, out_bytes, hipMemcpyDeviceToHost, stream));
                         HIP_OK(hipStreamSynchronize(stream));
-                        o[s].bytes[*id] = bytes;
+                        o[s].bytes[*id] = out_bytes;
                         o[s].full_bufs.push(id);
                     }
                     at[s] += take;

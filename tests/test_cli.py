@@ -362,12 +362,16 @@ def test_config4_shape_gz_unordered_2m_pairs(exe, oracle, tmp_path):
     # round 1's way (inputs also held in host memory), then under "-m 500" (the inputs inflate to ~1 GB) the
     # default — one pass with the text resident in HBM only — and the two-pass fallback with 125 MB output windows through temporary files in a directory created in the working
     # directory (main.cpp:192) and removed at exit
-    for env, extra in (({"FQD_UNORDERED_MODE": "memory"}, []), ({}, ["-m", "500"]), ({"FQD_UNORDERED_MODE": "twopass"}, ["-m", "500"])):
+    # ... and the default again with the `.gz` members deflated on the GPU (what happens when no level is asked for)
+    for env, extra in (({"FQD_UNORDERED_MODE": "memory"}, []), ({}, ["-m", "500"]), ({"FQD_UNORDERED_MODE": "twopass"}, ["-m", "500"]),
+                       ({"FQD_GZ_DEVICE": "1"}, ["-m", "500"])):
         for g in (g1, g2):
             g.unlink(missing_ok=True)
         r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", *extra, env={"FQD_GZ_LEVEL": "1", "FQD_HOST_TIMING": "1", **env}, cwd=tmp_path)
         assert r.returncode == 0, r.stderr
-        assert ("unordered/resident: survivors out of HBM" in r.stderr) == (not env), r.stderr
+        assert ("unordered/resident: survivors out of HBM" in r.stderr) == ("FQD_UNORDERED_MODE" not in env), r.stderr
+        if "FQD_GZ_DEVICE" in env:
+            assert g1.stat().st_size < 0.45 * e1.stat().st_size and g2.stat().st_size < 0.45 * e2.stat().st_size
         assert ("unordered/stream: pass 2" in r.stderr) == (env.get("FQD_UNORDERED_MODE") == "twopass"), r.stderr
         assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
                             f"{un} Non-matching entries from both files were skipped.\n")
@@ -380,6 +384,48 @@ def test_config4_shape_gz_unordered_2m_pairs(exe, oracle, tmp_path):
                     assert x == y
                     if not x:
                         break
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["fastq", "fasta", "nothing_joins", "windows_of_64k"])
+def test_unordered_gz_outputs_deflated_on_the_device(exe, oracle, tmp_path, case):
+    """The resident --unordered run with `.gz` outputs and no level asked for: the members come off the GPU
+    (fqd_bgzf_deflate) — any gzip reader must inflate them to the oracle's bytes; an output without records
+    is still a valid (empty) gzip file."""
+    rnd = random.Random(77)
+    n = 4000
+    seqs = random_reads(rnd, n, 300, 30, 80)
+    fasta = case == "fasta"
+    sep = b"/" if case == "nothing_joins" else b" "
+    r1 = [(b"M01:7:FC:1:%d:%d%s1:N:0" % (1100 + k % 7, 1000 + k, sep), seqs[k]) for k in range(n)]
+    r2 = [(b"M01:7:FC:1:%d:%d%s2:N:0" % (1100 + k % 7, 1000 + k, sep), seqs[(k * 7) % n]) for k in range(n)]
+    del r1[50:70]
+    rnd.shuffle(r2)
+
+    def text(recs):
+        return b"".join(b">" + i + b"\n" + q + b"\n" for i, q in recs) if fasta else fastq(recs)
+    ext = "fa" if fasta else "fq"
+    f1, f2 = tmp_path / f"r1.{ext}", tmp_path / f"r2.{ext}"
+    f1.write_bytes(text(r1)); f2.write_bytes(text(r2))
+    e1, e2 = tmp_path / f"e1.{ext}", tmp_path / f"e2.{ext}"
+    g1, g2 = tmp_path / f"g1.{ext}.gz", tmp_path / f"g2.{ext}.gz"
+    tot, dup, un = oracle.filter_paired(f1, f2, e1, e2, FASTA if fasta else FASTQ, unordered=True, tail_rule=True)
+    env = {"FQD_HOST_TIMING": "1"}
+    if case == "windows_of_64k":
+        env["FQD_STREAM_WINDOW_KB"] = "64"                  # many windows, each ending in a short member
+    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", *(["--format", "fasta"] if fasta else []), env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert "unordered/resident: survivors out of HBM" in r.stderr
+    assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
+                        f"{un} Non-matching entries from both files were skipped.\n")
+    assert (tot == 0) == (case == "nothing_joins")
+    for got, exp in ((g1, e1), (g2, e2)):
+        assert subprocess.run(["gzip", "-t", str(got)]).returncode == 0
+        assert gzip.open(got, "rb").read() == exp.read_bytes()
+        raw = got.read_bytes()
+        assert raw.endswith(bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0]))
+        if tot:
+            assert len(raw) < 0.6 * exp.stat().st_size
 
 
 # ---------------------------------------------------------------- GPU: several engines in one run (FQD_DEVICES)

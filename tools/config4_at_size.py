@@ -33,7 +33,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=100_000_000)
     ap.add_argument("--dir", default="/dev/shm/fqd_c4")
-    ap.add_argument("--gz-level", default="1", help="deflate level of inputs and outputs (the reference's default is 6)")
+    ap.add_argument("--gz-level", default="device", help="outputs: 'device' (the default run: members deflated on the GPU) or a level 1..9 "
+                                                           "of the host codec (the reference's default is 6); inputs are packed at level 1 either way")
     ap.add_argument("--mem-limit", default="", help="-m value in MB (default: the CLI's 2048)")
     ap.add_argument("--also", default="", help="further timed runs on the same inputs, each under extra environment settings: "
                                                "'FQD_HOST_THREADS=8;FQD_HOST_THREADS=32,FQD_GZ_LEVEL=6' (only their -v lines are checked)")
@@ -83,7 +84,7 @@ def main():
             del seqs
             out = d / f"r{mate + 1}.fq.gz"
             t0 = time.perf_counter()
-            subprocess.run([str(packer), str(plain), str(out)], check=True, env=dict(os.environ, FQD_GZ_LEVEL=a.gz_level))
+            subprocess.run([str(packer), str(plain), str(out)], check=True, env=dict(os.environ, FQD_GZ_LEVEL="1"))
             log(f"file {mate + 1}: {plain.stat().st_size / 1e9:.1f} GB -> {out.stat().st_size / 1e9:.2f} GB BGZF in {time.perf_counter() - t0:.0f} s")
             plain.unlink()
             gz.append(out)
@@ -93,9 +94,14 @@ def main():
     if a.mem_limit:
         cmd += ["-m", a.mem_limit]
     t0 = time.perf_counter()
-    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(d), env=dict(os.environ, FQD_GZ_LEVEL=a.gz_level, FQD_HOST_TIMING="1"))
+    base_env = dict(os.environ, FQD_HOST_TIMING="1")
+    base_env.pop("FQD_GZ_LEVEL", None)
+    if a.gz_level != "device":
+        base_env["FQD_GZ_LEVEL"] = a.gz_level
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(d), env=base_env)
     dt = time.perf_counter() - t0
-    log(f"CLI rc={r.returncode}  {dt:.1f} s  {n / dt / 1e6:.3f} M pairs/s   ({' '.join(cmd[1:])})")
+    log(f"CLI rc={r.returncode}  {dt:.1f} s  {n / dt / 1e6:.3f} M pairs/s   ({' '.join(cmd[1:])}; outputs: {a.gz_level}; "
+        f"{outs[0].stat().st_size / 1e9:.2f} + {outs[1].stat().st_size / 1e9:.2f} GB)")
     print(r.stdout, end="")
     for line in r.stderr.splitlines():
         if "unordered" in line or "error" in line.lower():
@@ -104,7 +110,7 @@ def main():
                                              f"0 Non-matching entries from both files were skipped.\n")
     log("-v lines == closed form:", ok)
     for extra in filter(None, a.also.split(";")):
-        env = dict(os.environ, FQD_GZ_LEVEL=a.gz_level, FQD_HOST_TIMING="1")
+        env = dict(base_env)
         env.update(kv.split("=", 1) for kv in extra.split(","))
         t1 = time.perf_counter()
         r2 = subprocess.run(cmd, capture_output=True, text=True, cwd=str(d), env=env)

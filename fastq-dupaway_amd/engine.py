@@ -246,6 +246,25 @@ class Engine:
         self._check(self._L.fqd_bgzf_deflate(self._h, _addr(src), n, lines_per_record, _addr(dst), dst.numel(), C.byref(total)))
         return int(total.value)
 
+    def bgzf_inflate(self, comp, comp_off, comp_len, out_off, out_len, crc, n_members: int, text) -> int:
+        """Members (device arrays describing them) of the BGZF bytes at comp inflated into text; returns the number
+        of members that failed (damaged stream, wrong size or CRC)."""
+        bad = C.c_uint64(0)
+        self._check(self._L.fqd_bgzf_inflate(self._h, _addr(comp), _addr(comp_off), _addr(comp_len), _addr(out_off), _addr(out_len),
+                                             _addr(crc), n_members, _addr(text), C.byref(bad)))
+        return int(bad.value)
+
+    def count_lines(self, text, n: int) -> int:
+        lines = C.c_uint64(0)
+        self._check(self._L.fqd_count_lines(self._h, _addr(text), n, C.byref(lines)))
+        return int(lines.value)
+
+    def scan_records(self, text, n: int, lines_per_record: int, n_records: int, start, seq_off, id_len, seq_len, size) -> bool:
+        ok = C.c_int(0)
+        self._check(self._L.fqd_scan_records(self._h, _addr(text), n, lines_per_record, n_records, _addr(start), _addr(seq_off),
+                                             _addr(id_len), _addr(seq_len), _addr(size), C.byref(ok)))
+        return bool(ok.value)
+
     def count_tags_le(self, t, other, other_index: int) -> int:
         """Records of t = (bytes, offsets, lengths, n) whose tag is <= the tag of record other_index of `other`."""
         tt, to = self._tags(*t), self._tags(*other)

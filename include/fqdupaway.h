@@ -305,6 +305,27 @@ uint64_t fqd_bgzf_bound(uint64_t n);
 int  fqd_bgzf_deflate(fqd_engine* e, const uint8_t* src, uint64_t n, uint32_t lines_per_record,
                       uint8_t* dst, uint64_t dst_capacity, uint64_t* out_bytes);
 
+/* BGZF input inflated in HBM: member m (m < n_members; all arrays device) is the raw deflate stream of comp_len[m]
+ * bytes at comp + comp_off[m] and inflates to exactly out_len[m] (<= 65536) bytes at text + out_off[m] whose CRC-32
+ * is crc[m] — what the host read off the member's header and trailer.  One GPU thread per member.  *n_bad (host) =
+ * members whose stream is damaged, ends early or late, or whose CRC differs; text is then to be discarded.
+ * Replaces the gzip decompressor the reference pushes onto its input stream (file_utils.hpp:58-69). */
+int  fqd_bgzf_inflate(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* comp_len,
+                      const uint64_t* out_off, const uint32_t* out_len, const uint32_t* crc, uint64_t n_members,
+                      uint8_t* text, uint64_t* n_bad);
+
+/* The n bytes of text (device) cut into records the way the reference's views do it (fastqview.cpp:92-138,
+ * fastaview.cpp:78-100): a record is lines_per_record lines (4: FASTQ, 2: FASTA), starts with '@' / '>', and a FASTQ
+ * record's sequence and quality lines are equally long.  fqd_count_lines gives the number of newlines; the caller
+ * sizes the arrays for n_records = lines / lines_per_record and fqd_scan_records fills, per record, start (offset of
+ * its first byte), seq_off (of its sequence line), id_len (ID line with its newline), seq_len (without), size (whole
+ * record).  *well_formed (host) = 1 iff the text is exactly n_records such records, ending with its last byte;
+ * otherwise the arrays are not to be used and the caller reads the file the host way, which reproduces the
+ * reference's diagnostics for whatever is wrong. */
+int  fqd_count_lines(fqd_engine* e, const uint8_t* text, uint64_t n, uint64_t* n_lines);
+int  fqd_scan_records(fqd_engine* e, const uint8_t* text, uint64_t n, uint32_t lines_per_record, uint64_t n_records,
+                      uint64_t* start, uint64_t* seq_off, uint32_t* id_len, uint32_t* seq_len, uint32_t* size, int* well_formed);
+
 /* keep_out[origin[k]] = flags[k] for k < n: puts the flags that came back from the
  * owners (in partition order) into input order.  All device pointers. */
 int  fqd_scatter_flags(fqd_engine* e, const uint8_t* flags, const uint32_t* origin, uint64_t n, uint8_t* keep_out);

@@ -1,0 +1,47 @@
+"""BGZF files for the tests of the GPU reader: members made by zlib under every strategy and level, so that
+stored, fixed-Huffman and dynamic blocks, several blocks per member and all match shapes occur."""
+import struct
+import zlib
+
+import numpy as np
+
+from bgzf_cases import fasta_text, fastq_text
+
+EOF_MARK = bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+
+
+def member(raw: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem_level=8, flush_every=0) -> bytes:
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, mem_level, strategy)
+    if flush_every:                                         # several blocks per member (empty stored blocks between them)
+        body = b"".join(c.compress(raw[i:i + flush_every]) + c.flush(zlib.Z_FULL_FLUSH) for i in range(0, len(raw), flush_every)) + c.flush()
+    else:
+        body = c.compress(raw) + c.flush()
+    total = 18 + len(body) + 8
+    assert total <= 65536
+    return (bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0]) + struct.pack("<H", total - 1) + body +
+            struct.pack("<II", zlib.crc32(raw), len(raw)))
+
+
+def bgzf(data: bytes, size=65280, **kw) -> bytes:
+    return b"".join(member(data[i:i + size], **kw) for i in range(0, len(data), size)) + EOF_MARK
+
+
+def cases():
+    rng = np.random.default_rng(9)
+    fq = fastq_text(2500, 31)
+    yield "level6", fq, bgzf(fq)
+    yield "level1", fq, bgzf(fq, level=1)
+    yield "level9_small_window_blocks", fq, bgzf(fq, level=9, mem_level=1)           # many blocks per member
+    yield "stored", fq[:200_000], bgzf(fq[:200_000], level=0)
+    yield "fixed_huffman", fq, bgzf(fq, strategy=zlib.Z_FIXED)
+    yield "huffman_only", fq, bgzf(fq, strategy=zlib.Z_HUFFMAN_ONLY)
+    yield "rle", fq, bgzf(fq, strategy=zlib.Z_RLE)
+    yield "flushes_inside_members", fq, bgzf(fq, flush_every=5000)
+    yield "members_of_64k", fq, bgzf(fq, size=65536, level=9)
+    yield "tiny_members", fq[:30_000], bgzf(fq[:30_000], size=97)
+    yield "fasta", (fa := fasta_text(3000, 8)), bgzf(fa)
+    rnd = rng.integers(0, 256, size=150_000, dtype=np.uint8).tobytes()
+    yield "random_bytes", rnd, bgzf(rnd, size=60000)
+    yield "long_runs", b"A" * 100_000 + b"CG" * 50_000, bgzf(b"A" * 100_000 + b"CG" * 50_000)
+    yield "one_byte", b"x", bgzf(b"x")
+    yield "empty_members_between", fq[:70_000], member(fq[:30_000]) + member(b"") + member(fq[30_000:70_000]) + EOF_MARK

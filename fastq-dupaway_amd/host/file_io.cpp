@@ -32,10 +32,7 @@ void throw_cannot_open(const std::string& name)
     throw DiagnosedError("Cannot open file " + name + "\n", "File does not exist or cannot be opened!");
 }
 
-namespace {
-
-// Length of the BGZF member that starts at p (at least 18 bytes readable), or 0 if p does not
-// start one: gzip header with FLG = FEXTRA and a 'B','C' subfield holding (total size - 1).
+// gzip header with FLG = FEXTRA and a 'B','C' subfield holding (total size - 1).
 size_t bgzf_member_size(const unsigned char* p, size_t avail, size_t* data_off)
 {
     if (avail < 18 || p[0] != 31 || p[1] != 139 || p[2] != 8 || p[3] != 4) return 0;
@@ -52,6 +49,8 @@ size_t bgzf_member_size(const unsigned char* p, size_t avail, size_t* data_off)
     }
     return 0;
 }
+
+namespace {
 
 // libdeflate (the whole-buffer DEFLATE library htslib also uses for BGZF) when the system has it: two to
 // three times zlib's speed on 64 KB members, same format.  Looked up at run time by its soname — the image
@@ -94,7 +93,7 @@ struct FastCodec {
 
 const char* gz_codec_name() { return FastCodec::get() ? "libdeflate" : "zlib"; }
 
-InputFile::InputFile(const std::string& name) : gz_(has_gz_extension(name))
+InputFile::InputFile(const std::string& name, bool as_bytes) : gz_(!as_bytes && has_gz_extension(name))
 {
     fd_ = ::open(name.c_str(), O_RDONLY);
     if (fd_ < 0) throw_cannot_open(name);

@@ -29,12 +29,17 @@ struct DiagnosedError : std::runtime_error {
 // (file_utils.hpp:111-121).
 [[noreturn]] void throw_cannot_open(const std::string& name);
 
+// Length of the BGZF member that starts at p (at least 18 bytes readable), or 0 if p does not start one: a gzip
+// header with an extra field holding the 'B','C' subfield = total size - 1.  *data_off = where its deflate data starts.
+size_t bgzf_member_size(const unsigned char* p, size_t avail, size_t* data_off);
+
 // "libdeflate" when the system library was found (and FQD_CODEC != zlib), else "zlib": what BGZF members go through.
 const char* gz_codec_name();
 
 class InputFile {
 public:
-    explicit InputFile(const std::string& name);
+    // as_bytes: the file as it lies on disk, whatever its extension (for callers that inflate it themselves).
+    explicit InputFile(const std::string& name, bool as_bytes = false);
     ~InputFile();
     InputFile(const InputFile&) = delete;
     InputFile& operator=(const InputFile&) = delete;

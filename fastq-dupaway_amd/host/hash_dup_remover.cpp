@@ -94,6 +94,7 @@ struct Device {
         HIP_OK(hipMalloc(&np, std::max<size_t>(n, 1024) * sizeof(T)));
         p = static_cast<T*>(np); cap = std::max<size_t>(n, 1024);
     }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
 // Thread-safe pool / queue of raw pointers.
@@ -925,6 +926,81 @@ void HashDupRemover::run_unordered_in_memory(const std::string* in, const std::s
 }
 
 // One pass, text resident in HBM (see run_unordered).
+// A BGZF input of the resident run goes to HBM as it lies on disk — a fifth of its text — and is inflated and cut
+// into records THERE (fqd_bgzf_inflate, fqd_scan_records): the host only reads the file and walks the member
+// headers.  Whatever is not a regular, well-formed BGZF file holding whole records is read the host way instead
+// (RecordStream), which is also what produces every diagnostic.  FQD_GUNZIP_DEVICE=0 turns it off.
+struct CompressedOnDevice {
+    Device<char> bytes;
+    std::vector<uint64_t> comp_off, out_off;
+    std::vector<uint32_t> comp_len, out_len, crc;
+    uint64_t text_bytes = 0;
+};
+
+static bool inflate_on_device()
+{
+    const char* v = std::getenv("FQD_GUNZIP_DEVICE");
+    return !v || std::atoi(v) != 0;
+}
+
+// false: not such a file (nothing is reported; the caller reads it the host way).
+static bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, CompressedOnDevice& c)
+{
+    uint64_t size = 0;
+    if (!has_gz_extension(name) || !is_regular_file(name, size) || size < 28) return false;
+    InputFile file(name, true);
+    HIP_OK(hipSetDevice(device));
+    hipStream_t up = nullptr;
+    HIP_OK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    struct Guard { hipStream_t s; ~Guard() { (void)hipStreamDestroy(s); } } g{up};
+    Pinned<char> block;
+    block.reserve(block_bytes);
+    c.bytes.reserve(size + 64);
+    std::string tail;                          // bytes already read from `tail_at` on: a member may straddle two blocks
+    uint64_t tail_at = 0, at = 0, member = 0;  // file offsets: of the tail, of the current block, of the member being parsed
+    for (;;) {
+        const size_t got = file.read(block.p, block_bytes, host_threads());
+        if (got == 0) break;
+        if (at + got > size) return false;                             // the file grew under us
+        HIP_OK(hipMemcpyAsync(c.bytes.p + at, block.p, got, hipMemcpyHostToDevice, up));
+        auto fetch = [&](uint64_t from, size_t len, unsigned char* dst) {
+            if (from + len > at + got) return false;
+            for (size_t k = 0; k < len; ++k)
+                dst[k] = static_cast<unsigned char>(from + k >= at ? block.p[from + k - at] : tail[from + k - tail_at]);
+            return true;
+        };
+        bool ok = true;
+        for (;;) {
+            unsigned char head[18], trailer[8];
+            if (!fetch(member, sizeof head, head)) break;
+            size_t data_off = 0;
+            const size_t total = bgzf_member_size(head, sizeof head, &data_off);
+            if (total == 0) { ok = false; break; }                     // not BGZF (or an extra field of another shape)
+            if (!fetch(member + total - 8, sizeof trailer, trailer)) break;
+            const uint32_t crc = trailer[0] | (uint32_t(trailer[1]) << 8) | (uint32_t(trailer[2]) << 16) | (uint32_t(trailer[3]) << 24);
+            const uint32_t isize = trailer[4] | (uint32_t(trailer[5]) << 8) | (uint32_t(trailer[6]) << 16) | (uint32_t(trailer[7]) << 24);
+            if (isize > 65536u) { ok = false; break; }
+            if (isize) {
+                c.comp_off.push_back(member + data_off); c.comp_len.push_back(static_cast<uint32_t>(total - data_off - 8));
+                c.out_off.push_back(c.text_bytes); c.out_len.push_back(isize); c.crc.push_back(crc);
+                c.text_bytes += isize;
+            }
+            member += total;
+        }
+        HIP_OK(hipStreamSynchronize(up));
+        if (!ok) return false;
+        std::string keep;
+        if (member < at + got) {
+            if (member < at) keep.assign(tail, static_cast<size_t>(member - tail_at), std::string::npos);
+            const uint64_t from = std::max(member, at);
+            keep.append(block.p + (from - at), static_cast<size_t>(at + got - from));
+        }
+        tail.swap(keep); tail_at = member;
+        at += got;
+    }
+    return at == size && member == size && c.text_bytes > 0;
+}
+
 // `.gz` outputs of the resident run: deflated on the GPU (fqd_bgzf_deflate; the size of zlib level 1-2 at a
 // small fraction of its time) unless a level was asked for — FQD_GZ_LEVEL=N means the host codec at level N —
 // or FQD_GZ_DEVICE=0/1 says otherwise.
@@ -998,9 +1074,60 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
                 if (side.failed) parse_failure[s] = side.failure;
             } catch (...) { err[s] = std::current_exception(); }
         };
-        std::thread second(load, 1);
-        load(0);
+        CompressedOnDevice packed[2];
+        bool on_device[2] = {false, false};
+        auto fetch_or_load = [&](int s) {
+            if (inflate_on_device()) {
+                try { on_device[s] = fetch_bgzf(in[s], block_bytes, tuning_.device, packed[s]); }
+                catch (const std::exception&) { on_device[s] = false; }               // the host way will say what is wrong
+            }
+            if (!on_device[s]) { packed[s] = CompressedOnDevice(); load(s); }
+        };
+        std::thread second(fetch_or_load, 1);
+        fetch_or_load(0);
         second.join();
+        // the GPU's share of a file that arrived compressed: inflate, count lines, cut into records
+        auto finish_on_device = [&](int s) -> bool {
+            FileOnDevice& f = dev[s];
+            CompressedOnDevice& c = packed[s];
+            const uint64_t members = c.comp_off.size();
+            Device<uint64_t> d_comp_off, d_out_off; Device<uint32_t> d_comp_len, d_out_len, d_crc;
+            d_comp_off.reserve(members); d_out_off.reserve(members); d_comp_len.reserve(members); d_out_len.reserve(members); d_crc.reserve(members);
+            HIP_OK(hipMemcpy(d_comp_off.p, c.comp_off.data(), members * sizeof(uint64_t), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(d_out_off.p, c.out_off.data(), members * sizeof(uint64_t), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(d_comp_len.p, c.comp_len.data(), members * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(d_out_len.p, c.out_len.data(), members * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(d_crc.p, c.crc.data(), members * sizeof(uint32_t), hipMemcpyHostToDevice));
+            f.text.room_for(c.text_bytes + 64, stream);
+            uint64_t bad = 0;
+            engine_ok(fqd_bgzf_inflate(eng.e, reinterpret_cast<const uint8_t*>(c.bytes.p), d_comp_off.p, d_comp_len.p, d_out_off.p, d_out_len.p,
+                                       d_crc.p, members, reinterpret_cast<uint8_t*>(f.text.p), &bad));
+            c.bytes.release();
+            if (bad) return false;
+            const uint32_t lines_per_record = format_ == Format::Fastq ? 4u : 2u;
+            uint64_t lines = 0;
+            engine_ok(fqd_count_lines(eng.e, reinterpret_cast<const uint8_t*>(f.text.p), c.text_bytes, &lines));
+            const uint64_t n = lines / lines_per_record;
+            f.start.room_for(n, stream); f.seq_off.room_for(n, stream); f.id_len.room_for(n, stream); f.seq_len.room_for(n, stream); f.size.room_for(n, stream);
+            int well_formed = 0;
+            engine_ok(fqd_scan_records(eng.e, reinterpret_cast<const uint8_t*>(f.text.p), c.text_bytes, lines_per_record, n,
+                                       f.start.p, f.seq_off.p, f.id_len.p, f.seq_len.p, f.size.p, &well_formed));
+            if (!well_formed || n == 0) return false;
+            f.text.used = c.text_bytes;
+            f.start.used = f.seq_off.used = f.id_len.used = f.seq_len.used = f.size.used = n;
+            f.n = n;
+            return true;
+        };
+        for (int s = 0; s < 2; ++s) {
+            if (!on_device[s]) continue;
+            StageClock::Scope t2("unordered/resident: inflate + record scan on the GPU");
+            if (!finish_on_device(s)) {                                               // read it again the host way: that one reports
+                FileOnDevice& f = dev[s];
+                f.text.used = f.start.used = f.seq_off.used = f.id_len.used = f.seq_len.used = f.size.used = 0; f.n = 0;
+                packed[s] = CompressedOnDevice();
+                load(s);
+            }
+        }
         for (int s = 0; s < 2; ++s) {
             if (err[s]) std::rethrow_exception(err[s]);
             if (parse_failure[s].set) { std::cerr << parse_failure[s].diag; throw std::runtime_error(parse_failure[s].what); }

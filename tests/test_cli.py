@@ -428,6 +428,72 @@ def test_unordered_gz_outputs_deflated_on_the_device(exe, oracle, tmp_path, case
             assert len(raw) < 0.6 * exp.stat().st_size
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["fastq", "fasta", "stored_and_fixed_blocks", "flipped_bit", "bad_record", "no_final_newline",
+                                  "plain_gzip", "truncated"])
+def test_unordered_bgzf_inputs_inflated_on_the_device(exe, oracle, tmp_path, case):
+    """BGZF inputs of the resident --unordered run are inflated and cut into records on the GPU
+    (fqd_bgzf_inflate, fqd_scan_records); anything but a well-formed BGZF file of whole records is read the
+    host way instead.  Either way: the oracle's bytes and lines, and for broken inputs exactly what the run
+    with FQD_GUNZIP_DEVICE=0 says and leaves behind."""
+    import zlib
+    from inflate_cases import bgzf, member, EOF_MARK
+    rnd = random.Random(91)
+    n = 6000
+    seqs = random_reads(rnd, n, 500, 40, 90)
+    fasta = case == "fasta"
+    r1 = [(b"M01:7:FC:1:%d:%d 1:N:0" % (1100 + k % 7, 1000 + k), seqs[k]) for k in range(n)]
+    r2 = [(b"M01:7:FC:1:%d:%d 2:N:0" % (1100 + k % 7, 1000 + k), seqs[(k * 11) % n]) for k in range(n)]
+    del r2[300:340]
+    rnd.shuffle(r2)
+
+    def text(recs):
+        return b"".join(b">" + i + b"\n" + q + b"\n" for i, q in recs) if fasta else fastq(recs)
+    t1, t2 = text(r1), text(r2)
+    if case == "bad_record":
+        cut = t2.index(b"\n@", len(t2) // 2) + 1
+        t2 = t2[:cut] + b"x" + t2[cut + 1:]                          # a record that does not start with '@'
+    if case == "no_final_newline":
+        t2 = t2[:-1]
+    kw = {"stored_and_fixed_blocks": dict(level=0)}.get(case, dict(level=1))
+    z1 = bgzf(t1, **kw)
+    z2 = bgzf(t2, strategy=zlib.Z_FIXED) if case == "stored_and_fixed_blocks" else bgzf(t2, **kw)
+    if case == "flipped_bit":
+        z2 = bytearray(z2); z2[len(z2) // 2] ^= 0x10; z2 = bytes(z2)
+    if case == "truncated":
+        z2 = z2[: len(z2) * 2 // 3]
+    if case == "plain_gzip":
+        z2 = gzip.compress(t2, 1)
+    ext = "fa" if fasta else "fq"
+    f1, f2 = tmp_path / f"r1.{ext}.gz", tmp_path / f"r2.{ext}.gz"
+    f1.write_bytes(z1); f2.write_bytes(z2)
+    fmt = ["--format", "fasta"] if fasta else []
+    runs = {}
+    for gunzip in ("1", "0"):
+        g1, g2 = tmp_path / f"g1_{gunzip}.{ext}", tmp_path / f"g2_{gunzip}.{ext}"
+        r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", *fmt,
+                env={"FQD_HOST_TIMING": "1", "FQD_GUNZIP_DEVICE": gunzip}, cwd=tmp_path)
+        said = "\n".join(l for l in r.stderr.splitlines() if "[host timing]" not in l)
+        runs[gunzip] = (r.returncode, r.stdout, said, g1.read_bytes() if g1.exists() else None, g2.read_bytes() if g2.exists() else None)
+        if r.returncode == 0:                               # (the stage clocks are printed by runs that finish)
+            assert ("inflate + record scan on the GPU" in r.stderr) == (gunzip == "1"), r.stderr    # file 1 is always good BGZF
+    assert runs["1"] == runs["0"]
+    rc, out, said, b1, b2 = runs["1"]
+    if case in ("fastq", "fasta", "stored_and_fixed_blocks", "plain_gzip"):
+        p1, p2 = tmp_path / f"p1.{ext}", tmp_path / f"p2.{ext}"
+        p1.write_bytes(t1); p2.write_bytes(t2)
+        e1, e2 = tmp_path / f"e1.{ext}", tmp_path / f"e2.{ext}"
+        tot, dup, un = oracle.filter_paired(p1, p2, e1, e2, FASTA if fasta else FASTQ, unordered=True, tail_rule=True)
+        assert rc == 0 and tot > 5000
+        assert out == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
+                       f"{un} Non-matching entries from both files were skipped.\n")
+        assert b1 == e1.read_bytes() and b2 == e2.read_bytes()
+    elif case in ("flipped_bit", "truncated"):
+        assert rc != 0 and "corrupt or truncated" in said
+    elif case == "bad_record":
+        assert rc != 0 and "Invalid record start character: x" in said
+
+
 # ---------------------------------------------------------------- GPU: several engines in one run (FQD_DEVICES)
 
 def uniform_fastq(rnd, n, L, pool, ident):

@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t block_scan(uint32_t v, uint32_t* wave_sums /
 }
 
 struct MemberLds {
-    alignas(16) uint8_t data[kMember + 16];
+    alignas(16) uint8_t data[kSkewedBytes + 16];   // skewed: see fqd_bgzf_core.hpp
     uint16_t ls[kMaxLines + 2];
     uint32_t line_at[kThreads];                         // newlines before the thread's chunk
     uint32_t wave_sums[16];
@@ -67,11 +67,14 @@ __device__ __forceinline__ uint32_t load_member(const uint8_t* __restrict__ src,
     const uint8_t* __restrict__ p = src + from;
     if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
         const uint32_t whole = L / 16u;
-        for (uint32_t i = threadIdx.x; i < whole; i += kThreads)
-            reinterpret_cast<uint4*>(data)[i] = reinterpret_cast<const uint4*>(p)[i];
-        for (uint32_t i = whole * 16u + threadIdx.x; i < L; i += kThreads) data[i] = p[i];
+        for (uint32_t i = threadIdx.x; i < whole; i += kThreads) {
+            const uint4 v = reinterpret_cast<const uint4*>(p)[i];
+            uint32_t* d = reinterpret_cast<uint32_t*>(data + Skewed::at(16u * i));      // 16 bytes never straddle a chunk
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        for (uint32_t i = whole * 16u + threadIdx.x; i < L; i += kThreads) data[Skewed::at(i)] = p[i];
     } else {
-        for (uint32_t i = threadIdx.x; i < L; i += kThreads) data[i] = p[i];
+        for (uint32_t i = threadIdx.x; i < L; i += kThreads) data[Skewed::at(i)] = p[i];
     }
     return L;
 }
@@ -80,8 +83,9 @@ __device__ __forceinline__ uint32_t load_member(const uint8_t* __restrict__ src,
 // line its chunk starts in.  Returns whether the index is usable (not more lines than it holds).
 __device__ __forceinline__ bool index_lines(MemberLds& s, uint32_t lo, uint32_t hi)
 {
+    const Skewed data{s.data};
     uint32_t mine = 0;
-    for (uint32_t p = lo; p < hi; ++p) mine += s.data[p] == uint8_t('\n') ? 1u : 0u;
+    for (uint32_t p = lo; p < hi; ++p) mine += data[p] == uint8_t('\n') ? 1u : 0u;
     uint32_t total;
     const uint32_t before = block_scan(mine, s.wave_sums, total);
     s.line_at[threadIdx.x] = before;
@@ -89,7 +93,7 @@ __device__ __forceinline__ bool index_lines(MemberLds& s, uint32_t lo, uint32_t 
     if (threadIdx.x == 0) s.ls[0] = 0;
     if (on) {
         uint32_t k = before + 1u;
-        for (uint32_t p = lo; p < hi; ++p) if (s.data[p] == uint8_t('\n')) s.ls[k++] = uint16_t(p + 1u);
+        for (uint32_t p = lo; p < hi; ++p) if (data[p] == uint8_t('\n')) s.ls[k++] = uint16_t(p + 1u);
     }
     __syncthreads();
     return on;
@@ -114,14 +118,15 @@ void bgzf_count_kernel(const uint8_t* __restrict__ src, uint64_t n, uint64_t mem
     __shared__ uint32_t hist[kLitLen + kDist];
     for (uint32_t i = threadIdx.x; i < kLitLen + kDist; i += kThreads) hist[i] = 0;
     __syncthreads();
-    for (uint64_t m = blockIdx.x; m < members; m += gridDim.x) {
+    const uint64_t every = sample_every(members);
+    for (uint64_t m = blockIdx.x * every; m < members; m += gridDim.x * every) {
         const uint32_t L = load_member(src, n, m, s.data);
         __syncthreads();
         uint32_t lo, hi;
         chunk_of(threadIdx.x, L, lo, hi);
         const bool lines_on = index_lines(s, lo, hi);
         TokenCounter sink{hist};
-        parse_chunk(s.data, lo, hi, s.ls, s.line_at[threadIdx.x], lines_on, lines_per_record, sink);
+        parse_chunk(Skewed{s.data}, lo, hi, s.ls, s.line_at[threadIdx.x], lines_on, lines_per_record, sink);
         __syncthreads();                                // before the next member overwrites data
     }
     for (uint32_t i = threadIdx.x; i < kLitLen + kDist; i += kThreads)
@@ -153,7 +158,8 @@ void bgzf_emit_kernel(const uint8_t* __restrict__ src, uint64_t n, uint64_t memb
         const uint32_t line = s.line_at[t];
 
         BitCounter price{lit_len, dist_len};
-        parse_chunk(s.data, lo, hi, s.ls, line, lines_on, lines_per_record, price);
+        const Skewed data{s.data};
+        parse_chunk(data, lo, hi, s.ls, line, lines_on, lines_per_record, price);
         uint32_t body_bits;
         const uint32_t before = block_scan(price.bits, s.wave_sums, body_bits);
         const uint32_t total_bits = header_bits + body_bits + lit_len[256];
@@ -170,7 +176,7 @@ void bgzf_emit_kernel(const uint8_t* __restrict__ src, uint64_t n, uint64_t memb
                     w.put(header_bits - at >= 32u ? codes->header[at >> 5] : codes->header[at >> 5] & ((1u << (header_bits - at)) - 1u),
                           header_bits - at >= 32u ? 32u : header_bits - at);
             Emitter<DeviceOr> emit{lit_code, lit_len, dist_code, dist_len, w};
-            parse_chunk(s.data, lo, hi, s.ls, line, lines_on, lines_per_record, emit);
+            parse_chunk(data, lo, hi, s.ls, line, lines_on, lines_per_record, emit);
             if (t == kThreads - 1u) w.put(lit_code[256], lit_len[256]);      // end of block
             w.finish();
         } else {
@@ -181,11 +187,11 @@ void bgzf_emit_kernel(const uint8_t* __restrict__ src, uint64_t n, uint64_t memb
                 w.finish();
             }
             BitWriter<DeviceOr> w(out, (kHeadBytes + 5u + lo) * 8u, orw);
-            for (uint32_t p = lo; p < hi; ++p) w.put(s.data[p], 8);
+            for (uint32_t p = lo; p < hi; ++p) w.put(data[p], 8);
             w.finish();
         }
 
-        crc[t] = crc_chunk(crc_table, s.data, lo, hi);
+        crc[t] = crc_chunk(crc_table, data, lo, hi);
         __syncthreads();
         for (uint32_t k = 0; k < kLevels; ++k) {
             if ((t & ((2u << k) - 1u)) == 0u) crc[t] = crc_advance(codes->crc_shift[k], crc[t]) ^ crc[t + (1u << k)];

@@ -41,7 +41,7 @@ constexpr uint32_t kMember = 65280;                    // input bytes per member
 constexpr uint32_t kSlot = 65536;                      // bytes reserved per member before compaction
 constexpr uint32_t kThreads = 512;
 constexpr uint32_t kChunk = 128;                       // kThreads * kChunk >= kMember
-constexpr uint32_t kMaxLines = 4096;                   // line starts kept per member; beyond: no column matches
+constexpr uint32_t kMaxLines = 4000;                   // line starts kept per member; beyond: no column matches
 constexpr uint32_t kMinMatch = 4;
 constexpr uint32_t kMaxMatch = 258;
 constexpr uint32_t kLitLen = 286, kDist = 30;
@@ -94,10 +94,28 @@ FQD_HD void chunk_of(uint32_t t, uint32_t L, uint32_t& lo, uint32_t& hi)
     lo = hi > kChunk ? hi - kChunk : 0u;
 }
 
+// The member's bytes as the parser sees them.  In LDS every 128-byte chunk is followed by 4 bytes of
+// padding: the 64 lanes of a wave work 128 bytes apart, which unpadded is the same bank for all of them.
+constexpr uint32_t kSkewedBytes = kThreads * (kChunk + 4u);
+struct Skewed {
+    const uint8_t* base;
+    FQD_HD static uint32_t at(uint32_t p) { return p + ((p >> 7) << 2); }
+    FQD_HD uint8_t operator[](uint32_t p) const { return base[at(p)]; }
+};
+struct Linear {
+    const uint8_t* base;
+    FQD_HD uint8_t operator[](uint32_t p) const { return base[p]; }
+};
+
+// Every `sample_every`-th member is parsed for the token histogram once there are enough of them (the codes
+// of a call describe FASTQ statistics, which do not change along a file); every symbol then gets a count of
+// at least one, so that whatever the other members hold can be written.
+FQD_HD uint32_t sample_every(uint64_t members) { return members >= 64u ? 8u : 1u; }
+
 // Greedy parse of [lo, hi): `line` = number of newlines before lo, ls[j] = start of line j
 // (ls[0] = 0), valid when lines_on.  The sink sees every token in order.
-template <class Sink>
-FQD_HD void parse_chunk(const uint8_t* data, uint32_t lo, uint32_t hi, const uint16_t* ls, uint32_t line,
+template <class Data, class Sink>
+FQD_HD void parse_chunk(const Data& data, uint32_t lo, uint32_t hi, const uint16_t* ls, uint32_t line,
                         bool lines_on, uint32_t lines_per_record, Sink& sink)
 {
     uint32_t p = lo, j = line;
@@ -179,7 +197,8 @@ struct Emitter {
 
 // -------------------------------------------------------------------------------------------
 // CRC-32 (the gzip one: reflected 0xEDB88320).
-FQD_HD uint32_t crc_chunk(const uint32_t* table, const uint8_t* data, uint32_t lo, uint32_t hi)
+template <class Data>
+FQD_HD uint32_t crc_chunk(const uint32_t* table, const Data& data, uint32_t lo, uint32_t hi)
 {
     uint32_t reg = (lo == 0u && hi > 0u) ? 0xFFFFFFFFu : 0u;       // the chunk holding byte 0 carries the preset
     for (uint32_t p = lo; p < hi; ++p) reg = table[(reg ^ data[p]) & 0xFFu] ^ (reg >> 8);
@@ -261,8 +280,9 @@ inline void assign_codes(const uint8_t* len, uint32_t n, uint16_t* code)
 inline void build_codes(const uint64_t* hist, uint64_t members, Codes& c)
 {
     uint64_t lit[kLitLen], dst[kDist];
-    for (uint32_t s = 0; s < kLitLen; ++s) lit[s] = hist[s];
-    for (uint32_t s = 0; s < kDist; ++s) dst[s] = hist[kLitLen + s];
+    const uint64_t floor = sample_every(members) > 1u ? 1u : 0u;      // a sampled histogram must not leave a symbol without a code
+    for (uint32_t s = 0; s < kLitLen; ++s) lit[s] = hist[s] + floor;
+    for (uint32_t s = 0; s < kDist; ++s) dst[s] = hist[kLitLen + s] + floor;
     lit[256] = members ? members : 1;
     bool any = false;
     for (uint32_t s = 0; s < 256; ++s) any |= lit[s] != 0;

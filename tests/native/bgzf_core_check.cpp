@@ -55,14 +55,14 @@ int main(int argc, char** argv)
     in.resize(n + 64);
     std::vector<uint64_t> hist(kLitLen + kDist, 0);
     Lines x;
-    for (uint64_t m = 0; m < members; ++m) {
+    for (uint64_t m = 0; m < members; m += sample_every(members)) {
         const uint8_t* data = in.data() + m * kMember;
         const uint32_t L = uint32_t(std::min<uint64_t>(kMember, n - m * kMember));
         index_lines(data, L, x);
         for (uint32_t t = 0; t < kThreads; ++t) {
             uint32_t lo, hi; chunk_of(t, L, lo, hi);
             Counter c{hist.data()};
-            parse_chunk(data, lo, hi, x.ls.data(), x.line_at[t], x.on, K, c);
+            parse_chunk(Linear{data}, lo, hi, x.ls.data(), x.line_at[t], x.on, K, c);
         }
     }
     static Codes codes;
@@ -79,7 +79,7 @@ int main(int argc, char** argv)
         for (uint32_t t = 0; t < kThreads; ++t) {
             uint32_t lo, hi; chunk_of(t, L, lo, hi);
             BitCounter price{codes.lit_len, codes.dist_len};
-            parse_chunk(data, lo, hi, x.ls.data(), x.line_at[t], x.on, K, price);
+            parse_chunk(Linear{data}, lo, hi, x.ls.data(), x.line_at[t], x.on, K, price);
             bits[t] = price.bits; before[t] = body; body += bits[t];
         }
         const uint32_t total_bits = codes.header_bits + body + codes.lit_len[256];
@@ -97,7 +97,7 @@ int main(int argc, char** argv)
                         w.put(codes.header_bits - at >= 32 ? codes.header[at >> 5] : codes.header[at >> 5] & ((1u << (codes.header_bits - at)) - 1u),
                               codes.header_bits - at >= 32 ? 32 : codes.header_bits - at);
                 Emitter<HostOr> emit{codes.lit_code, codes.lit_len, codes.dist_code, codes.dist_len, w};
-                parse_chunk(data, lo, hi, x.ls.data(), x.line_at[t], x.on, K, emit);
+                parse_chunk(Linear{data}, lo, hi, x.ls.data(), x.line_at[t], x.on, K, emit);
                 if (t == kThreads - 1) w.put(codes.lit_code[256], codes.lit_len[256]);
                 w.finish();
             } else {
@@ -106,7 +106,7 @@ int main(int argc, char** argv)
                 for (uint32_t p = lo; p < hi; ++p) w.put(data[p], 8);
                 w.finish();
             }
-            crc[t] = crc_chunk(codes.crc_table, data, lo, hi);
+            crc[t] = crc_chunk(codes.crc_table, Linear{data}, lo, hi);
         }
         for (uint32_t k = 0; k < kLevels; ++k)
             for (uint32_t t = 0; t < kThreads; t += 2u << k) crc[t] = crc_advance(codes.crc_shift[k], crc[t]) ^ crc[t + (1u << k)];

@@ -65,4 +65,4 @@ def test_ratio_on_fastq_is_gzip_1_class(tmp_path):
     raw = harness_bgzf(data, 4, tmp_path)
     assert gzip.decompress(raw) == data
     z1 = len(zlib.compress(data, 1))
-    assert len(raw) < 1.08 * z1, (len(raw), z1, len(data))
+    assert len(raw) < 1.10 * z1, (len(raw), z1, len(data))

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--gz-level", default="device", help="outputs: 'device' (the default run: members deflated on the GPU) or a level 1..9 "
                                                            "of the host codec (the reference's default is 6); inputs are packed at level 1 either way")
     ap.add_argument("--mem-limit", default="", help="-m value in MB (default: the CLI's 2048)")
+    ap.add_argument("--keep-inputs", action="store_true", help="leave r1.fq.gz / r2.fq.gz in --dir (for a profiler run of the CLI on them)")
+    ap.add_argument("--no-check", action="store_true", help="skip reading the outputs back")
     ap.add_argument("--also", default="", help="further timed runs on the same inputs, each under extra environment settings: "
                                                "'FQD_HOST_THREADS=8;FQD_HOST_THREADS=32,FQD_GZ_LEVEL=6' (only their -v lines are checked)")
     a = ap.parse_args()
@@ -120,7 +122,7 @@ def main():
         ok &= r2.returncode == 0 and r2.stdout == r.stdout
     # outputs: ids of every record, in order
     want = np.nonzero(expect)[0]
-    for k, o in enumerate(outs):
+    for k, o in enumerate([] if a.no_check else outs):
         t0 = time.perf_counter()
         p = subprocess.Popen(["gzip", "-dc", str(o)], stdout=subprocess.PIPE, bufsize=1 << 24)
         got = np.empty(len(want) + 8, dtype=np.int64); m = 0; good = True
@@ -145,7 +147,7 @@ def main():
         ok &= same and p.returncode == 0
         log(f"output {k + 1}: {m} records (expected {len(want)}), survivors' IDs in tag order == closed form: {same}  ({time.perf_counter() - t0:.0f} s)")
     log("RESULT:", "ok" if ok else "MISMATCH", f"| {n} pairs, {dups} duplicate pairs removed, {dt:.1f} s end to end, {n / dt / 1e6:.3f} M pairs/s")
-    for f in gz + outs:
+    for f in ([] if a.keep_inputs else gz) + outs:
         f.unlink(missing_ok=True)
     sys.exit(0 if ok else 1)
 

@@ -139,12 +139,11 @@ void bgzf_emit_kernel(const uint8_t* __restrict__ src, uint64_t n, uint64_t memb
                       const Codes* __restrict__ codes, uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes)
 {
     __shared__ MemberLds s;
-    __shared__ uint16_t lit_code[kLitLen], dist_code[kDist];
-    __shared__ uint8_t  lit_len[kLitLen], dist_len[kDist];
+    __shared__ uint32_t lit[kLitLen], dst[kDist];
     __shared__ uint32_t crc_table[256];
     __shared__ uint32_t crc[kThreads];
-    for (uint32_t i = threadIdx.x; i < kLitLen; i += kThreads) { lit_code[i] = codes->lit_code[i]; lit_len[i] = codes->lit_len[i]; }
-    for (uint32_t i = threadIdx.x; i < kDist; i += kThreads) { dist_code[i] = codes->dist_code[i]; dist_len[i] = codes->dist_len[i]; }
+    for (uint32_t i = threadIdx.x; i < kLitLen; i += kThreads) lit[i] = codes->lit[i];
+    for (uint32_t i = threadIdx.x; i < kDist; i += kThreads) dst[i] = codes->dist[i];
     for (uint32_t i = threadIdx.x; i < 256u; i += kThreads) crc_table[i] = codes->crc_table[i];
     const uint32_t header_bits = codes->header_bits;
     __syncthreads();
@@ -157,12 +156,12 @@ void bgzf_emit_kernel(const uint8_t* __restrict__ src, uint64_t n, uint64_t memb
         const bool lines_on = index_lines(s, lo, hi);
         const uint32_t line = s.line_at[t];
 
-        BitCounter price{lit_len, dist_len};
+        BitCounter price{lit, dst};
         const Skewed data{s.data};
         parse_chunk(data, lo, hi, s.ls, line, lines_on, lines_per_record, price);
         uint32_t body_bits;
         const uint32_t before = block_scan(price.bits, s.wave_sums, body_bits);
-        const uint32_t total_bits = header_bits + body_bits + lit_len[256];
+        const uint32_t total_bits = header_bits + body_bits + (lit[256] >> 16);
         uint32_t clen = (total_bits + 7u) / 8u;
         const bool stored = clen >= L + 5u;
         if (stored) clen = L + 5u;
@@ -175,9 +174,9 @@ void bgzf_emit_kernel(const uint8_t* __restrict__ src, uint64_t n, uint64_t memb
                 for (uint32_t at = 0; at < header_bits; at += 32u)
                     w.put(header_bits - at >= 32u ? codes->header[at >> 5] : codes->header[at >> 5] & ((1u << (header_bits - at)) - 1u),
                           header_bits - at >= 32u ? 32u : header_bits - at);
-            Emitter<DeviceOr> emit{lit_code, lit_len, dist_code, dist_len, w};
+            Emitter<DeviceOr> emit{lit, dst, w};
             parse_chunk(data, lo, hi, s.ls, line, lines_on, lines_per_record, emit);
-            if (t == kThreads - 1u) w.put(lit_code[256], lit_len[256]);      // end of block
+            if (t == kThreads - 1u) w.put(lit[256] & 0xFFFFu, lit[256] >> 16);      // end of block
             w.finish();
         } else {
             // BFINAL = 1, BTYPE = 00, pad to the byte, LEN, NLEN, the bytes themselves (RFC 1951 §3.2.4)

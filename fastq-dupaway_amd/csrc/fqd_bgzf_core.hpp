@@ -41,7 +41,7 @@ constexpr uint32_t kMember = 65280;                    // input bytes per member
 constexpr uint32_t kSlot = 65536;                      // bytes reserved per member before compaction
 constexpr uint32_t kThreads = 512;
 constexpr uint32_t kChunk = 128;                       // kThreads * kChunk >= kMember
-constexpr uint32_t kMaxLines = 4000;                   // line starts kept per member; beyond: no column matches
+constexpr uint32_t kMaxLines = 3800;                   // line starts kept per member; beyond: no column matches
 constexpr uint32_t kMinMatch = 4;
 constexpr uint32_t kMaxMatch = 258;
 constexpr uint32_t kLitLen = 286, kDist = 30;
@@ -54,10 +54,8 @@ static_assert(kThreads * kChunk >= kMember, "chunks must cover a member");
 // scalar cache).  Codes are stored bit-reversed: deflate packs Huffman codes starting from their
 // most significant bit into a stream that is otherwise filled from bit 0 upwards.
 struct Codes {
-    uint16_t lit_code[kLitLen];
-    uint16_t dist_code[kDist];
-    uint8_t  lit_len[kLitLen];
-    uint8_t  dist_len[kDist];
+    uint32_t lit[kLitLen];                             // reversed code | length << 16
+    uint32_t dist[kDist];
     uint32_t header_bits;                              // BFINAL, BTYPE = 10, HLIT, HDIST, HCLEN, the three tables
     uint32_t header[48];                               // ... as a bit string, bit 0 of word 0 first
     uint32_t crc_table[256];
@@ -113,52 +111,71 @@ struct Linear {
 FQD_HD uint32_t sample_every(uint64_t members) { return members >= 64u ? 8u : 1u; }
 
 // Greedy parse of [lo, hi): `line` = number of newlines before lo, ls[j] = start of line j
-// (ls[0] = 0), valid when lines_on.  The sink sees every token in order.
+// (ls[0] = 0), valid when lines_on.  The sink sees every token in order.  Per input byte: one read of
+// the byte, one of its code — the previous byte rides in a register, and the column candidate is looked
+// at only inside ID lines (lines that begin with '@' or '>'), its distance fixed when the line is entered.
 template <class Data, class Sink>
 FQD_HD void parse_chunk(const Data& data, uint32_t lo, uint32_t hi, const uint16_t* ls, uint32_t line,
                         bool lines_on, uint32_t lines_per_record, Sink& sink)
 {
     uint32_t p = lo, j = line;
+    uint32_t prev = p > 0 ? uint32_t(data[p - 1]) : 0x100u;
+    uint32_t delta = 0;                                              // distance of the column candidate; 0: none in this line
+    auto enter_line = [&]() {
+        delta = 0;
+        if (lines_on && j >= lines_per_record) {
+            const uint32_t s = ls[j];
+            if (s < hi) {
+                const uint32_t first = data[s], d = s - uint32_t(ls[j - lines_per_record]);
+                if ((first == uint32_t('@') || first == uint32_t('>')) && d <= 32768u) delta = d;
+            }
+        }
+    };
+    enter_line();
     while (p < hi) {
         const uint32_t b = data[p];
         const uint32_t room = hi - p < kMaxMatch ? hi - p : kMaxMatch;
-        uint32_t best = 0, dist = 0;
+        uint32_t best = 0, dist = 0, newlines = 0, last = b;
         if (room >= kMinMatch) {
-            if (p > 0 && data[p - 1] == b) {                         // the run goes on: distance 1
+            if (b == prev) {                                         // the run goes on: distance 1
                 uint32_t r = 1;
                 while (r < room && data[p + r] == b) ++r;
-                if (r >= kMinMatch) { best = r; dist = 1; }
+                if (r >= kMinMatch) { best = r; dist = 1; newlines = b == uint32_t('\n') ? r : 0u; }
             }
-            if (lines_on && j >= lines_per_record && best < room) {  // same column, one record up
-                const uint32_t q = uint32_t(ls[j - lines_per_record]) + (p - uint32_t(ls[j]));
-                if (p - q <= 32768u && data[q] == b) {
-                    uint32_t r = 1;
-                    while (r < room && data[q + r] == data[p + r]) ++r;
-                    if (r >= kMinMatch && r > best) { best = r; dist = p - q; }
+            if (delta && best < room) {                              // same column, one record up
+                const uint32_t q = p - delta;
+                if (data[q] == b) {
+                    uint32_t r = 1, n2 = b == uint32_t('\n') ? 1u : 0u, c = b;
+                    while (r < room) {
+                        const uint32_t x = data[p + r];
+                        if (uint32_t(data[q + r]) != x) break;
+                        c = x; n2 += x == uint32_t('\n') ? 1u : 0u; ++r;
+                    }
+                    if (r >= kMinMatch && r > best) { best = r; dist = delta; newlines = n2; last = c; }
                 }
             }
         }
         if (best) {
             sink.match(best, dist);
-            for (uint32_t i = 0; i < best; ++i) j += data[p + i] == uint8_t('\n') ? 1u : 0u;
-            p += best;
+            p += best; prev = last;
+            if (newlines) { j += newlines; enter_line(); }
         } else {
             sink.literal(b);
-            j += b == uint32_t('\n') ? 1u : 0u;
-            ++p;
+            prev = b; ++p;
+            if (b == uint32_t('\n')) { ++j; enter_line(); }
         }
     }
 }
 
-// Sink 1: the size of the chunk under a pair of codes.
+// Sink 1: the size of the chunk under a pair of codes (entries: reversed code | length << 16).
 struct BitCounter {
-    const uint8_t* lit_len; const uint8_t* dist_len;
+    const uint32_t* lit; const uint32_t* dst;
     uint32_t bits = 0;
-    FQD_HD void literal(uint32_t b) { bits += lit_len[b]; }
+    FQD_HD void literal(uint32_t b) { bits += lit[b] >> 16; }
     FQD_HD void match(uint32_t len, uint32_t dist)
     {
         const Sym l = length_symbol(len), d = dist_symbol(dist);
-        bits += uint32_t(lit_len[l.sym]) + l.ebits + uint32_t(dist_len[d.sym]) + d.ebits;
+        bits += (lit[l.sym] >> 16) + l.ebits + (dst[d.sym] >> 16) + d.ebits;
     }
 };
 
@@ -184,14 +201,15 @@ struct BitWriter {
 // Sink 2: the tokens as bits.
 template <class Or>
 struct Emitter {
-    const uint16_t* lit_code; const uint8_t* lit_len; const uint16_t* dist_code; const uint8_t* dist_len;
+    const uint32_t* lit; const uint32_t* dst;
     BitWriter<Or>& out;
-    FQD_HD void literal(uint32_t b) { out.put(lit_code[b], lit_len[b]); }
+    FQD_HD void literal(uint32_t b) { const uint32_t e = lit[b]; out.put(e & 0xFFFFu, e >> 16); }
     FQD_HD void match(uint32_t len, uint32_t dist)
     {
         const Sym l = length_symbol(len), d = dist_symbol(dist);
-        out.put(uint32_t(lit_code[l.sym]) | (l.eval << lit_len[l.sym]), uint32_t(lit_len[l.sym]) + l.ebits);     // <= 15 + 5
-        out.put(uint32_t(dist_code[d.sym]) | (d.eval << dist_len[d.sym]), uint32_t(dist_len[d.sym]) + d.ebits);  // <= 15 + 13
+        const uint32_t el = lit[l.sym], ed = dst[d.sym];
+        out.put((el & 0xFFFFu) | (l.eval << (el >> 16)), (el >> 16) + l.ebits);     // <= 15 + 5
+        out.put((ed & 0xFFFFu) | (d.eval << (ed >> 16)), (ed >> 16) + d.ebits);     // <= 15 + 13
     }
 };
 
@@ -288,17 +306,21 @@ inline void build_codes(const uint64_t* hist, uint64_t members, Codes& c)
     for (uint32_t s = 0; s < 256; ++s) any |= lit[s] != 0;
     for (uint32_t s = 257; s < kLitLen; ++s) any |= lit[s] != 0;
     if (!any) lit[0] = 1;                                            // a complete code needs two symbols
-    build_lengths(lit, kLitLen, 15, c.lit_len);
-    build_lengths(dst, kDist, 15, c.dist_len);
+    uint8_t lit_len[kLitLen], dist_len[kDist];
+    uint16_t lit_code[kLitLen], dist_code[kDist];
+    build_lengths(lit, kLitLen, 15, lit_len);
+    build_lengths(dst, kDist, 15, dist_len);
     bool any_dist = false;
-    for (uint32_t s = 0; s < kDist; ++s) any_dist |= c.dist_len[s] != 0;
-    if (!any_dist) c.dist_len[0] = 1;                                // one unused 1-bit code: §3.2.7 allows it, every inflater takes it
-    assign_codes(c.lit_len, kLitLen, c.lit_code);
-    assign_codes(c.dist_len, kDist, c.dist_code);
+    for (uint32_t s = 0; s < kDist; ++s) any_dist |= dist_len[s] != 0;
+    if (!any_dist) dist_len[0] = 1;                                  // one unused 1-bit code: §3.2.7 allows it, every inflater takes it
+    assign_codes(lit_len, kLitLen, lit_code);
+    assign_codes(dist_len, kDist, dist_code);
+    for (uint32_t s = 0; s < kLitLen; ++s) c.lit[s] = uint32_t(lit_code[s]) | (uint32_t(lit_len[s]) << 16);
+    for (uint32_t s = 0; s < kDist; ++s) c.dist[s] = uint32_t(dist_code[s]) | (uint32_t(dist_len[s]) << 16);
 
     uint32_t nlit = kLitLen, ndist = kDist;
-    while (nlit > 257 && c.lit_len[nlit - 1] == 0) --nlit;
-    while (ndist > 1 && c.dist_len[ndist - 1] == 0) --ndist;
+    while (nlit > 257 && lit_len[nlit - 1] == 0) --nlit;
+    while (ndist > 1 && dist_len[ndist - 1] == 0) --ndist;
     for (uint32_t& w : c.header) w = 0;
     uint32_t at = 0;
     auto put = [&](uint32_t value, uint32_t nbits) {
@@ -310,8 +332,8 @@ inline void build_codes(const uint64_t* hist, uint64_t members, Codes& c)
     static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     for (uint32_t k = 0; k < 19; ++k) put(order[k] < 16 ? 4u : 0u, 3);
     auto put_len = [&](uint32_t l) { uint32_t r = 0; for (uint32_t b = 0; b < 4; ++b) r |= ((l >> b) & 1u) << (3u - b); put(r, 4); };
-    for (uint32_t s = 0; s < nlit; ++s) put_len(c.lit_len[s]);
-    for (uint32_t s = 0; s < ndist; ++s) put_len(c.dist_len[s]);
+    for (uint32_t s = 0; s < nlit; ++s) put_len(lit_len[s]);
+    for (uint32_t s = 0; s < ndist; ++s) put_len(dist_len[s]);
     c.header_bits = at;
 
     for (uint32_t i = 0; i < 256; ++i) {

@@ -78,11 +78,11 @@ int main(int argc, char** argv)
         uint32_t bits[kThreads], before[kThreads], body = 0;
         for (uint32_t t = 0; t < kThreads; ++t) {
             uint32_t lo, hi; chunk_of(t, L, lo, hi);
-            BitCounter price{codes.lit_len, codes.dist_len};
+            BitCounter price{codes.lit, codes.dist};
             parse_chunk(Linear{data}, lo, hi, x.ls.data(), x.line_at[t], x.on, K, price);
             bits[t] = price.bits; before[t] = body; body += bits[t];
         }
-        const uint32_t total_bits = codes.header_bits + body + codes.lit_len[256];
+        const uint32_t total_bits = codes.header_bits + body + (codes.lit[256] >> 16);
         uint32_t clen = (total_bits + 7) / 8;
         const bool stored = clen >= L + 5;
         if (stored) { clen = L + 5; ++stored_members; }
@@ -96,9 +96,9 @@ int main(int argc, char** argv)
                     for (uint32_t at = 0; at < codes.header_bits; at += 32)
                         w.put(codes.header_bits - at >= 32 ? codes.header[at >> 5] : codes.header[at >> 5] & ((1u << (codes.header_bits - at)) - 1u),
                               codes.header_bits - at >= 32 ? 32 : codes.header_bits - at);
-                Emitter<HostOr> emit{codes.lit_code, codes.lit_len, codes.dist_code, codes.dist_len, w};
+                Emitter<HostOr> emit{codes.lit, codes.dist, w};
                 parse_chunk(Linear{data}, lo, hi, x.ls.data(), x.line_at[t], x.on, K, emit);
-                if (t == kThreads - 1) w.put(codes.lit_code[256], codes.lit_len[256]);
+                if (t == kThreads - 1) w.put(codes.lit[256] & 0xFFFFu, codes.lit[256] >> 16);
                 w.finish();
             } else {
                 if (t == 0) { BitWriter<HostOr> w(slot.data(), kHeadBytes * 8, orw); w.put(1, 8); w.put(L, 16); w.put(~L & 0xFFFFu, 16); w.finish(); }

@@ -32,7 +32,7 @@ int main(int argc, char** argv)
     in.resize(n + 16);
     std::FILE* out = std::fopen(argv[2], "wb");
     unsigned long long members = 0, bad = 0, bytes = 0;
-    std::vector<uint8_t> buf(1 << 16);
+    std::vector<uint8_t> buf((1 << 16) + 16, 0xEE);
     Tables t; Lens l;
     for (size_t at = 0; at + 18 <= n;) {
         const uint8_t* p = in.data() + at;
@@ -41,10 +41,15 @@ int main(int argc, char** argv)
         const uint8_t* tail = p + total - 8;
         const uint32_t isize = tail[4] | (uint32_t(tail[5]) << 8) | (uint32_t(tail[6]) << 16) | (uint32_t(tail[7]) << 24);
         ++members;
-        if (isize > buf.size()) { ++bad; at += total; continue; }
-        const uint32_t st = inflate_member(p + 18, uint32_t(total - 26), buf.data(), isize, t, l);
+        if (isize > (1u << 16)) { ++bad; at += total; continue; }
+        // members land at every alignment, as they do in the text of a file; the bytes around them are not theirs
+        uint8_t* dst = buf.data() + 4 + (members & 3);
+        std::fill(buf.begin(), buf.end(), uint8_t(0xEE));
+        const uint32_t st = inflate_member(p + 18, uint32_t(total - 26), dst, isize, t, l);
+        if (st == kOk) for (size_t k = 0; k < buf.size(); ++k)
+            if ((buf.data() + k < dst || buf.data() + k >= dst + isize) && buf[k] != 0xEE) { std::fprintf(stderr, "member at %zu wrote outside its bytes\n", at); ++bad; break; }
         if (st != kOk) { ++bad; std::fprintf(stderr, "member at %zu: status %u\n", at, st); }
-        else { std::fwrite(buf.data(), 1, isize, out); bytes += isize; }
+        else { std::fwrite(dst, 1, isize, out); bytes += isize; }
         at += total;
     }
     std::fclose(out);

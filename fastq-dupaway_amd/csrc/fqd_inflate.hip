@@ -1,7 +1,7 @@
 // fqd_inflate.hip — BGZF inputs inflated and cut into records on the GPU (same library as fqd_engine.hip).
 //
 //   bgzf_inflate_kernel   one thread per member (fqd_inflate_core.hpp), 64 members per wave, the two
-//                         canonical-code tables of every thread in LDS, interleaved by lane
+//                         canonical-code tables of every thread in LDS (420 B, interleaved by lane: six waves per CU)
 //   bgzf_check_crc_kernel one workgroup per member: CRC-32 of what came out against the member's trailer
 //                         (chunk registers + pairwise combine, as the writer: fqd_bgzf_core.hpp)
 //   count_newlines / newline_positions / records kernels: the inflated text cut into FASTQ/FASTA records
@@ -33,11 +33,6 @@ namespace {
 
 constexpr uint32_t kWave = 64;
 
-struct LdsTables {                                      // entry i of lane l at [i * 64 + l]
-    uint16_t* base;
-    __device__ uint16_t get(uint32_t i) const { return base[i * kWave]; }
-    __device__ void set(uint32_t i, uint16_t v) { base[i * kWave] = v; }
-};
 struct GlobalLens {                                     // byte i of thread g at [i * stride + g]
     uint8_t* base; uint64_t stride;
     __device__ uint32_t get(uint32_t i) const { return base[i * stride]; }
@@ -49,9 +44,9 @@ void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __res
                          const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ out_len, uint64_t members,
                          uint8_t* __restrict__ text, uint8_t* __restrict__ lens_scratch, unsigned long long* __restrict__ n_bad)
 {
-    __shared__ uint16_t tables[fqd::inflate::kTableEntries * kWave];
+    __shared__ alignas(4) uint8_t tables[fqd::inflate::kPackedBytes * kWave];      // 26880 B: six waves per CU
     const uint64_t threads = uint64_t(gridDim.x) * kWave, gid = uint64_t(blockIdx.x) * kWave + threadIdx.x;
-    LdsTables t{tables + threadIdx.x};
+    fqd::inflate::PackedTables<kWave> t(tables, threadIdx.x);
     GlobalLens lens{lens_scratch + gid, threads};
     uint32_t bad = 0;
     for (uint64_t m = gid; m < members; m += threads) {
@@ -247,7 +242,7 @@ int fqd_bgzf_inflate(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_of
     if (n_members == 0) return FQD_OK;
     INF_TRY(e, hipSetDevice(fqd_internal_device(e)));
     hipStream_t stream = fqd_internal_stream(e);
-    const uint32_t grid = uint32_t(std::min<uint64_t>((n_members + kWave - 1) / kWave, 256u * 3u * 4u));
+    const uint32_t grid = uint32_t(std::min<uint64_t>((n_members + kWave - 1) / kWave, 256u * 6u * 2u));
     const size_t lens_bytes = round_up(size_t(fqd::inflate::kLitSymbols + fqd::inflate::kDistSymbols + 2) * grid * kWave, 256);
     const size_t tabs_bytes = round_up(sizeof(CrcTables), 256);
     void* base = nullptr;

@@ -10,13 +10,13 @@
 // The decoder works on the canonical form of a Huffman code: the symbols in code order (symbol[]) and,
 // per code length, where its codes end when written left-justified — fifteen numbers that stay in
 // registers.  The length of the next code is then fifteen comparisons away, its symbol one LDS read
-// more.  That needs 2 x 16 + 288 + 32 sixteen-bit entries per thread — small enough to live in LDS
-// for a whole wave — where a lookup-table decoder would need kilobytes per thread.  The main loop is a state machine that does
+// more.  That needs 420 bytes per thread (PackedTables below) — six waves' worth fit a CU's LDS — where a
+// lookup-table decoder would need kilobytes per thread.  The main loop is a state machine that does
 // a bounded amount of work per turn (one symbol decoded, or a few bytes of a match copied), so the
 // 64 members of a wave advance side by side instead of waiting out each other's long copies.
 //
-// `Tables` is where the per-thread arrays live (LDS, interleaved by lane, on the GPU; plain arrays in
-// tests/native/inflate_core_check.cpp, which runs this very code on the CPU against zlib).
+// `Tables` is where the per-thread arrays live: PackedTables<64> in LDS on the GPU, PackedTables<1> over a
+// plain array in tests/native/inflate_core_check.cpp, which runs this very code on the CPU against zlib.
 #pragma once
 
 #include <cstddef>
@@ -36,6 +36,40 @@ constexpr uint32_t kLitSymbols = 288, kDistSymbols = 30;
 // entries of a thread's table space (uint16 each): lit count[16], lit symbol[288], dist count[16], dist symbol[32]
 constexpr uint32_t kLitCount = 0, kLitSymbol = 16, kDistCount = 16 + 288, kDistSymbol = 16 + 288 + 16;
 constexpr uint32_t kTableEntries = 16 + 288 + 16 + 32;
+
+// Where a thread's tables live: 32 sixteen-bit "base" entries (lit 0..15, dist 16..31), the literal/length
+// symbols as a byte plane plus a ninth-bit plane, the distance symbols as bytes — 420 bytes per thread, so
+// that six waves of 64 threads fit the 160 KB of a CU.  Consecutive entries of one thread lie `Stride`
+// elements apart (64 on the GPU: the lanes of a wave side by side in every row; 1 in the CPU harness).
+constexpr uint32_t kPackedBytes = 32 * 2 + 288 + 36 + 32;
+template <uint32_t Stride>
+struct PackedTables {
+    uint16_t* base16;                 // 32 rows
+    uint8_t* lit_lo;                  // 288 rows
+    uint8_t* lit_hi;                  // 36 rows: bit (j & 7) of row (j >> 3) = ninth bit of literal/length symbol j
+    uint8_t* dist;                    // 32 rows
+    // `block` = the wave's (or thread's) table memory, `lane` = this thread's column
+    FQD_HD PackedTables(uint8_t* block, uint32_t lane)
+        : base16(reinterpret_cast<uint16_t*>(block) + lane), lit_lo(block + 64u * Stride + lane),
+          lit_hi(block + (64u + 288u) * Stride + lane), dist(block + (64u + 288u + 36u) * Stride + lane) {}
+    FQD_HD static uint32_t base_row(uint32_t i) { return i < kDistCount ? i : 16u + (i - kDistCount); }
+    FQD_HD uint16_t base_get(uint32_t i) const { return base16[base_row(i) * Stride]; }
+    FQD_HD void base_set(uint32_t i, uint16_t v) { base16[base_row(i) * Stride] = v; }
+    FQD_HD uint32_t sym_get(uint32_t i) const
+    {
+        if (i >= kDistSymbol) return dist[(i - kDistSymbol) * Stride];
+        const uint32_t j = i - kLitSymbol;
+        return uint32_t(lit_lo[j * Stride]) | (((uint32_t(lit_hi[(j >> 3) * Stride]) >> (j & 7u)) & 1u) << 8);
+    }
+    FQD_HD void sym_set(uint32_t i, uint32_t v)
+    {
+        if (i >= kDistSymbol) { dist[(i - kDistSymbol) * Stride] = uint8_t(v); return; }
+        const uint32_t j = i - kLitSymbol;
+        lit_lo[j * Stride] = uint8_t(v);
+        uint8_t& h = lit_hi[(j >> 3) * Stride];
+        h = uint8_t((h & ~(1u << (j & 7u))) | (((v >> 8) & 1u) << (j & 7u)));
+    }
+};
 
 enum Status : uint32_t { kOk = 0, kBadBlockType = 1, kBadStored = 2, kBadLengths = 3, kBadCode = 4, kBadDistance = 5,
                          kOutputOverrun = 6, kInputOverrun = 7, kShortOutput = 8 };
@@ -109,9 +143,9 @@ FQD_HD uint32_t decode_symbol(BitReader& in, const Tables& t, const Code& c, uin
 #pragma unroll
     for (uint32_t l = 0; l + 1 < kMaxBits; ++l) len += w >= c.lim[l] ? 1u : 0u;
     if (w >= c.lim[kMaxBits - 1]) return 0xFFFFu;                     // no code starts like this
-    const uint32_t index = uint32_t(int32_t(int16_t(t.get(base_at + len))) + int32_t(w >> (kMaxBits - len)));
+    const uint32_t index = uint32_t(int32_t(int16_t(t.base_get(base_at + len))) + int32_t(w >> (kMaxBits - len)));
     in.buf >>= len; in.cnt -= len;
-    return t.get(symbol_at + index);
+    return t.sym_get(symbol_at + index);
 }
 
 // Tables and comparison limits from code lengths len(0..n-1) (0 = symbol unused).  Returns false for an
@@ -120,35 +154,35 @@ FQD_HD uint32_t decode_symbol(BitReader& in, const Tables& t, const Code& c, uin
 template <class Tables, class Len>
 FQD_HD bool build_table(Tables& t, uint32_t base_at, uint32_t symbol_at, uint32_t n, const Len& len, Code& c, bool may_be_single = false)
 {
-    for (uint32_t l = 0; l <= kMaxBits; ++l) t.set(base_at + l, 0);
-    for (uint32_t s = 0; s < n; ++s) t.set(base_at + len(s), uint16_t(t.get(base_at + len(s)) + 1u));
+    for (uint32_t l = 0; l <= kMaxBits; ++l) t.base_set(base_at + l, 0);
+    for (uint32_t s = 0; s < n; ++s) t.base_set(base_at + len(s), uint16_t(t.base_get(base_at + len(s)) + 1u));
     int32_t left = 1;
     uint32_t codes = 0;
     for (uint32_t l = 1; l <= kMaxBits; ++l) {
         left <<= 1;
-        left -= int32_t(t.get(base_at + l));
-        codes += t.get(base_at + l);
+        left -= int32_t(t.base_get(base_at + l));
+        codes += t.base_get(base_at + l);
         if (left < 0) return false;
     }
-    if (left > 0 && !(may_be_single && (codes == 0u || (codes == 1u && t.get(base_at + 1u) == 1u)))) return false;
+    if (left > 0 && !(may_be_single && (codes == 0u || (codes == 1u && t.base_get(base_at + 1u) == 1u)))) return false;
     // per length: first code, place of its first symbol; the count makes room for the running place
     uint32_t code = 0, offset = 0;
     int32_t base[kMaxBits];
 #pragma unroll
     for (uint32_t l = 1; l <= kMaxBits; ++l) {
-        const uint32_t count = t.get(base_at + l);
+        const uint32_t count = t.base_get(base_at + l);
         base[l - 1] = int32_t(offset) - int32_t(code);
         c.lim[l - 1] = (code + count) << (kMaxBits - l);
-        t.set(base_at + l, uint16_t(offset));
+        t.base_set(base_at + l, uint16_t(offset));
         offset += count;
         code = (code + count) << 1;
     }
     for (uint32_t s = 0; s < n; ++s) {
         const uint32_t l = len(s);
-        if (l) { const uint32_t at = t.get(base_at + l); t.set(symbol_at + at, uint16_t(s)); t.set(base_at + l, uint16_t(at + 1u)); }
+        if (l) { const uint32_t at = t.base_get(base_at + l); t.sym_set(symbol_at + at, s); t.base_set(base_at + l, uint16_t(at + 1u)); }
     }
 #pragma unroll
-    for (uint32_t l = 1; l <= kMaxBits; ++l) t.set(base_at + l, uint16_t(base[l - 1]));
+    for (uint32_t l = 1; l <= kMaxBits; ++l) t.base_set(base_at + l, uint16_t(base[l - 1]));
     return true;
 }
 

@@ -425,12 +425,37 @@ void OutputFile::write_borrowed(const char* p, size_t n)
     drain(0);                                                 // nothing refers to the buffer any more
 }
 
-void OutputFile::write_members(const char* p, size_t n)
+void OutputFile::write_members(const char* p, size_t n, unsigned threads)
 {
     if (!gz_) throw std::logic_error("write_members: not a .gz output");
     submit_block();
     drain(0);
-    if (n && std::fwrite(p, 1, n, f_) != n) throw std::runtime_error("write failed: " + name_);
+    if (n == 0) return;
+    // A large batch into a regular file: its place is reserved and mapped, and several threads copy their share
+    // in — the page cache is filled in parallel, which one write stream cannot do (see write_pieces).
+    if (threads > 1 && n >= (8u << 20) && std::fflush(f_) == 0) {
+        const int fd = ::fileno(f_);
+        struct stat st;
+        const off_t at = ::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) ? ::lseek(fd, 0, SEEK_CUR) : off_t(-1);
+        if (at >= 0 && ::fallocate(fd, 0, at, static_cast<off_t>(n)) == 0) {
+            static const uint64_t page = static_cast<uint64_t>(::sysconf(_SC_PAGESIZE));
+            const uint64_t lo = static_cast<uint64_t>(at) / page * page, lead = static_cast<uint64_t>(at) - lo;
+            void* map = ::mmap(nullptr, lead + n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, static_cast<off_t>(lo));
+            if (map != MAP_FAILED) {
+                char* dst = static_cast<char*>(map) + lead;
+                const unsigned T = static_cast<unsigned>(std::max<uint64_t>(1, std::min<uint64_t>(threads, n >> 21)));
+                auto part = [&](unsigned k) { const size_t a = n / T * k, b = k + 1 == T ? n : n / T * (k + 1); std::memcpy(dst + a, p + a, b - a); };
+                std::vector<std::thread> pool;
+                for (unsigned k = 1; k < T; ++k) pool.emplace_back(part, k);
+                part(0);
+                for (std::thread& th : pool) th.join();
+                ::munmap(map, lead + n);
+                if (::lseek(fd, at + static_cast<off_t>(n), SEEK_SET) < 0) throw std::runtime_error("write failed: " + name_);
+                return;
+            }
+        }
+    }
+    if (std::fwrite(p, 1, n, f_) != n) throw std::runtime_error("write failed: " + name_);
 }
 
 void OutputFile::put_plain(const char* p, size_t n)

@@ -80,7 +80,7 @@ public:
     void write_borrowed(const char* p, size_t n);
     // .gz only: whole gzip members made elsewhere (on the GPU: fqd_bgzf_deflate) go to the file as they are,
     // after whatever write() still holds.
-    void write_members(const char* p, size_t n);
+    void write_members(const char* p, size_t n, unsigned threads = 1);
     bool is_gz() const { return gz_; }
     // Several pieces in one go: plain files hand them to writev() as they lie (no staging copy).
     struct Piece { const char* p; size_t n; };

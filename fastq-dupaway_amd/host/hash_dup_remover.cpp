@@ -1186,7 +1186,7 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
                     if (*id < 0) break;
                     try {
                         if (!o[s].error) {
-                            if (o[s].on_device) sinks[s]->write_members(o[s].buf[*id].p, o[s].bytes[*id]);
+                            if (o[s].on_device) sinks[s]->write_members(o[s].buf[*id].p, o[s].bytes[*id], write_threads());
                             else sinks[s]->write_borrowed(o[s].buf[*id].p, o[s].bytes[*id]);
                         }
                     }

@@ -12,11 +12,6 @@
 
 using namespace fqd::inflate;
 
-struct Tables {
-    uint16_t v[kTableEntries];
-    uint16_t get(uint32_t i) const { return v[i]; }
-    void set(uint32_t i, uint16_t x) { v[i] = x; }
-};
 struct Lens {
     uint8_t v[kLitSymbols + kDistSymbols + 2];
     uint32_t get(uint32_t i) const { return v[i]; }
@@ -33,7 +28,8 @@ int main(int argc, char** argv)
     std::FILE* out = std::fopen(argv[2], "wb");
     unsigned long long members = 0, bad = 0, bytes = 0;
     std::vector<uint8_t> buf((1 << 16) + 16, 0xEE);
-    Tables t; Lens l;
+    alignas(4) static uint8_t table_bytes[kPackedBytes];
+    PackedTables<1> t(table_bytes, 0); Lens l;
     for (size_t at = 0; at + 18 <= n;) {
         const uint8_t* p = in.data() + at;
         if (!(p[0] == 31 && p[1] == 139 && p[2] == 8 && p[3] == 4 && p[12] == 'B' && p[13] == 'C')) { ++bad; break; }

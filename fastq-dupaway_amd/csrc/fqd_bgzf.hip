@@ -290,11 +290,12 @@ int fqd_bgzf_deflate(fqd_engine* e, const uint8_t* src, uint64_t n, uint32_t lin
 
     const size_t hist_bytes = round_up((kLitLen + kDist) * sizeof(uint64_t), 256);
     const size_t codes_bytes = round_up(sizeof(Codes), 256);
-    const size_t sizes_bytes = round_up(members * sizeof(uint32_t), 256);
-    const size_t offs_bytes = round_up((members + 1) * sizeof(uint64_t), 256);
+    const uint64_t roomy = (members + 255) / 256 * 256;        // the scratch is sized in steps: calls of about the same size do not regrow it
+    const size_t sizes_bytes = round_up(roomy * sizeof(uint32_t), 256);
+    const size_t offs_bytes = round_up((roomy + 1) * sizeof(uint64_t), 256);
     const size_t slots_bytes = members * size_t(kSlot);
     void* base = nullptr;
-    const int rc = fqd_internal_scratch(e, 1, hist_bytes + codes_bytes + sizes_bytes + offs_bytes + slots_bytes, &base);
+    const int rc = fqd_internal_scratch(e, 1, hist_bytes + codes_bytes + sizes_bytes + offs_bytes + roomy * size_t(kSlot), &base);
     if (rc != FQD_OK) return rc;
     uint8_t* at = static_cast<uint8_t*>(base);
     unsigned long long* d_hist = reinterpret_cast<unsigned long long*>(at); at += hist_bytes;

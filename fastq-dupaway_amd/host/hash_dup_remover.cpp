@@ -1174,6 +1174,7 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
             std::thread writer; std::exception_ptr error;
         } o[2];
         static int kStop = -1;
+        const uint64_t roomy = window + window / 4;             // the most a window may hold
         for (int s = 0; s < 2; ++s) {
             o[s].src_off.reserve(upto); o[s].dst_off.reserve(upto + 1); o[s].len.reserve(upto);
             engine_ok(fqd_output_plan(eng.e, jp.keep.p, jp.pair[s].p, upto, dev[s].start.p, dev[s].size.p,
@@ -1214,24 +1215,29 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
                     uint64_t hi;
                     for (;;) {
                         hi = at[s] + take == upto ? o[s].total : peek_u64(o[s].dst_off.p, at[s] + take);
-                        if (hi - lo <= 2 * window || take == 1) break;
+                        if (hi - lo <= roomy || take == 1) break;
                         take = std::max<uint64_t>(1, take / 2);
                     }
                     const uint64_t bytes = hi - lo;
                     if (bytes) {
                         int* id = o[s].free_bufs.pop();
-                        o[s].d_win.reserve(bytes + 64); o[s].buf[*id].reserve(bytes + 64);
+                        // every buffer is sized once, for the largest window the loop above lets through: a window a little
+                        // larger than all before it must not cost a new pinned allocation (tens of milliseconds each)
+                        const uint64_t room = std::max(bytes, std::min<uint64_t>(roomy, o[s].total));      // (a small output: what it needs)
+                        o[s].d_win.reserve(room + 64);
+                        o[s].buf[*id].reserve((o[s].on_device ? std::max<uint64_t>(room / 2, 1u << 20) : room) + 64);
                         // dst_off is absolute in the output: the window's buffer starts `lo` bytes in
                         engine_ok(fqd_copy_spans(eng.e, reinterpret_cast<const uint8_t*>(dev[s].text.p), o[s].src_off.p + at[s], o[s].len.p + at[s], take,
                                                  reinterpret_cast<uint8_t*>(o[s].d_win.p) - lo, o[s].dst_off.p + at[s]));
                         uint64_t out_bytes = bytes;
                         const char* from = o[s].d_win.p;
                         if (o[s].on_device) {
-                            const uint64_t cap = fqd_bgzf_bound(bytes);
+                            const uint64_t cap = fqd_bgzf_bound(room);
                             o[s].d_members.reserve(cap);
                             engine_ok(fqd_bgzf_deflate(eng.e, reinterpret_cast<const uint8_t*>(o[s].d_win.p), bytes, lines_per_record,
                                                        reinterpret_cast<uint8_t*>(o[s].d_members.p), cap, &out_bytes));
                             from = o[s].d_members.p;
+                            o[s].buf[*id].reserve(out_bytes + 64);           // (text that does not shrink to half)
                         }
                         HIP_OK(hipMemcpyAsync(o[s].buf[*id].p, from, out_bytes, hipMemcpyDeviceToHost, stream));
                         HIP_OK(hipStreamSynchronize(stream));

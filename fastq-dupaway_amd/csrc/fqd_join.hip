@@ -736,7 +736,7 @@ void plan_gather_kernel(const uint8_t* __restrict__ keep, const uint32_t* __rest
     for (int e = 0; e < 8; ++e) {
         const uint64_t k = base + uint32_t(e);
         if (k < n) {
-            const uint32_t r = idx[k];
+            const uint64_t r = idx ? uint64_t(idx[k]) : k;               // no list: pair k is record k
             const uint32_t L = keep[k] ? sizes[r] : 0u;
             src_out[k] = starts[r]; len_out[k] = L; s += L;
         }
@@ -1032,7 +1032,7 @@ int fqd_output_plan(fqd_engine* e, const uint8_t* keep, const uint32_t* idx, uin
                     uint64_t* src_off, uint32_t* len, uint64_t* dst_off, uint64_t* total)
 {
     if (!e) return FQD_ERR_ARG;
-    if (!total || (n && (!keep || !idx || !starts || !sizes || !src_off || !len || !dst_off)))
+    if (!total || (n && (!keep || !starts || !sizes || !src_off || !len || !dst_off)))
         return fqd_internal_fail(e, FQD_ERR_ARG, "fqd_output_plan: bad arguments");
     *total = 0;
     if (n == 0) return FQD_OK;

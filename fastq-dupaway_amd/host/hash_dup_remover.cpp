@@ -622,7 +622,7 @@ void HashDupRemover::run_ordered_multi(int S, const std::string* in, const std::
 
 void HashDupRemover::filterSE(const std::string& infile, const std::string& outfile)
 {
-    try { if (tuning_.devices.empty()) run_ordered(1, &infile, &outfile); else run_ordered_multi(1, &infile, &outfile); }
+    try { if (tuning_.devices.empty()) { if (!run_ordered_resident(1, &infile, &outfile)) run_ordered(1, &infile, &outfile); } else run_ordered_multi(1, &infile, &outfile); }
     catch (const DiagnosedError& e) { std::cerr << e.diag; throw; }
 }
 
@@ -632,7 +632,7 @@ void HashDupRemover::filterPE(const std::string& infile1, const std::string& inf
     const std::string in[2] = {infile1, infile2}, out[2] = {outfile1, outfile2};
     try {
         if (unordered) run_unordered(in, out);
-        else if (tuning_.devices.empty()) run_ordered(2, in, out);
+        else if (tuning_.devices.empty()) { if (!run_ordered_resident(2, in, out)) run_ordered(2, in, out); }
         else           run_ordered_multi(2, in, out);
     } catch (const DiagnosedError& e) { std::cerr << e.diag; throw; }
 }
@@ -926,6 +926,16 @@ void HashDupRemover::run_unordered_in_memory(const std::string* in, const std::s
 }
 
 // One pass, text resident in HBM (see run_unordered).
+// A file whose text stays in HBM: the text and, per record, where it starts, where its sequence starts, the
+// lengths of its ID line and sequence, its size.
+struct FileOnDevice {
+    GrowDevice<char> text;
+    GrowDevice<uint64_t> start, seq_off; GrowDevice<uint32_t> id_len, seq_len, size;
+    Device<uint64_t> tag_off; Device<uint32_t> tag_len;
+    uint64_t n = 0;
+    void forget() { text.used = start.used = seq_off.used = id_len.used = seq_len.used = size.used = 0; n = 0; }
+};
+
 // A BGZF input of the resident run goes to HBM as it lies on disk — a fifth of its text — and is inflated and cut
 // into records THERE (fqd_bgzf_inflate, fqd_scan_records): the host only reads the file and walks the member
 // headers.  Whatever is not a regular, well-formed BGZF file holding whole records is read the host way instead
@@ -1001,6 +1011,40 @@ static bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, 
     return at == size && member == size && c.text_bytes > 0;
 }
 
+// The GPU's share of a file that arrived compressed: inflate, count lines, cut into records.  false: a damaged
+// member, or text that is not whole records — the caller reads the file the host way, which says what is wrong.
+static bool finish_on_device(fqd_engine* e, hipStream_t stream, Format format, CompressedOnDevice& c, FileOnDevice& f)
+{
+    auto engine_ok = [&](int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(e)); };
+    const uint64_t members = c.comp_off.size();
+    Device<uint64_t> d_comp_off, d_out_off; Device<uint32_t> d_comp_len, d_out_len, d_crc;
+    d_comp_off.reserve(members); d_out_off.reserve(members); d_comp_len.reserve(members); d_out_len.reserve(members); d_crc.reserve(members);
+    HIP_OK(hipMemcpy(d_comp_off.p, c.comp_off.data(), members * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_out_off.p, c.out_off.data(), members * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_comp_len.p, c.comp_len.data(), members * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_out_len.p, c.out_len.data(), members * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_crc.p, c.crc.data(), members * sizeof(uint32_t), hipMemcpyHostToDevice));
+    f.text.room_for(c.text_bytes + 64, stream);
+    uint64_t bad = 0;
+    engine_ok(fqd_bgzf_inflate(e, reinterpret_cast<const uint8_t*>(c.bytes.p), d_comp_off.p, d_comp_len.p, d_out_off.p, d_out_len.p,
+                               d_crc.p, members, reinterpret_cast<uint8_t*>(f.text.p), &bad));
+    c.bytes.release();
+    if (bad) return false;
+    const uint32_t lines_per_record = format == Format::Fastq ? 4u : 2u;
+    uint64_t lines = 0;
+    engine_ok(fqd_count_lines(e, reinterpret_cast<const uint8_t*>(f.text.p), c.text_bytes, &lines));
+    const uint64_t n = lines / lines_per_record;
+    f.start.room_for(n, stream); f.seq_off.room_for(n, stream); f.id_len.room_for(n, stream); f.seq_len.room_for(n, stream); f.size.room_for(n, stream);
+    int well_formed = 0;
+    engine_ok(fqd_scan_records(e, reinterpret_cast<const uint8_t*>(f.text.p), c.text_bytes, lines_per_record, n,
+                               f.start.p, f.seq_off.p, f.id_len.p, f.seq_len.p, f.size.p, &well_formed));
+    if (!well_formed || n == 0) return false;
+    f.text.used = c.text_bytes;
+    f.start.used = f.seq_off.used = f.id_len.used = f.seq_len.used = f.size.used = n;
+    f.n = n;
+    return true;
+}
+
 // `.gz` outputs of the resident run: deflated on the GPU (fqd_bgzf_deflate; the size of zlib level 1-2 at a
 // small fraction of its time) unless a level was asked for — FQD_GZ_LEVEL=N means the host codec at level N —
 // or FQD_GZ_DEVICE=0/1 says otherwise.
@@ -1008,6 +1052,190 @@ static bool deflate_on_device()
 {
     if (const char* v = std::getenv("FQD_GZ_DEVICE")) return std::atoi(v) != 0;
     return std::getenv("FQD_GZ_LEVEL") == nullptr;
+}
+
+// The outputs of a run whose text is in HBM: pair k < upto (record idx[s][k] of file s; idx[s] == nullptr: record k)
+// is written iff keep[k].  The device assembles windows of survivors in output order (and deflates them, for `.gz`
+// outputs: deflate_on_device), the host writes what comes back, a writer thread per file.  Closes the sinks.
+static void write_survivors(fqd_engine* e, hipStream_t stream, int S, FileOnDevice* const* file, const uint32_t* const* idx,
+                            const uint8_t* keep, uint64_t upto, uint64_t dups, OutputFile* const* sinks, Format format, long long memlimit)
+{
+    auto engine_ok = [&](int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(e)); };
+    uint64_t window = std::max<uint64_t>(4u << 20, static_cast<uint64_t>(memlimit > 0 ? memlimit : (2ll << 30)) / 16);   // bytes per buffer, two per file
+    if (const char* v = std::getenv("FQD_STREAM_WINDOW_KB")) { const long kb = std::atol(v); if (kb > 0) window = static_cast<uint64_t>(kb) << 10; }
+    const uint32_t lines_per_record = format == Format::Fastq ? 4u : 2u;
+    struct Out {
+        Device<uint64_t> src_off, dst_off; Device<uint32_t> len; uint64_t total = 0;
+        Pinned<char> buf[2]; Device<char> d_win, d_members;
+        Channel<int> free_bufs, full_bufs; int slot_id[2] = {0, 1}; size_t bytes[2] = {0, 0};
+        bool on_device = false;                       // .gz: windows leave the device as finished BGZF members
+        std::thread writer; std::exception_ptr error;
+    } o[2];
+    static int kStop = -1;
+    const uint64_t roomy = window + window / 4;             // the most a window may hold
+    for (int s = 0; s < S; ++s) {
+        o[s].src_off.reserve(upto); o[s].dst_off.reserve(upto + 1); o[s].len.reserve(upto);
+        engine_ok(fqd_output_plan(e, keep, idx[s], upto, file[s]->start.p, file[s]->size.p,
+                                  o[s].src_off.p, o[s].len.p, o[s].dst_off.p, &o[s].total));
+        o[s].free_bufs.push(&o[s].slot_id[0]); o[s].free_bufs.push(&o[s].slot_id[1]);
+        o[s].on_device = sinks[s]->is_gz() && deflate_on_device();
+        o[s].writer = std::thread([&, s] {
+            for (;;) {
+                int* id = o[s].full_bufs.pop();
+                if (*id < 0) break;
+                try {
+                    if (!o[s].error) {
+                        if (o[s].on_device) sinks[s]->write_members(o[s].buf[*id].p, o[s].bytes[*id], write_threads());
+                        else if (sinks[s]->is_gz()) sinks[s]->write_borrowed(o[s].buf[*id].p, o[s].bytes[*id]);
+                        else {                                   // a plain file: the window in slices, copied in by several threads
+                            constexpr size_t kSlices = 128;
+                            OutputFile::Piece pieces[kSlices];
+                            const size_t n = o[s].bytes[*id];
+                            for (size_t k = 0; k < kSlices; ++k) { const size_t a = n / kSlices * k, b = k + 1 == kSlices ? n : n / kSlices * (k + 1); pieces[k] = {o[s].buf[*id].p + a, b - a}; }
+                            sinks[s]->write_pieces(pieces, kSlices, write_threads());
+                        }
+                    }
+                }
+                catch (...) { o[s].error = std::current_exception(); }
+                o[s].free_bufs.push(id);
+            }
+        });
+    }
+    auto peek_u64 = [&](const uint64_t* d, uint64_t k) {
+        uint64_t v = 0;
+        HIP_OK(hipMemcpyAsync(&v, d + k, sizeof v, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        return v;
+    };
+    std::exception_ptr failure;
+    try {
+        uint64_t at[2] = {0, 0};
+        while (at[0] < upto || (S == 2 && at[1] < upto)) {
+            for (int s = 0; s < S; ++s) {
+                if (at[s] >= upto) continue;
+                // as many pairs as fill a window: from the average record size, halved until the bytes fit
+                const uint64_t avg = std::max<uint64_t>(1, o[s].total / std::max<uint64_t>(1, upto - dups));
+                uint64_t take = std::min<uint64_t>(upto - at[s], std::max<uint64_t>(1, window / avg));
+                const uint64_t lo = peek_u64(o[s].dst_off.p, at[s]);
+                uint64_t hi;
+                for (;;) {
+                    hi = at[s] + take == upto ? o[s].total : peek_u64(o[s].dst_off.p, at[s] + take);
+                    if (hi - lo <= roomy || take == 1) break;
+                    take = std::max<uint64_t>(1, take / 2);
+                }
+                const uint64_t bytes = hi - lo;
+                if (bytes) {
+                    int* id = o[s].free_bufs.pop();
+                    // every buffer is sized once, for the largest window the loop above lets through: a window a little
+                    // larger than all before it must not cost a new pinned allocation (tens of milliseconds each)
+                    const uint64_t room = std::max(bytes, std::min<uint64_t>(roomy, o[s].total));      // (a small output: what it needs)
+                    o[s].d_win.reserve(room + 64);
+                    o[s].buf[*id].reserve((o[s].on_device ? std::max<uint64_t>(room / 2, 1u << 20) : room) + 64);
+                    // dst_off is absolute in the output: the window's buffer starts `lo` bytes in
+                    engine_ok(fqd_copy_spans(e, reinterpret_cast<const uint8_t*>(file[s]->text.p), o[s].src_off.p + at[s], o[s].len.p + at[s], take,
+                                             reinterpret_cast<uint8_t*>(o[s].d_win.p) - lo, o[s].dst_off.p + at[s]));
+                    uint64_t out_bytes = bytes;
+                    const char* from = o[s].d_win.p;
+                    if (o[s].on_device) {
+                        const uint64_t cap = fqd_bgzf_bound(room);
+                        o[s].d_members.reserve(cap);
+                        engine_ok(fqd_bgzf_deflate(e, reinterpret_cast<const uint8_t*>(o[s].d_win.p), bytes, lines_per_record,
+                                                   reinterpret_cast<uint8_t*>(o[s].d_members.p), cap, &out_bytes));
+                        from = o[s].d_members.p;
+                        o[s].buf[*id].reserve(out_bytes + 64);           // (text that does not shrink to half)
+                    }
+                    HIP_OK(hipMemcpyAsync(o[s].buf[*id].p, from, out_bytes, hipMemcpyDeviceToHost, stream));
+                    HIP_OK(hipStreamSynchronize(stream));
+                    o[s].bytes[*id] = out_bytes;
+                    o[s].full_bufs.push(id);
+                }
+                at[s] += take;
+            }
+        }
+    } catch (...) { failure = std::current_exception(); }
+    for (int s = 0; s < S; ++s) { o[s].full_bufs.push(&kStop); o[s].writer.join(); }
+    if (failure) std::rethrow_exception(failure);
+    for (int s = 0; s < S; ++s) { if (o[s].error) std::rethrow_exception(o[s].error); sinks[s]->close(); }
+}
+
+// An ordered run (single-end, or paired files read side by side) whose inputs are BGZF: the files go to HBM
+// compressed, are inflated and cut into records there, every read (pair) is deduplicated where it lies, and the
+// survivors leave in input order window by window (deflated on the device for `.gz` outputs).  Taken only when
+// everything is plain sailing — regular BGZF files of whole records, as many in file 2 as in file 1, no unknown
+// base, everything fits in HBM; otherwise false is returned BEFORE any output is touched and the streaming run
+// (run_ordered), which reproduces the reference's behaviour for every irregular input, does the job.
+bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const std::string* out)
+{
+    if (const char* v = std::getenv("FQD_ORDERED_RESIDENT")) if (std::atoi(v) == 0) return false;
+    if (!inflate_on_device()) return false;
+    for (int s = 0; s < S; ++s) { uint64_t size = 0; if (!has_gz_extension(in[s]) || !is_regular_file(in[s], size)) return false; }
+    HIP_OK(hipSetDevice(tuning_.device));
+    hipStream_t stream = nullptr;
+    HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
+    const size_t block_bytes = std::max<size_t>(1u << 20, std::min<size_t>(tuning_.block_bytes, static_cast<size_t>(memlimit_ > 0 ? memlimit_ / 16 : tuning_.block_bytes)));
+    FileOnDevice dev[2];
+    Device<uint8_t> keep;
+    uint64_t n = 0, dups = 0;
+    std::unique_ptr<EngineHandle> eng;
+    try {
+        CompressedOnDevice packed[2];
+        bool fetched[2] = {false, false};
+        {
+            StageClock::Scope t("ordered/resident: files to HBM");
+            auto fetch = [&](int s) { try { fetched[s] = fetch_bgzf(in[s], block_bytes, tuning_.device, packed[s]); } catch (const std::exception&) { fetched[s] = false; } };
+            std::thread second;
+            if (S == 2) second = std::thread(fetch, 1);
+            fetch(0);
+            if (S == 2) second.join();
+        }
+        for (int s = 0; s < S; ++s) if (!fetched[s]) return false;
+        eng = std::make_unique<EngineHandle>(S, tuning_.device, stream);
+        {
+            StageClock::Scope t("ordered/resident: inflate + record scan on the GPU");
+            for (int s = 0; s < S; ++s) if (!finish_on_device(eng->e, stream, format_, packed[s], dev[s])) return false;
+        }
+        if (S == 2 && dev[0].n != dev[1].n) return false;
+        n = dev[0].n;
+        StageClock::Scope t("ordered/resident: dedup on the GPU");
+        keep.reserve(n);
+        const size_t kBatch = 16u << 20;
+        int rc = FQD_OK;
+        for (size_t a = 0; a < n && rc == FQD_OK; a += kBatch) {
+            fqd_reads seg[2] = {};
+            for (int s = 0; s < S; ++s) {
+                seg[s].bases = reinterpret_cast<const uint8_t*>(dev[s].text.p);
+                seg[s].offsets = dev[s].seq_off.p + a; seg[s].lengths = dev[s].seq_len.p + a;
+            }
+            rc = fqd_submit(eng->e, seg, std::min<size_t>(kBatch, n - a), FQD_MEM_DEVICE, keep.p + a);
+        }
+        if (rc == FQD_OK) rc = fqd_engine_sync(eng->e);
+        if (rc == FQD_ERR_BAD_BASE) return false;                 // the streaming run cuts the output where the reference does
+        if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng->e));
+        fqd_stats st{};
+        fqd_get_stats(eng->e, &st);
+        dups = st.duplicates;
+    } catch (const DeviceOutOfMemory&) {
+        return false;
+    }
+    // from here on the run is this one's: outputs are created, filled and closed
+    OutputFile sink0(out[0]);
+    std::unique_ptr<OutputFile> sink1;
+    if (S == 2) sink1 = std::make_unique<OutputFile>(out[1]);
+    OutputFile* sinks[2] = {&sink0, sink1.get()};
+    {
+        StageClock::Scope t("ordered/resident: survivors out of HBM");
+        FileOnDevice* files[2] = {&dev[0], &dev[1]};
+        const uint32_t* idx[2] = {nullptr, nullptr};
+        write_survivors(eng->e, stream, S, files, idx, keep.p, n, dups, sinks, format_, memlimit_);
+    }
+    StageClock::report();
+    summary_.total = n; summary_.duplicates = dups; summary_.unmatched = 0;
+    if (verbose_) {
+        if (S == 1) std::cout << summary_.total << " reads processed, out of which " << summary_.duplicates << " duplicates were removed.\n";
+        else        std::cout << summary_.total << " read pairs processed, out of which " << summary_.duplicates << " duplicates were removed.\n";
+    }
+    return true;
 }
 
 void HashDupRemover::run_unordered_resident(const std::string* in, const std::string* out)
@@ -1020,12 +1248,7 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
     auto engine_ok = [&](int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng.e)); };
     const size_t block_bytes = std::max<size_t>(1u << 20, std::min<size_t>(tuning_.block_bytes, static_cast<size_t>(memlimit_ > 0 ? memlimit_ / 16 : tuning_.block_bytes)));
 
-    struct FileOnDevice {
-        GrowDevice<char> text;
-        GrowDevice<uint64_t> start, seq_off; GrowDevice<uint32_t> id_len, seq_len, size;
-        Device<uint64_t> tag_off; Device<uint32_t> tag_len;
-        uint64_t n = 0;
-    } dev[2];
+    FileOnDevice dev[2];
 
     // ---- the one pass: every block to the tail of the file's text in HBM -------------------------------
     {
@@ -1086,44 +1309,11 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
         std::thread second(fetch_or_load, 1);
         fetch_or_load(0);
         second.join();
-        // the GPU's share of a file that arrived compressed: inflate, count lines, cut into records
-        auto finish_on_device = [&](int s) -> bool {
-            FileOnDevice& f = dev[s];
-            CompressedOnDevice& c = packed[s];
-            const uint64_t members = c.comp_off.size();
-            Device<uint64_t> d_comp_off, d_out_off; Device<uint32_t> d_comp_len, d_out_len, d_crc;
-            d_comp_off.reserve(members); d_out_off.reserve(members); d_comp_len.reserve(members); d_out_len.reserve(members); d_crc.reserve(members);
-            HIP_OK(hipMemcpy(d_comp_off.p, c.comp_off.data(), members * sizeof(uint64_t), hipMemcpyHostToDevice));
-            HIP_OK(hipMemcpy(d_out_off.p, c.out_off.data(), members * sizeof(uint64_t), hipMemcpyHostToDevice));
-            HIP_OK(hipMemcpy(d_comp_len.p, c.comp_len.data(), members * sizeof(uint32_t), hipMemcpyHostToDevice));
-            HIP_OK(hipMemcpy(d_out_len.p, c.out_len.data(), members * sizeof(uint32_t), hipMemcpyHostToDevice));
-            HIP_OK(hipMemcpy(d_crc.p, c.crc.data(), members * sizeof(uint32_t), hipMemcpyHostToDevice));
-            f.text.room_for(c.text_bytes + 64, stream);
-            uint64_t bad = 0;
-            engine_ok(fqd_bgzf_inflate(eng.e, reinterpret_cast<const uint8_t*>(c.bytes.p), d_comp_off.p, d_comp_len.p, d_out_off.p, d_out_len.p,
-                                       d_crc.p, members, reinterpret_cast<uint8_t*>(f.text.p), &bad));
-            c.bytes.release();
-            if (bad) return false;
-            const uint32_t lines_per_record = format_ == Format::Fastq ? 4u : 2u;
-            uint64_t lines = 0;
-            engine_ok(fqd_count_lines(eng.e, reinterpret_cast<const uint8_t*>(f.text.p), c.text_bytes, &lines));
-            const uint64_t n = lines / lines_per_record;
-            f.start.room_for(n, stream); f.seq_off.room_for(n, stream); f.id_len.room_for(n, stream); f.seq_len.room_for(n, stream); f.size.room_for(n, stream);
-            int well_formed = 0;
-            engine_ok(fqd_scan_records(eng.e, reinterpret_cast<const uint8_t*>(f.text.p), c.text_bytes, lines_per_record, n,
-                                       f.start.p, f.seq_off.p, f.id_len.p, f.seq_len.p, f.size.p, &well_formed));
-            if (!well_formed || n == 0) return false;
-            f.text.used = c.text_bytes;
-            f.start.used = f.seq_off.used = f.id_len.used = f.seq_len.used = f.size.used = n;
-            f.n = n;
-            return true;
-        };
         for (int s = 0; s < 2; ++s) {
             if (!on_device[s]) continue;
             StageClock::Scope t2("unordered/resident: inflate + record scan on the GPU");
-            if (!finish_on_device(s)) {                                               // read it again the host way: that one reports
-                FileOnDevice& f = dev[s];
-                f.text.used = f.start.used = f.seq_off.used = f.id_len.used = f.seq_len.used = f.size.used = 0; f.n = 0;
+            if (!finish_on_device(eng.e, stream, format_, packed[s], dev[s])) {         // read it again the host way: that one reports
+                dev[s].forget();
                 packed[s] = CompressedOnDevice();
                 load(s);
             }
@@ -1163,94 +1353,9 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
     // ---- outputs: the device assembles windows of survivors in output order, the host writes them -----
     {
         StageClock::Scope t("unordered/resident: survivors out of HBM");
-        uint64_t window = std::max<uint64_t>(4u << 20, static_cast<uint64_t>(memlimit_ > 0 ? memlimit_ : (2ll << 30)) / 16);   // bytes per buffer, two per file
-        if (const char* v = std::getenv("FQD_STREAM_WINDOW_KB")) { const long kb = std::atol(v); if (kb > 0) window = static_cast<uint64_t>(kb) << 10; }
-        const uint32_t lines_per_record = format_ == Format::Fastq ? 4u : 2u;
-        struct Out {
-            Device<uint64_t> src_off, dst_off; Device<uint32_t> len; uint64_t total = 0;
-            Pinned<char> buf[2]; Device<char> d_win, d_members;
-            Channel<int> free_bufs, full_bufs; int slot_id[2] = {0, 1}; size_t bytes[2] = {0, 0};
-            bool on_device = false;                       // .gz: windows leave the device as finished BGZF members
-            std::thread writer; std::exception_ptr error;
-        } o[2];
-        static int kStop = -1;
-        const uint64_t roomy = window + window / 4;             // the most a window may hold
-        for (int s = 0; s < 2; ++s) {
-            o[s].src_off.reserve(upto); o[s].dst_off.reserve(upto + 1); o[s].len.reserve(upto);
-            engine_ok(fqd_output_plan(eng.e, jp.keep.p, jp.pair[s].p, upto, dev[s].start.p, dev[s].size.p,
-                                      o[s].src_off.p, o[s].len.p, o[s].dst_off.p, &o[s].total));
-            o[s].free_bufs.push(&o[s].slot_id[0]); o[s].free_bufs.push(&o[s].slot_id[1]);
-            o[s].on_device = sinks[s]->is_gz() && deflate_on_device();
-            o[s].writer = std::thread([&, s] {
-                for (;;) {
-                    int* id = o[s].full_bufs.pop();
-                    if (*id < 0) break;
-                    try {
-                        if (!o[s].error) {
-                            if (o[s].on_device) sinks[s]->write_members(o[s].buf[*id].p, o[s].bytes[*id], write_threads());
-                            else sinks[s]->write_borrowed(o[s].buf[*id].p, o[s].bytes[*id]);
-                        }
-                    }
-                    catch (...) { o[s].error = std::current_exception(); }
-                    o[s].free_bufs.push(id);
-                }
-            });
-        }
-        auto peek_u64 = [&](const uint64_t* d, uint64_t k) {
-            uint64_t v = 0;
-            HIP_OK(hipMemcpyAsync(&v, d + k, sizeof v, hipMemcpyDeviceToHost, stream));
-            HIP_OK(hipStreamSynchronize(stream));
-            return v;
-        };
-        std::exception_ptr failure;
-        try {
-            uint64_t at[2] = {0, 0};
-            while (at[0] < upto || at[1] < upto) {
-                for (int s = 0; s < 2; ++s) {
-                    if (at[s] >= upto) continue;
-                    // as many pairs as fill a window: from the average record size, halved until the bytes fit
-                    const uint64_t avg = std::max<uint64_t>(1, o[s].total / std::max<uint64_t>(1, upto - dups));
-                    uint64_t take = std::min<uint64_t>(upto - at[s], std::max<uint64_t>(1, window / avg));
-                    const uint64_t lo = peek_u64(o[s].dst_off.p, at[s]);
-                    uint64_t hi;
-                    for (;;) {
-                        hi = at[s] + take == upto ? o[s].total : peek_u64(o[s].dst_off.p, at[s] + take);
-                        if (hi - lo <= roomy || take == 1) break;
-                        take = std::max<uint64_t>(1, take / 2);
-                    }
-                    const uint64_t bytes = hi - lo;
-                    if (bytes) {
-                        int* id = o[s].free_bufs.pop();
-                        // every buffer is sized once, for the largest window the loop above lets through: a window a little
-                        // larger than all before it must not cost a new pinned allocation (tens of milliseconds each)
-                        const uint64_t room = std::max(bytes, std::min<uint64_t>(roomy, o[s].total));      // (a small output: what it needs)
-                        o[s].d_win.reserve(room + 64);
-                        o[s].buf[*id].reserve((o[s].on_device ? std::max<uint64_t>(room / 2, 1u << 20) : room) + 64);
-                        // dst_off is absolute in the output: the window's buffer starts `lo` bytes in
-                        engine_ok(fqd_copy_spans(eng.e, reinterpret_cast<const uint8_t*>(dev[s].text.p), o[s].src_off.p + at[s], o[s].len.p + at[s], take,
-                                                 reinterpret_cast<uint8_t*>(o[s].d_win.p) - lo, o[s].dst_off.p + at[s]));
-                        uint64_t out_bytes = bytes;
-                        const char* from = o[s].d_win.p;
-                        if (o[s].on_device) {
-                            const uint64_t cap = fqd_bgzf_bound(room);
-                            o[s].d_members.reserve(cap);
-                            engine_ok(fqd_bgzf_deflate(eng.e, reinterpret_cast<const uint8_t*>(o[s].d_win.p), bytes, lines_per_record,
-                                                       reinterpret_cast<uint8_t*>(o[s].d_members.p), cap, &out_bytes));
-                            from = o[s].d_members.p;
-                            o[s].buf[*id].reserve(out_bytes + 64);           // (text that does not shrink to half)
-                        }
-                        HIP_OK(hipMemcpyAsync(o[s].buf[*id].p, from, out_bytes, hipMemcpyDeviceToHost, stream));
-                        HIP_OK(hipStreamSynchronize(stream));
-                        o[s].bytes[*id] = out_bytes;
-                        o[s].full_bufs.push(id);
-                    }
-                    at[s] += take;
-                }
-            }
-        } catch (...) { failure = std::current_exception(); }
-        for (int s = 0; s < 2; ++s) { o[s].full_bufs.push(&kStop); o[s].writer.join(); }
-        if (failure) std::rethrow_exception(failure);
-        for (int s = 0; s < 2; ++s) { if (o[s].error) std::rethrow_exception(o[s].error); sinks[s]->close(); }
+        FileOnDevice* files[2] = {&dev[0], &dev[1]};
+        const uint32_t* idx[2] = {jp.pair[0].p, jp.pair[1].p};
+        write_survivors(eng.e, stream, 2, files, idx, jp.keep.p, upto, dups, sinks, format_, memlimit_);
     }
     StageClock::report();
     if (jp.bad) throw_unknown_base(jp.bad_byte);

@@ -58,6 +58,7 @@ public:
     const Summary& summary() const { return summary_; }
 private:
     void run_ordered(int n_files, const std::string* in, const std::string* out);
+    bool run_ordered_resident(int n_files, const std::string* in, const std::string* out);   // false: not taken, nothing touched
     void run_ordered_multi(int n_files, const std::string* in, const std::string* out);
     void run_unordered(const std::string* in, const std::string* out);
     void run_unordered_in_memory(const std::string* in, const std::string* out);

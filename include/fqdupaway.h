@@ -287,7 +287,8 @@ int  fqd_output_offsets(fqd_engine* e, const uint8_t* keep, const uint32_t* idx,
 
 /* The same for a run whose text stays in HBM, per PAIR instead of per record: for pair k (tag order, k < n)
  * src_off[k] = starts[idx[k]] (where record idx[k] lies in the text), len[k] = sizes[idx[k]] if keep[k] else 0,
- * dst_off[k] = sum of len[j], j < k (where it goes in the output); *total (host) = output size.  A window
+ * dst_off[k] = sum of len[j], j < k (where it goes in the output); *total (host) = output size.  idx == NULL:
+ * pair k is record k (an ordered run: the output keeps the input's order).  A window
  * [a, b) of pairs is then assembled in output order by one fqd_copy_spans over src_off+a, len+a, dst_off+a. */
 int  fqd_output_plan(fqd_engine* e, const uint8_t* keep, const uint32_t* idx, uint64_t n, const uint64_t* starts,
                      const uint32_t* sizes, uint64_t* src_off, uint32_t* len, uint64_t* dst_off, uint64_t* total);

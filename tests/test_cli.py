@@ -494,6 +494,81 @@ def test_unordered_bgzf_inputs_inflated_on_the_device(exe, oracle, tmp_path, cas
         assert rc != 0 and "Invalid record start character: x" in said
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("case", ["fastq_to_gz", "fastq_to_plain", "fasta", "small_windows", "bad_base", "bad_record", "uneven_pairs",
+                                  "flipped_bit", "plain_gzip"])
+def test_ordered_runs_on_bgzf_inputs_stay_on_the_device(exe, oracle, tmp_path, case, paired):
+    """SE / ordered PE with BGZF inputs: files to HBM compressed, inflate + record scan + dedup there, survivors out in
+    input order (run_ordered_resident).  Irregular inputs are left to the streaming run untouched.  Either way the
+    oracle's bytes and lines, and exactly what FQD_ORDERED_RESIDENT=0 gives."""
+    from inflate_cases import bgzf
+    rnd = random.Random(17 + paired)
+    n = 5000
+    fasta = case == "fasta"
+    seqs = random_reads(rnd, n, 700, 30, 100)
+    r1 = [(b"M01:7:FC:1:%d:%d 1:N:0" % (1100 + k % 7, 1000 + k), seqs[k]) for k in range(n)]
+    r2 = [(b"M01:7:FC:1:%d:%d 2:N:0" % (1100 + k % 7, 1000 + k), seqs[(k * 13) % n]) for k in range(n)]
+    if case == "uneven_pairs":
+        del r2[-7:]
+    if case == "bad_base":
+        i, q = r1[3000]; r1[3000] = (i, q[:5] + b"x" + q[6:])
+
+    def text(recs):
+        return b"".join(b">" + i + b"\n" + q + b"\n" for i, q in recs) if fasta else fastq(recs)
+    t = [text(r1), text(r2)]
+    if case == "bad_record":
+        cut = t[0].index(b"\n@", len(t[0]) // 2) + 1
+        t[0] = t[0][:cut] + b"y" + t[0][cut + 1:]
+    z = [bgzf(x, level=1) for x in t]
+    if case == "flipped_bit":
+        b = bytearray(z[0]); b[len(b) // 2] ^= 4; z[0] = bytes(b)
+    if case == "plain_gzip":
+        z[0] = gzip.compress(t[0], 1)
+    S = 2 if paired else 1
+    ext = "fa" if fasta else "fq"
+    oext = ext if case == "fastq_to_plain" else ext + ".gz"
+    ins = [tmp_path / f"r{s + 1}.{ext}.gz" for s in range(S)]
+    for s in range(S):
+        ins[s].write_bytes(z[s])
+    fmt = ["--format", "fasta"] if fasta else []
+    env0 = {"FQD_HOST_TIMING": "1"}
+    if case == "small_windows":
+        env0["FQD_STREAM_WINDOW_KB"] = "96"
+    runs = {}
+    for resident in ("1", "0"):
+        outs = [tmp_path / f"g{s + 1}_{resident}.{oext}" for s in range(S)]
+        args = ["-i", ins[0], "-o", outs[0]] + (["-u", ins[1], "-p", outs[1]] if paired else [])
+        r = run(exe, *args, "--fast", "-v", *fmt, env={**env0, "FQD_ORDERED_RESIDENT": resident}, cwd=tmp_path)
+        said = "\n".join(l for l in r.stderr.splitlines() if "[host timing]" not in l)
+
+        def content(p):
+            if not p.exists():
+                return None
+            return gzip.open(p, "rb").read() if str(p).endswith(".gz") else p.read_bytes()
+        runs[resident] = (r.returncode, r.stdout, said, [content(p) for p in outs])
+        good = case in ("fastq_to_gz", "fastq_to_plain", "fasta", "small_windows") or (case == "uneven_pairs" and not paired)
+        if r.returncode == 0:
+            assert ("ordered/resident: survivors out of HBM" in r.stderr) == (resident == "1" and good), r.stderr
+    assert runs["1"] == runs["0"]
+    rc, out, said, got = runs["1"]
+    if case in ("fastq_to_gz", "fastq_to_plain", "fasta", "small_windows", "uneven_pairs", "plain_gzip"):
+        ps = [tmp_path / f"p{s + 1}.{ext}" for s in range(S)]
+        es = [tmp_path / f"e{s + 1}.{ext}" for s in range(S)]
+        for s in range(S):
+            ps[s].write_bytes(t[s])
+        if paired:
+            tot, dup, un = oracle.filter_paired(ps[0], ps[1], es[0], es[1], FASTA if fasta else FASTQ)
+            line = f"{tot} read pairs processed, out of which {dup} duplicates were removed.\n"
+        else:
+            tot, dup = oracle.filter_single(ps[0], es[0], FASTA if fasta else FASTQ)
+            line = f"{tot} reads processed, out of which {dup} duplicates were removed.\n"
+        assert rc == 0 and out == line and tot > 4000
+        assert got == [e.read_bytes() for e in es]
+    else:
+        assert rc != 0
+
+
 # ---------------------------------------------------------------- GPU: several engines in one run (FQD_DEVICES)
 
 def uniform_fastq(rnd, n, L, pool, ident):

@@ -66,7 +66,7 @@ def main():
     plain_files = list(files)
     ext = ".fq.gz" if a.gz else ".fq"
     if a.gz:                                     # BGZF inputs, packed by the host driver's own file layer
-        packer = d / "e2e_bgzf_pack"
+        packer = Path("/tmp") / f"e2e_bgzf_pack_{os.getpid()}"      # not in --dir: /dev/shm is mounted noexec
         subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(packer), str(ROOT / "tools" / "bgzf_pack.cpp"),
                         str(ROOT / "fastq-dupaway_amd" / "host" / "file_io.cpp"), "-lz", "-lpthread"], check=True)
         for k, f in enumerate(files):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FQD_ABI_VERSION 2
+#define FQD_ABI_VERSION 3
 
 /* status codes */
 #define FQD_OK              0

@@ -32,6 +32,7 @@ namespace fqd {
 namespace inflate {
 
 constexpr uint32_t kMaxBits = 15;
+constexpr uint32_t kBurst = 32;                  // literals decoded back to back before the other states get their turn
 constexpr uint32_t kLitSymbols = 288, kDistSymbols = 30;
 // entries of a thread's table space (uint16 each): lit count[16], lit symbol[288], dist count[16], dist symbol[32]
 constexpr uint32_t kLitCount = 0, kLitSymbol = 16, kDistCount = 16 + 288, kDistSymbol = 16 + 288 + 16;
@@ -52,6 +53,15 @@ struct PackedTables {
     FQD_HD PackedTables(uint8_t* block, uint32_t lane)
         : base16(reinterpret_cast<uint16_t*>(block) + lane), lit_lo(block + 64u * Stride + lane),
           lit_hi(block + (64u + 288u) * Stride + lane), dist(block + (64u + 288u + 36u) * Stride + lane) {}
+    // wave vote (the CPU harness is a wave of one)
+    FQD_HD bool most_lanes(bool mine) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return 2 * __popcll(__ballot(mine)) >= __popcll(__ballot(true));
+#else
+        return mine;
+#endif
+    }
     FQD_HD static uint32_t base_row(uint32_t i) { return i < kDistCount ? i : 16u + (i - kDistCount); }
     FQD_HD uint16_t base_get(uint32_t i) const { return base16[base_row(i) * Stride]; }
     FQD_HD void base_set(uint32_t i, uint16_t v) { base16[base_row(i) * Stride] = v; }
@@ -217,7 +227,19 @@ FQD_HD uint32_t inflate_member(const uint8_t* in_bytes, uint32_t in_len, uint8_t
     constexpr uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     while (state != kDone) {
         if (state == kSymbols) {
-            const uint32_t sym = decode_symbol(in, t, lit, kLitCount, kLitSymbol);
+            // Literals are most of what a FASTQ stream holds, and a turn of this loop costs every lane of the wave
+            // every branch some lane takes: a run of up to kBurst literals is therefore decoded in a tight loop of
+            // its own, kept up as long as most lanes of the wave are still in it (a stream full of matches would
+            // otherwise wait out the few lanes that are).
+            uint32_t sym = decode_symbol(in, t, lit, kLitCount, kLitSymbol);
+            for (uint32_t burst = 1; burst < kBurst; ++burst) {
+                const bool more = sym < 256u && pos + 1u < out_len;
+                if (!t.most_lanes(more)) break;                   // the run goes on while most of the wave is in it
+                if (more) {
+                    out[pos++] = uint8_t(sym);
+                    sym = decode_symbol(in, t, lit, kLitCount, kLitSymbol);
+                }
+            }
             if (sym < 256u) {
                 if (pos >= out_len) { status = kOutputOverrun; break; }
                 out[pos++] = uint8_t(sym);

@@ -1024,20 +1024,29 @@ static bool finish_on_device(fqd_engine* e, hipStream_t stream, Format format, C
     HIP_OK(hipMemcpy(d_comp_len.p, c.comp_len.data(), members * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_out_len.p, c.out_len.data(), members * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_crc.p, c.crc.data(), members * sizeof(uint32_t), hipMemcpyHostToDevice));
-    f.text.room_for(c.text_bytes + 64, stream);
+    { StageClock::Scope t("  on the GPU: room for the text"); f.text.room_for(c.text_bytes + 64, stream); }
     uint64_t bad = 0;
-    engine_ok(fqd_bgzf_inflate(e, reinterpret_cast<const uint8_t*>(c.bytes.p), d_comp_off.p, d_comp_len.p, d_out_off.p, d_out_len.p,
-                               d_crc.p, members, reinterpret_cast<uint8_t*>(f.text.p), &bad));
-    c.bytes.release();
+    {
+        StageClock::Scope t("  on the GPU: inflate + CRC check");
+        engine_ok(fqd_bgzf_inflate(e, reinterpret_cast<const uint8_t*>(c.bytes.p), d_comp_off.p, d_comp_len.p, d_out_off.p, d_out_len.p,
+                                   d_crc.p, members, reinterpret_cast<uint8_t*>(f.text.p), &bad));
+    }
+    { StageClock::Scope t("  on the GPU: compressed bytes freed"); c.bytes.release(); }
     if (bad) return false;
     const uint32_t lines_per_record = format == Format::Fastq ? 4u : 2u;
     uint64_t lines = 0;
-    engine_ok(fqd_count_lines(e, reinterpret_cast<const uint8_t*>(f.text.p), c.text_bytes, &lines));
+    { StageClock::Scope t("  on the GPU: line count"); engine_ok(fqd_count_lines(e, reinterpret_cast<const uint8_t*>(f.text.p), c.text_bytes, &lines)); }
     const uint64_t n = lines / lines_per_record;
-    f.start.room_for(n, stream); f.seq_off.room_for(n, stream); f.id_len.room_for(n, stream); f.seq_len.room_for(n, stream); f.size.room_for(n, stream);
+    {
+        StageClock::Scope t("  on the GPU: room for the record arrays");
+        f.start.room_for(n, stream); f.seq_off.room_for(n, stream); f.id_len.room_for(n, stream); f.seq_len.room_for(n, stream); f.size.room_for(n, stream);
+    }
     int well_formed = 0;
-    engine_ok(fqd_scan_records(e, reinterpret_cast<const uint8_t*>(f.text.p), c.text_bytes, lines_per_record, n,
-                               f.start.p, f.seq_off.p, f.id_len.p, f.seq_len.p, f.size.p, &well_formed));
+    {
+        StageClock::Scope t("  on the GPU: record scan");
+        engine_ok(fqd_scan_records(e, reinterpret_cast<const uint8_t*>(f.text.p), c.text_bytes, lines_per_record, n,
+                                   f.start.p, f.seq_off.p, f.id_len.p, f.seq_len.p, f.size.p, &well_formed));
+    }
     if (!well_formed || n == 0) return false;
     f.text.used = c.text_bytes;
     f.start.used = f.seq_off.used = f.id_len.used = f.seq_len.used = f.size.used = n;

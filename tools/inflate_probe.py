@@ -29,6 +29,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", type=int, default=1_900_000)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--host-packed", action="store_true", help="also inflate the same text packed by the host codec (libdeflate / zlib level 1: many more matches)")
+    ap.add_argument("--quality", choices=["mixed", "flat"], default="mixed", help="flat: every quality 'I' (long runs, as the configs[4] generator writes)")
     a = ap.parse_args()
     import torch
     from fastq_dupaway_amd import Engine
@@ -43,7 +45,10 @@ def main():
     rec[:, 11:18] = torch.tensor(list(b" 1:N:0\n"), dtype=torch.uint8, device=dev)
     rec[:, 18:18 + L] = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (n, L), device=dev, generator=g)]
     rec[:, 18 + L] = 10; rec[:, 19 + L] = ord("+"); rec[:, 20 + L] = 10
-    rec[:, 21 + L:21 + 2 * L] = torch.tensor(list(b"FFFFFFFF:,#"), dtype=torch.uint8, device=dev)[torch.randint(0, 11, (n, L), device=dev, generator=g)]
+    if a.quality == "flat":
+        rec[:, 21 + L:21 + 2 * L] = ord("I")
+    else:
+        rec[:, 21 + L:21 + 2 * L] = torch.tensor(list(b"FFFFFFFF:,#"), dtype=torch.uint8, device=dev)[torch.randint(0, 11, (n, L), device=dev, generator=g)]
     rec[:, 21 + 2 * L] = 10
     src = rec.reshape(-1); nbytes = src.numel()
     with Engine(segments=1, device=0) as e:
@@ -61,6 +66,24 @@ def main():
         for _ in range(a.reps):
             t0 = time.perf_counter(); bad = e.bgzf_inflate(dst, *args, len(arrs[0]), text); dt = time.perf_counter() - t0
             print(f"inflate {len(arrs[0])} members -> {total / 1e6:.0f} MB: {dt * 1e3:.1f} ms = {total / dt / 1e9:.1f} GB/s, bad {bad}, equal {bool(torch.equal(text[:total], src))}", flush=True)
+        if a.host_packed:
+            import os, subprocess, tempfile
+            d = tempfile.mkdtemp(prefix="fqd_probe_", dir="/tmp")
+            packer = os.path.join(d, "pack")
+            subprocess.run(["g++", "-O2", "-std=c++17", "-o", packer, str(ROOT / "tools" / "bgzf_pack.cpp"),
+                            str(ROOT / "fastq-dupaway_amd" / "host" / "file_io.cpp"), "-lz", "-lpthread"], check=True)
+            src.cpu().numpy().tofile(os.path.join(d, "t.fq"))
+            subprocess.run([packer, os.path.join(d, "t.fq"), os.path.join(d, "t.fq.gz")], check=True, env=dict(os.environ, FQD_GZ_LEVEL="1"))
+            raw = open(os.path.join(d, "t.fq.gz"), "rb").read()
+            arrs, total = walk(raw)
+            comp = torch.frombuffer(bytearray(raw + bytes(16)), dtype=torch.uint8).to(dev)
+            args = [t(v) for v in arrs]
+            text.zero_(); torch.cuda.synchronize()
+            for _ in range(a.reps):
+                t0 = time.perf_counter(); bad = e.bgzf_inflate(comp, *args, len(arrs[0]), text); dt = time.perf_counter() - t0
+                print(f"inflate (host-packed, {len(raw) / 1e6:.0f} MB) {len(arrs[0])} members -> {total / 1e6:.0f} MB: {dt * 1e3:.1f} ms = {total / dt / 1e9:.1f} GB/s, "
+                      f"bad {bad}, equal {bool(torch.equal(text[:total], src))}", flush=True)
+            import shutil; shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -79,21 +79,20 @@ __device__ __forceinline__ uint32_t load_member(const uint8_t* __restrict__ src,
     return L;
 }
 
-// Line starts of the member (ls[0] = 0, ls[j] = byte after the j-th newline) and, per thread, the
-// line its chunk starts in.  Returns whether the index is usable (not more lines than it holds).
-__device__ __forceinline__ bool index_lines(MemberLds& s, uint32_t lo, uint32_t hi)
+// Line starts of the member (ls[0] = 0, ls[j] = byte after the j-th newline) from the threads' newline masks and,
+// per thread, the line its chunk starts in.  Returns whether the index is usable (not more lines than it holds).
+__device__ __forceinline__ bool index_lines(MemberLds& s, const Scan& sc, uint32_t lo)
 {
-    const Skewed data{s.data};
-    uint32_t mine = 0;
-    for (uint32_t p = lo; p < hi; ++p) mine += data[p] == uint8_t('\n') ? 1u : 0u;
+    const uint32_t mine = uint32_t(__popcll(sc.nl.lo) + __popcll(sc.nl.hi));
     uint32_t total;
     const uint32_t before = block_scan(mine, s.wave_sums, total);
     s.line_at[threadIdx.x] = before;
     const bool on = total <= kMaxLines;
-    if (threadIdx.x == 0) s.ls[0] = 0;
+    if (threadIdx.x == 0) { s.ls[0] = 0; s.n_lines = total; }
     if (on) {
         uint32_t k = before + 1u;
-        for (uint32_t p = lo; p < hi; ++p) if (data[p] == uint8_t('\n')) s.ls[k++] = uint16_t(p + 1u);
+        for (uint64_t m = sc.nl.lo; m; m &= m - 1u) s.ls[k++] = uint16_t(lo + uint32_t(__builtin_ctzll(m)) + 1u);
+        for (uint64_t m = sc.nl.hi; m; m &= m - 1u) s.ls[k++] = uint16_t(lo + 64u + uint32_t(__builtin_ctzll(m)) + 1u);
     }
     __syncthreads();
     return on;
@@ -124,9 +123,12 @@ void bgzf_count_kernel(const uint8_t* __restrict__ src, uint64_t n, uint64_t mem
         __syncthreads();
         uint32_t lo, hi;
         chunk_of(threadIdx.x, L, lo, hi);
-        const bool lines_on = index_lines(s, lo, hi);
+        const Skewed data{s.data};
+        const Scan sc = scan_chunk(data, lo, hi);
+        const bool lines_on = index_lines(s, sc, lo);
+        const Columns col = column_masks(data, lo, hi, s.ls, s.line_at[threadIdx.x], s.n_lines, L, lines_on, lines_per_record);
         TokenCounter sink{hist};
-        parse_chunk(Skewed{s.data}, lo, hi, s.ls, s.line_at[threadIdx.x], lines_on, lines_per_record, sink);
+        parse_chunk(data, lo, hi, sc, col, sink);
         __syncthreads();                                // before the next member overwrites data
     }
     for (uint32_t i = threadIdx.x; i < kLitLen + kDist; i += kThreads)
@@ -153,12 +155,13 @@ void bgzf_emit_kernel(const uint8_t* __restrict__ src, uint64_t n, uint64_t memb
         __syncthreads();
         uint32_t lo, hi;
         chunk_of(t, L, lo, hi);
-        const bool lines_on = index_lines(s, lo, hi);
-        const uint32_t line = s.line_at[t];
+        const Skewed data{s.data};
+        const Scan sc = scan_chunk(data, lo, hi);
+        const bool lines_on = index_lines(s, sc, lo);
+        const Columns col = column_masks(data, lo, hi, s.ls, s.line_at[t], s.n_lines, L, lines_on, lines_per_record);
 
         BitCounter price{lit, dst};
-        const Skewed data{s.data};
-        parse_chunk(data, lo, hi, s.ls, line, lines_on, lines_per_record, price);
+        parse_chunk(data, lo, hi, sc, col, price);
         uint32_t body_bits;
         const uint32_t before = block_scan(price.bits, s.wave_sums, body_bits);
         const uint32_t total_bits = header_bits + body_bits + (lit[256] >> 16);
@@ -175,7 +178,7 @@ void bgzf_emit_kernel(const uint8_t* __restrict__ src, uint64_t n, uint64_t memb
                     w.put(header_bits - at >= 32u ? codes->header[at >> 5] : codes->header[at >> 5] & ((1u << (header_bits - at)) - 1u),
                           header_bits - at >= 32u ? 32u : header_bits - at);
             Emitter<DeviceOr> emit{lit, dst, w};
-            parse_chunk(data, lo, hi, s.ls, line, lines_on, lines_per_record, emit);
+            parse_chunk(data, lo, hi, sc, col, emit);
             if (t == kThreads - 1u) w.put(lit[256] & 0xFFFFu, lit[256] >> 16);      // end of block
             w.finish();
         } else {

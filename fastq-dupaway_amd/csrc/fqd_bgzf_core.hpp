@@ -99,10 +99,15 @@ struct Skewed {
     const uint8_t* base;
     FQD_HD static uint32_t at(uint32_t p) { return p + ((p >> 7) << 2); }
     FQD_HD uint8_t operator[](uint32_t p) const { return base[at(p)]; }
+    FQD_HD uint32_t word(uint32_t p) const { return *reinterpret_cast<const uint32_t*>(base + at(p)); }   // p a multiple of 4
 };
 struct Linear {
     const uint8_t* base;
     FQD_HD uint8_t operator[](uint32_t p) const { return base[p]; }
+    FQD_HD uint32_t word(uint32_t p) const
+    {
+        return uint32_t(base[p]) | (uint32_t(base[p + 1]) << 8) | (uint32_t(base[p + 2]) << 16) | (uint32_t(base[p + 3]) << 24);
+    }
 };
 
 // Every `sample_every`-th member is parsed for the token histogram once there are enough of them (the codes
@@ -110,60 +115,116 @@ struct Linear {
 // at least one, so that whatever the other members hold can be written.
 FQD_HD uint32_t sample_every(uint64_t members) { return members >= 64u ? 8u : 1u; }
 
-// Greedy parse of [lo, hi): `line` = number of newlines before lo, ls[j] = start of line j
-// (ls[0] = 0), valid when lines_on.  The sink sees every token in order.  Per input byte: one read of
-// the byte, one of its code — the previous byte rides in a register, and the column candidate is looked
-// at only inside ID lines (lines that begin with '@' or '>'), its distance fixed when the line is entered.
-template <class Data, class Sink>
-FQD_HD void parse_chunk(const Data& data, uint32_t lo, uint32_t hi, const uint16_t* ls, uint32_t line,
-                        bool lines_on, uint32_t lines_per_record, Sink& sink)
+// What a thread knows about its chunk before it parses it, as 128-bit masks (bit i = byte lo + i): which bytes
+// equal the byte before them (the runs), which are newlines, and — inside ID lines — which equal the byte
+// `delta` back, the same column one record up.  The masks come from 32-bit reads and byte-parallel arithmetic, a
+// fixed amount of work for every lane; the parse then jumps from token to token with count-trailing-zeros
+// instead of comparing byte by byte in loops whose lengths differ from lane to lane.
+struct Mask128 { uint64_t lo, hi; };
+struct Scan { Mask128 eq, nl; };
+struct Columns { Mask128 same; uint32_t delta0, delta1, split; };        // bits below `split` belong to delta0
+
+FQD_HD uint32_t zero_bytes(uint32_t x)                               // bit k = byte k of x is zero
 {
-    uint32_t p = lo, j = line;
-    uint32_t prev = p > 0 ? uint32_t(data[p - 1]) : 0x100u;
-    uint32_t delta = 0;                                              // distance of the column candidate; 0: none in this line
-    auto enter_line = [&]() {
-        delta = 0;
-        if (lines_on && j >= lines_per_record) {
-            const uint32_t s = ls[j];
-            if (s < hi) {
-                const uint32_t first = data[s], d = s - uint32_t(ls[j - lines_per_record]);
-                if ((first == uint32_t('@') || first == uint32_t('>')) && d <= 32768u) delta = d;
-            }
-        }
-    };
-    enter_line();
-    while (p < hi) {
-        const uint32_t b = data[p];
-        const uint32_t room = hi - p < kMaxMatch ? hi - p : kMaxMatch;
-        uint32_t best = 0, dist = 0, newlines = 0, last = b;
-        if (room >= kMinMatch) {
-            if (b == prev) {                                         // the run goes on: distance 1
-                uint32_t r = 1;
-                while (r < room && data[p + r] == b) ++r;
-                if (r >= kMinMatch) { best = r; dist = 1; newlines = b == uint32_t('\n') ? r : 0u; }
-            }
-            if (delta && best < room) {                              // same column, one record up
-                const uint32_t q = p - delta;
-                if (data[q] == b) {
-                    uint32_t r = 1, n2 = b == uint32_t('\n') ? 1u : 0u, c = b;
-                    while (r < room) {
-                        const uint32_t x = data[p + r];
-                        if (uint32_t(data[q + r]) != x) break;
-                        c = x; n2 += x == uint32_t('\n') ? 1u : 0u; ++r;
-                    }
-                    if (r >= kMinMatch && r > best) { best = r; dist = delta; newlines = n2; last = c; }
+    uint32_t y = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    y = ~(y | x | 0x7F7F7F7Fu);                                      // 0x80 in every zero byte, exactly
+    return ((y >> 7) * 0x01020408u) >> 24;
+}
+
+template <class Data>
+FQD_HD Scan scan_chunk(const Data& data, uint32_t lo, uint32_t hi)
+{
+    Scan s{{0, 0}, {0, 0}};
+    const uint32_t L = hi - lo;
+    if (L == 0) return s;
+    const uint32_t a = lo & ~3u, sh = (lo & 3u) * 8u;
+    uint32_t next = data.word(a);
+    uint32_t carry = lo > 0 ? uint32_t(data[lo - 1]) : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < kChunk / 4u; ++k) {                     // bytes at and beyond hi are masked off below
+        const uint32_t w0 = next;
+        next = data.word(a + 4u * k + 4u);
+        const uint32_t cur = sh ? (w0 >> sh) | (next << (32u - sh)) : w0;
+        const uint64_t eq = zero_bytes(cur ^ ((cur << 8) | carry)), nl = zero_bytes(cur ^ 0x0A0A0A0Au);
+        carry = cur >> 24;
+        if (k < 16u) { s.eq.lo |= eq << (k * 4u); s.nl.lo |= nl << (k * 4u); }
+        else { s.eq.hi |= eq << ((k - 16u) * 4u); s.nl.hi |= nl << ((k - 16u) * 4u); }
+    }
+    if (lo == 0) s.eq.lo &= ~uint64_t(1);                            // byte 0 has no byte before it
+    if (L < 64u) { const uint64_t m = (uint64_t(1) << L) - 1u; s.eq.lo &= m; s.nl.lo &= m; s.eq.hi = s.nl.hi = 0; }
+    else if (L < 128u) { const uint64_t m = (uint64_t(1) << (L - 64u)) - 1u; s.eq.hi &= m; s.nl.hi &= m; }
+    return s;
+}
+
+FQD_HD bool bit_of(const Mask128& m, uint32_t p) { return ((p < 64u ? m.lo >> p : m.hi >> (p - 64u)) & 1u) != 0; }
+
+// Consecutive set bits from bit p on (p < 128).
+FQD_HD uint32_t run_from(const Mask128& m, uint32_t p)
+{
+    if (p >= 64u) { const uint64_t inv = ~(m.hi >> (p - 64u)); return inv ? uint32_t(__builtin_ctzll(inv)) : 64u; }
+    const uint64_t v = p ? (m.lo >> p) | (m.hi << (64u - p)) : m.lo;
+    const uint64_t inv = ~v;
+    if (inv) return uint32_t(__builtin_ctzll(inv));
+    const uint64_t inv2 = ~(p ? m.hi >> p : m.hi);                   // bits p + 64 and up
+    return 64u + (inv2 ? uint32_t(__builtin_ctzll(inv2)) : 64u);
+}
+
+// The column masks of the (at most two) ID lines that reach into [lo, hi): lines whose first byte is '@' or '>',
+// compared with the line lines_per_record lines up.  ls[j] = start of line j, n_lines = newlines in the member.
+template <class Data>
+FQD_HD Columns column_masks(const Data& data, uint32_t lo, uint32_t hi, const uint16_t* ls, uint32_t line, uint32_t n_lines,
+                            uint32_t member_len, bool lines_on, uint32_t lines_per_record)
+{
+    Columns c{{0, 0}, 0, 0, kChunk};
+    if (!lines_on || lo == hi) return c;
+    uint32_t found = 0, j = line;
+    for (uint32_t tries = 0; tries < 8u && found < 2u; ++tries, ++j) {
+        const uint32_t s = ls[j];
+        if (s >= hi) break;
+        const uint32_t e = j < n_lines ? uint32_t(ls[j + 1]) : member_len;
+        if (j >= lines_per_record && s < member_len) {
+            const uint32_t first = data[s], d = s - uint32_t(ls[j - lines_per_record]);
+            if ((first == uint32_t('@') || first == uint32_t('>')) && d <= 32768u) {
+                const uint32_t from = s > lo ? s : lo, to = e < hi ? e : hi;
+                for (uint32_t i = from; i < to; ++i) {
+                    const uint64_t same = data[i] == data[i - d] ? 1u : 0u;
+                    const uint32_t at = i - lo;
+                    if (at < 64u) c.same.lo |= same << at; else c.same.hi |= same << (at - 64u);
                 }
+                if (found == 0u) c.delta0 = d; else { c.delta1 = d; c.split = from - lo; }
+                ++found;
             }
         }
-        if (best) {
-            sink.match(best, dist);
-            p += best; prev = last;
-            if (newlines) { j += newlines; enter_line(); }
-        } else {
-            sink.literal(b);
-            prev = b; ++p;
-            if (b == uint32_t('\n')) { ++j; enter_line(); }
+        if (e >= hi) break;
+    }
+    return c;
+}
+
+// Greedy parse of [lo, hi) from the masks.  The sink sees every token in order.
+template <class Data, class Sink>
+FQD_HD void parse_chunk(const Data& data, uint32_t lo, uint32_t hi, const Scan& sc, const Columns& col, Sink& sink)
+{
+    const uint32_t L = hi - lo;
+    uint32_t p = 0;
+    while (p < L) {
+        const uint32_t room = L - p;                                 // <= 128 < kMaxMatch
+        uint32_t best = 0, dist = 0;
+        if (room >= kMinMatch) {
+            if (bit_of(sc.eq, p)) {                                  // the run goes on: distance 1
+                uint32_t r = run_from(sc.eq, p);
+                r = r < room ? r : room;
+                if (r >= kMinMatch) { best = r; dist = 1; }
+            }
+            if (bit_of(col.same, p) && best < room) {                // same column, one record up
+                uint32_t r = run_from(col.same, p);
+                r = r < room ? r : room;
+                const bool first = p < col.split;
+                if (first && r > col.split - p) r = col.split - p;   // a run never reaches into the next ID line's distance
+                if (r >= kMinMatch && r > best) { best = r; dist = first ? col.delta0 : col.delta1; }
+            }
         }
+        if (best) { sink.match(best, dist); p += best; }
+        else { sink.literal(data[lo + p]); ++p; }
     }
 }
 

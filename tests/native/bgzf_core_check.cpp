@@ -18,6 +18,7 @@ struct HostOr { void operator()(uint32_t* p, uint32_t v) const { *p |= v; } };
 struct Lines {
     std::vector<uint16_t> ls = std::vector<uint16_t>(kMaxLines + 2);
     uint32_t line_at[kThreads];
+    uint32_t n_lines = 0;
     bool on;
 };
 
@@ -27,15 +28,19 @@ static void index_lines(const uint8_t* data, uint32_t L, Lines& x)
     for (uint32_t t = 0; t < kThreads; ++t) {
         uint32_t lo, hi; chunk_of(t, L, lo, hi);
         x.line_at[t] = total;
-        for (uint32_t p = lo; p < hi; ++p) total += data[p] == '\n';
+        const Scan sc = scan_chunk(Linear{data}, lo, hi);
+        total += uint32_t(__builtin_popcountll(sc.nl.lo) + __builtin_popcountll(sc.nl.hi));
     }
+    x.n_lines = total;
     x.on = total <= kMaxLines;
     x.ls[0] = 0;
     if (!x.on) return;
     for (uint32_t t = 0; t < kThreads; ++t) {
         uint32_t lo, hi; chunk_of(t, L, lo, hi);
+        const Scan sc = scan_chunk(Linear{data}, lo, hi);
         uint32_t k = x.line_at[t] + 1;
-        for (uint32_t p = lo; p < hi; ++p) if (data[p] == '\n') x.ls[k++] = uint16_t(p + 1);
+        for (uint64_t m = sc.nl.lo; m; m &= m - 1) x.ls[k++] = uint16_t(lo + uint32_t(__builtin_ctzll(m)) + 1);
+        for (uint64_t m = sc.nl.hi; m; m &= m - 1) x.ls[k++] = uint16_t(lo + 64 + uint32_t(__builtin_ctzll(m)) + 1);
     }
 }
 
@@ -62,7 +67,9 @@ int main(int argc, char** argv)
         for (uint32_t t = 0; t < kThreads; ++t) {
             uint32_t lo, hi; chunk_of(t, L, lo, hi);
             Counter c{hist.data()};
-            parse_chunk(Linear{data}, lo, hi, x.ls.data(), x.line_at[t], x.on, K, c);
+            const Scan sc = scan_chunk(Linear{data}, lo, hi);
+            const Columns col = column_masks(Linear{data}, lo, hi, x.ls.data(), x.line_at[t], x.n_lines, L, x.on, K);
+            parse_chunk(Linear{data}, lo, hi, sc, col, c);
         }
     }
     static Codes codes;
@@ -79,7 +86,9 @@ int main(int argc, char** argv)
         for (uint32_t t = 0; t < kThreads; ++t) {
             uint32_t lo, hi; chunk_of(t, L, lo, hi);
             BitCounter price{codes.lit, codes.dist};
-            parse_chunk(Linear{data}, lo, hi, x.ls.data(), x.line_at[t], x.on, K, price);
+            const Scan sc = scan_chunk(Linear{data}, lo, hi);
+            const Columns col = column_masks(Linear{data}, lo, hi, x.ls.data(), x.line_at[t], x.n_lines, L, x.on, K);
+            parse_chunk(Linear{data}, lo, hi, sc, col, price);
             bits[t] = price.bits; before[t] = body; body += bits[t];
         }
         const uint32_t total_bits = codes.header_bits + body + (codes.lit[256] >> 16);
@@ -97,7 +106,9 @@ int main(int argc, char** argv)
                         w.put(codes.header_bits - at >= 32 ? codes.header[at >> 5] : codes.header[at >> 5] & ((1u << (codes.header_bits - at)) - 1u),
                               codes.header_bits - at >= 32 ? 32 : codes.header_bits - at);
                 Emitter<HostOr> emit{codes.lit, codes.dist, w};
-                parse_chunk(Linear{data}, lo, hi, x.ls.data(), x.line_at[t], x.on, K, emit);
+                const Scan sc = scan_chunk(Linear{data}, lo, hi);
+                const Columns col = column_masks(Linear{data}, lo, hi, x.ls.data(), x.line_at[t], x.n_lines, L, x.on, K);
+                parse_chunk(Linear{data}, lo, hi, sc, col, emit);
                 if (t == kThreads - 1) w.put(codes.lit[256] & 0xFFFFu, codes.lit[256] >> 16);
                 w.finish();
             } else {

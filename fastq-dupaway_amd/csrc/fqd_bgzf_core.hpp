@@ -101,6 +101,11 @@ struct Skewed {
     FQD_HD uint8_t operator[](uint32_t p) const { return base[at(p)]; }
     FQD_HD uint32_t word(uint32_t p) const { return *reinterpret_cast<const uint32_t*>(base + at(p)); }   // p a multiple of 4
 };
+struct Aligned {                                       // plain bytes at a 4-byte aligned base
+    const uint8_t* base;
+    FQD_HD uint8_t operator[](uint32_t p) const { return base[p]; }
+    FQD_HD uint32_t word(uint32_t p) const { return *reinterpret_cast<const uint32_t*>(base + p); }      // p a multiple of 4
+};
 struct Linear {
     const uint8_t* base;
     FQD_HD uint8_t operator[](uint32_t p) const { return base[p]; }
@@ -280,7 +285,16 @@ template <class Data>
 FQD_HD uint32_t crc_chunk(const uint32_t* table, const Data& data, uint32_t lo, uint32_t hi)
 {
     uint32_t reg = (lo == 0u && hi > 0u) ? 0xFFFFFFFFu : 0u;       // the chunk holding byte 0 carries the preset
-    for (uint32_t p = lo; p < hi; ++p) reg = table[(reg ^ data[p]) & 0xFFu] ^ (reg >> 8);
+    uint32_t p = lo;
+    for (; p < hi && (p & 3u); ++p) reg = table[(reg ^ data[p]) & 0xFFu] ^ (reg >> 8);
+    for (; p + 4u <= hi; p += 4u) {                                 // one read of the text per four bytes
+        reg ^= data.word(p);
+        reg = table[reg & 0xFFu] ^ (reg >> 8);
+        reg = table[reg & 0xFFu] ^ (reg >> 8);
+        reg = table[reg & 0xFFu] ^ (reg >> 8);
+        reg = table[reg & 0xFFu] ^ (reg >> 8);
+    }
+    for (; p < hi; ++p) reg = table[(reg ^ data[p]) & 0xFFu] ^ (reg >> 8);
     return reg;
 }
 

@@ -89,7 +89,7 @@ void bgzf_check_crc_kernel(const uint8_t* __restrict__ text, const uint64_t* __r
         __syncthreads();
         uint32_t lo, hi;
         chunk_of(t, L, lo, hi);
-        crc[t] = crc_chunk(table, Linear{data}, lo, hi);
+        crc[t] = crc_chunk(table, Aligned{data}, lo, hi);
         __syncthreads();
         for (uint32_t k = 0; k < kLevels; ++k) {
             if ((t & ((2u << k) - 1u)) == 0u) crc[t] = crc_advance(tabs->shift[k], crc[t]) ^ crc[t + (1u << k)];

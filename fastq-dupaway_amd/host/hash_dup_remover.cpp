@@ -49,6 +49,10 @@ namespace {
         throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
 // RAII over the C ABI
+// Set by a resident run of the CLI after its outputs are closed (Tuning::leave_memory_to_exit): from then on
+// buffers are not freed one by one — the process is about to end and the driver releases everything at once.
+static std::atomic<bool> g_leave_memory_to_exit{false};
+
 struct EngineHandle {
     fqd_engine* e = nullptr;
     EngineHandle(int segments, int device, hipStream_t stream)
@@ -58,7 +62,7 @@ struct EngineHandle {
         const int rc = fqd_engine_create(&cfg, &e);
         if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(nullptr));
     }
-    ~EngineHandle() { fqd_engine_destroy(e); }
+    ~EngineHandle() { if (!g_leave_memory_to_exit) fqd_engine_destroy(e); }
 };
 
 // The reference's two lines for a byte outside {A,C,G,T,N} (seq_utils.cpp:17-19).
@@ -71,7 +75,7 @@ struct EngineHandle {
 template <class T>
 struct Pinned {
     T* p = nullptr; size_t cap = 0;
-    ~Pinned() { if (p) (void)hipHostFree(p); }
+    ~Pinned() { if (p && !g_leave_memory_to_exit) (void)hipHostFree(p); }
     void reserve(size_t n)
     {
         if (n <= cap) return;
@@ -85,7 +89,7 @@ struct Pinned {
 template <class T>
 struct Device {
     T* p = nullptr; size_t cap = 0;
-    ~Device() { if (p) (void)hipFree(p); }
+    ~Device() { if (p && !g_leave_memory_to_exit) (void)hipFree(p); }
     void reserve(size_t n)
     {
         if (n <= cap) return;
@@ -732,7 +736,7 @@ struct DeviceOutOfMemory : std::runtime_error { using std::runtime_error::runtim
 template <class T>
 struct GrowDevice {
     T* p = nullptr; size_t cap = 0, used = 0;
-    ~GrowDevice() { if (p) (void)hipFree(p); }
+    ~GrowDevice() { if (p && !g_leave_memory_to_exit) (void)hipFree(p); }
     void room_for(size_t more, hipStream_t s)
     {
         if (used + more <= cap) return;
@@ -1238,6 +1242,7 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
         const uint32_t* idx[2] = {nullptr, nullptr};
         write_survivors(eng->e, stream, S, files, idx, keep.p, n, dups, sinks, format_, memlimit_);
     }
+    if (tuning_.leave_memory_to_exit) g_leave_memory_to_exit = true;
     StageClock::report();
     summary_.total = n; summary_.duplicates = dups; summary_.unmatched = 0;
     if (verbose_) {
@@ -1366,6 +1371,7 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
         const uint32_t* idx[2] = {jp.pair[0].p, jp.pair[1].p};
         write_survivors(eng.e, stream, 2, files, idx, jp.keep.p, upto, dups, sinks, format_, memlimit_);
     }
+    if (tuning_.leave_memory_to_exit) g_leave_memory_to_exit = true;
     StageClock::report();
     if (jp.bad) throw_unknown_base(jp.bad_byte);
     summary_.total = n_proc; summary_.duplicates = dups; summary_.unmatched = jp.unmatched;

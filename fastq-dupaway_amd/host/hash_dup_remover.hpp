@@ -46,6 +46,9 @@ struct Tuning {
     // peer copies instead of RCCL.
     std::vector<int> devices;
     bool   use_rccl = true;
+    // The process ends right after the run (the CLI): once the outputs of a resident run are closed, its tens of
+    // gigabytes of HBM and pinned memory are left to process exit instead of being unmapped buffer by buffer.
+    bool   leave_memory_to_exit = false;
 };
 
 class HashDupRemover {

@@ -226,6 +226,7 @@ int main(int argc, char** argv)                                // main.cpp:181-2
         if (const char* x = std::getenv("FQD_EXCHANGE")) tune.use_rccl = std::string(x) != "copy";
         if (const char* j = std::getenv("FQD_FULL_JOIN")) tune.reference_tail_rule = !(j[0] == '1');
         if (const char* b = std::getenv("FQD_BLOCK_MB")) { const long mb = std::atol(b); if (mb > 0) tune.block_bytes = static_cast<size_t>(mb) << 20; }
+        tune.leave_memory_to_exit = std::getenv("FQD_FREE_AT_END") == nullptr;   // the process ends after this run
         fqdhost::TemporaryDirectory tempdir;                   // main.cpp:192 (created lazily here)
         const fqdhost::Format fmt = (opts.mode & FASTA) ? fqdhost::Format::Fasta : fqdhost::Format::Fastq;
         fqdhost::HashDupRemover remover(fmt, opts.memLimit, &tempdir, opts.verbose, tune);   // main.cpp:218-242

@@ -100,3 +100,16 @@ def test_damaged_bgzf_is_reported(io, tmp_path):
     (tmp_path / "flip.fq.gz").write_bytes(raw)
     _, err = io("r", tmp_path / "flip.fq.gz", 1 << 20, 4, ok=False)
     assert "corrupt or truncated" in err
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_finished_members_are_passed_through(build, tmp_path, threads):
+    """write_members (what the device deflater's output goes through): bytes land after what write() still held and
+    before what comes later, whether copied by one thread or through the parallel mapping (>= 8 MB per call)."""
+    run = runner("auto")
+    src, out = tmp_path / "members.fq.gz", tmp_path / "out.fq.gz"
+    (length, h), _ = run("w", src, 60_000_000, 9)              # ~20 MB of members
+    body = gzip.open(src, "rb").read()
+    run("m", src, out, threads)
+    assert subprocess.run(["gzip", "-t", str(out)]).returncode == 0
+    assert gzip.open(out, "rb").read() == b"@before\n" + body + b"@after\n"

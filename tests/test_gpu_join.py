@@ -293,6 +293,15 @@ def test_device_halves_of_the_streaming_run():
         exp_win = np.concatenate([text[int(rec_start[idx[k]]):int(rec_start[idx[k]]) + int(sizes[idx[k]])] for k in range(a, b) if keep[k]])
         assert np.array_equal(d_win.cpu().numpy()[: hi - lo], exp_win)
 
+        # no index list: pair k is record k (the ordered run's plan)
+        m = min(n_pairs, n_rec)
+        tot3 = e.output_plan(d_keep, None, m, d_start, d_sz, d_src, d_len, d_dst)
+        kept3 = np.where(keep[:m] == 1, sizes[:m], 0).astype(np.int64)
+        assert tot3 == int(kept3.sum())
+        assert np.array_equal(d_src.cpu().numpy().view(np.uint64)[:m], rec_start[:m])
+        assert np.array_equal(d_len.cpu().numpy().view(np.uint32)[:m], kept3.astype(np.uint32))
+        assert np.array_equal(d_dst.cpu().numpy()[:m], np.concatenate([[0], np.cumsum(kept3)[:-1]]))
+
 
 def test_join_fuzz_small_cases_against_the_oracle(oracle):
     """Many small joins — tags drawn from tiny alphabets so that repeats, prefixes of each other, empty tags

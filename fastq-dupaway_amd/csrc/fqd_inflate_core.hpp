@@ -65,12 +65,12 @@ struct PackedTables {
     FQD_HD static uint32_t base_row(uint32_t i) { return i < kDistCount ? i : 16u + (i - kDistCount); }
     FQD_HD uint16_t base_get(uint32_t i) const { return base16[base_row(i) * Stride]; }
     FQD_HD void base_set(uint32_t i, uint16_t v) { base16[base_row(i) * Stride] = v; }
-    FQD_HD uint32_t sym_get(uint32_t i) const
+    FQD_HD uint32_t lit_sym(uint32_t j) const         // j-th literal/length symbol in code order
     {
-        if (i >= kDistSymbol) return dist[(i - kDistSymbol) * Stride];
-        const uint32_t j = i - kLitSymbol;
         return uint32_t(lit_lo[j * Stride]) | (((uint32_t(lit_hi[(j >> 3) * Stride]) >> (j & 7u)) & 1u) << 8);
     }
+    FQD_HD uint32_t dist_sym(uint32_t j) const { return dist[j * Stride]; }
+    FQD_HD uint32_t sym_get(uint32_t i) const { return i >= kDistSymbol ? dist_sym(i - kDistSymbol) : lit_sym(i - kLitSymbol); }
     FQD_HD void sym_set(uint32_t i, uint32_t v)
     {
         if (i >= kDistSymbol) { dist[(i - kDistSymbol) * Stride] = uint8_t(v); return; }
@@ -155,7 +155,7 @@ FQD_HD uint32_t decode_symbol(BitReader& in, const Tables& t, const Code& c, uin
     if (w >= c.lim[kMaxBits - 1]) return 0xFFFFu;                     // no code starts like this
     const uint32_t index = uint32_t(int32_t(int16_t(t.base_get(base_at + len))) + int32_t(w >> (kMaxBits - len)));
     in.buf >>= len; in.cnt -= len;
-    return t.sym_get(symbol_at + index);
+    return symbol_at == kLitSymbol ? t.lit_sym(index) : t.dist_sym(index);   // (a constant at every call site)
 }
 
 // Tables and comparison limits from code lengths len(0..n-1) (0 = symbol unused).  Returns false for an

@@ -98,9 +98,10 @@ struct BitReader {
 
     FQD_HD BitReader(const uint8_t* p, uint32_t nbytes)
     {
-        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-        words = reinterpret_cast<const uint32_t*>(a & ~uintptr_t(3));
-        const uint32_t skip = uint32_t(a & 3u);
+        // (stepping back from p, not rebuilding the pointer from an integer: the compiler then still knows that it
+        //  points to global memory and its loads do not share a wait counter with the LDS reads)
+        const uint32_t skip = uint32_t(reinterpret_cast<uintptr_t>(p) & 3u);
+        words = reinterpret_cast<const uint32_t*>(p - skip);
         end_word = (skip + nbytes + 3u) / 4u;
         ahead = end_word ? words[0] : 0u;
         fill();

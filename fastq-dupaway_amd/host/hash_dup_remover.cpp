@@ -1015,6 +1015,8 @@ static bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, 
     return at == size && member == size && c.text_bytes > 0;
 }
 
+static bool records_on_device(fqd_engine* e, hipStream_t stream, Format format, uint64_t text_bytes, FileOnDevice& f);
+
 // The GPU's share of a file that arrived compressed: inflate, count lines, cut into records.  false: a damaged
 // member, or text that is not whole records — the caller reads the file the host way, which says what is wrong.
 static bool finish_on_device(fqd_engine* e, hipStream_t stream, Format format, CompressedOnDevice& c, FileOnDevice& f)
@@ -1037,6 +1039,14 @@ static bool finish_on_device(fqd_engine* e, hipStream_t stream, Format format, C
     }
     { StageClock::Scope t("  on the GPU: compressed bytes freed"); c.bytes.release(); }
     if (bad) return false;
+    return records_on_device(e, stream, format, c.text_bytes, f);
+}
+
+// The text of a file is in HBM (f.text, text_bytes of it): cut it into records there.  false: not whole records.
+static bool records_on_device(fqd_engine* e, hipStream_t stream, Format format, uint64_t text_bytes, FileOnDevice& f)
+{
+    auto engine_ok = [&](int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(e)); };
+    struct { uint64_t text_bytes; } c{text_bytes};
     const uint32_t lines_per_record = format == Format::Fastq ? 4u : 2u;
     uint64_t lines = 0;
     { StageClock::Scope t("  on the GPU: line count"); engine_ok(fqd_count_lines(e, reinterpret_cast<const uint8_t*>(f.text.p), c.text_bytes, &lines)); }
@@ -1171,8 +1181,35 @@ static void write_survivors(fqd_engine* e, hipStream_t stream, int S, FileOnDevi
     for (int s = 0; s < S; ++s) { if (o[s].error) std::rethrow_exception(o[s].error); sinks[s]->close(); }
 }
 
-// An ordered run (single-end, or paired files read side by side) whose inputs are BGZF: the files go to HBM
-// compressed, are inflated and cut into records there, every read (pair) is deduplicated where it lies, and the
+// A plain regular file as it is to the tail of f.text (a pinned block, parallel preads, H2D); false: not such a file.
+static bool fetch_plain(const std::string& name, size_t block_bytes, int device, FileOnDevice& f, uint64_t& text_bytes)
+{
+    uint64_t size = 0;
+    if (has_gz_extension(name) || !is_regular_file(name, size) || size == 0) return false;
+    InputFile file(name, true);
+    HIP_OK(hipSetDevice(device));
+    hipStream_t up = nullptr;
+    HIP_OK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    struct Guard { hipStream_t s; ~Guard() { (void)hipStreamDestroy(s); } } g{up};
+    Pinned<char> block[2];
+    block[0].reserve(block_bytes); block[1].reserve(block_bytes);
+    f.text.room_for(size + 64, up);
+    uint64_t at = 0;
+    for (int k = 0;; k ^= 1) {                                   // the copy of one block overlaps the read of the next
+        const size_t got = file.read(block[k].p, block_bytes, host_threads());
+        HIP_OK(hipStreamSynchronize(up));                          // the other block's copy
+        if (got == 0) break;
+        if (at + got > size) return false;                         // the file grew under us
+        HIP_OK(hipMemcpyAsync(f.text.p + at, block[k].p, got, hipMemcpyHostToDevice, up));
+        at += got;
+    }
+    text_bytes = at;
+    return at == size;
+}
+
+// An ordered run (single-end, or paired files read side by side) with a codec at either end — BGZF inputs, or `.gz`
+// outputs of plain regular inputs: the files go to HBM as they lie on disk, are inflated (if compressed) and cut into
+// records there, every read (pair) is deduplicated where it lies, and the
 // survivors leave in input order window by window (deflated on the device for `.gz` outputs).  Taken only when
 // everything is plain sailing — regular BGZF files of whole records, as many in file 2 as in file 1, no unknown
 // base, everything fits in HBM; otherwise false is returned BEFORE any output is touched and the streaming run
@@ -1181,7 +1218,16 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
 {
     if (const char* v = std::getenv("FQD_ORDERED_RESIDENT")) if (std::atoi(v) == 0) return false;
     if (!inflate_on_device()) return false;
-    for (int s = 0; s < S; ++s) { uint64_t size = 0; if (!has_gz_extension(in[s]) || !is_regular_file(in[s], size)) return false; }
+    // worth it when a codec is involved: a BGZF input, or a `.gz` output the GPU can deflate (plain files in and
+    // out are better off in the streaming run, where reading, the GPU and writing overlap)
+    bool any_gz_in = false, any_gz_out = false;
+    for (int s = 0; s < S; ++s) {
+        uint64_t size = 0;
+        if (!is_regular_file(in[s], size)) return false;
+        any_gz_in |= has_gz_extension(in[s]);
+        any_gz_out |= has_gz_extension(out[s]);
+    }
+    if (!any_gz_in && !(any_gz_out && deflate_on_device())) return false;
     HIP_OK(hipSetDevice(tuning_.device));
     hipStream_t stream = nullptr;
     HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -1194,9 +1240,16 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
     try {
         CompressedOnDevice packed[2];
         bool fetched[2] = {false, false};
+        uint64_t plain_bytes[2] = {0, 0};
         {
             StageClock::Scope t("ordered/resident: files to HBM");
-            auto fetch = [&](int s) { try { fetched[s] = fetch_bgzf(in[s], block_bytes, tuning_.device, packed[s]); } catch (const std::exception&) { fetched[s] = false; } };
+            auto fetch = [&](int s) {
+                try {
+                    fetched[s] = has_gz_extension(in[s]) ? fetch_bgzf(in[s], block_bytes, tuning_.device, packed[s])
+                                                         : fetch_plain(in[s], block_bytes, tuning_.device, dev[s], plain_bytes[s]);
+                } catch (const DeviceOutOfMemory&) { fetched[s] = false; }
+                catch (const std::exception&) { fetched[s] = false; }
+            };
             std::thread second;
             if (S == 2) second = std::thread(fetch, 1);
             fetch(0);
@@ -1206,7 +1259,11 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
         eng = std::make_unique<EngineHandle>(S, tuning_.device, stream);
         {
             StageClock::Scope t("ordered/resident: inflate + record scan on the GPU");
-            for (int s = 0; s < S; ++s) if (!finish_on_device(eng->e, stream, format_, packed[s], dev[s])) return false;
+            for (int s = 0; s < S; ++s) {
+                const bool ok = has_gz_extension(in[s]) ? finish_on_device(eng->e, stream, format_, packed[s], dev[s])
+                                                        : records_on_device(eng->e, stream, format_, plain_bytes[s], dev[s]);
+                if (!ok) return false;
+            }
         }
         if (S == 2 && dev[0].n != dev[1].n) return false;
         n = dev[0].n;

@@ -497,7 +497,7 @@ def test_unordered_bgzf_inputs_inflated_on_the_device(exe, oracle, tmp_path, cas
 @pytest.mark.gpu
 @pytest.mark.parametrize("paired", [False, True])
 @pytest.mark.parametrize("case", ["fastq_to_gz", "fastq_to_plain", "fasta", "small_windows", "bad_base", "bad_record", "uneven_pairs",
-                                  "flipped_bit", "plain_gzip"])
+                                  "flipped_bit", "plain_gzip", "plain_in_gz_out", "plain_in_gz_out_no_final_newline"])
 def test_ordered_runs_on_bgzf_inputs_stay_on_the_device(exe, oracle, tmp_path, case, paired):
     """SE / ordered PE with BGZF inputs: files to HBM compressed, inflate + record scan + dedup there, survivors out in
     input order (run_ordered_resident).  Irregular inputs are left to the streaming run untouched.  Either way the
@@ -520,7 +520,10 @@ def test_ordered_runs_on_bgzf_inputs_stay_on_the_device(exe, oracle, tmp_path, c
     if case == "bad_record":
         cut = t[0].index(b"\n@", len(t[0]) // 2) + 1
         t[0] = t[0][:cut] + b"y" + t[0][cut + 1:]
-    z = [bgzf(x, level=1) for x in t]
+    plain_in = case.startswith("plain_in")
+    if case == "plain_in_gz_out_no_final_newline":
+        t[0] = t[0][:-1]
+    z = list(t) if plain_in else [bgzf(x, level=1) for x in t]
     if case == "flipped_bit":
         b = bytearray(z[0]); b[len(b) // 2] ^= 4; z[0] = bytes(b)
     if case == "plain_gzip":
@@ -528,7 +531,7 @@ def test_ordered_runs_on_bgzf_inputs_stay_on_the_device(exe, oracle, tmp_path, c
     S = 2 if paired else 1
     ext = "fa" if fasta else "fq"
     oext = ext if case == "fastq_to_plain" else ext + ".gz"
-    ins = [tmp_path / f"r{s + 1}.{ext}.gz" for s in range(S)]
+    ins = [tmp_path / (f"r{s + 1}.{ext}" + ("" if plain_in else ".gz")) for s in range(S)]
     for s in range(S):
         ins[s].write_bytes(z[s])
     fmt = ["--format", "fasta"] if fasta else []
@@ -547,12 +550,13 @@ def test_ordered_runs_on_bgzf_inputs_stay_on_the_device(exe, oracle, tmp_path, c
                 return None
             return gzip.open(p, "rb").read() if str(p).endswith(".gz") else p.read_bytes()
         runs[resident] = (r.returncode, r.stdout, said, [content(p) for p in outs])
-        good = case in ("fastq_to_gz", "fastq_to_plain", "fasta", "small_windows") or (case == "uneven_pairs" and not paired)
+        good = case in ("fastq_to_gz", "fastq_to_plain", "fasta", "small_windows", "plain_in_gz_out") or (case == "uneven_pairs" and not paired)
         if r.returncode == 0:
             assert ("ordered/resident: survivors out of HBM" in r.stderr) == (resident == "1" and good), r.stderr
     assert runs["1"] == runs["0"]
     rc, out, said, got = runs["1"]
-    if case in ("fastq_to_gz", "fastq_to_plain", "fasta", "small_windows", "uneven_pairs", "plain_gzip"):
+    if case in ("fastq_to_gz", "fastq_to_plain", "fasta", "small_windows", "uneven_pairs", "plain_gzip", "plain_in_gz_out",
+                "plain_in_gz_out_no_final_newline"):
         ps = [tmp_path / f"p{s + 1}.{ext}" for s in range(S)]
         es = [tmp_path / f"e{s + 1}.{ext}" for s in range(S)]
         for s in range(S):

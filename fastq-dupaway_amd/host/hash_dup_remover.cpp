@@ -1370,20 +1370,28 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
         };
         CompressedOnDevice packed[2];
         bool on_device[2] = {false, false};
+        bool plain_on_device[2] = {false, false};              // a plain regular file: copied to HBM as it is, cut into records there
+        uint64_t plain_bytes[2] = {0, 0};
         auto fetch_or_load = [&](int s) {
             if (inflate_on_device()) {
-                try { on_device[s] = fetch_bgzf(in[s], block_bytes, tuning_.device, packed[s]); }
-                catch (const std::exception&) { on_device[s] = false; }               // the host way will say what is wrong
+                try {
+                    if (has_gz_extension(in[s])) on_device[s] = fetch_bgzf(in[s], block_bytes, tuning_.device, packed[s]);
+                    else plain_on_device[s] = fetch_plain(in[s], block_bytes, tuning_.device, dev[s], plain_bytes[s]);
+                }
+                catch (const DeviceOutOfMemory&) { err[s] = std::current_exception(); return; }   // rethrown below: the two-pass run takes over
+                catch (const std::exception&) { on_device[s] = plain_on_device[s] = false; }          // the host way will say what is wrong
             }
-            if (!on_device[s]) { packed[s] = CompressedOnDevice(); load(s); }
+            if (!on_device[s] && !plain_on_device[s]) { packed[s] = CompressedOnDevice(); dev[s].forget(); load(s); }
         };
         std::thread second(fetch_or_load, 1);
         fetch_or_load(0);
         second.join();
         for (int s = 0; s < 2; ++s) {
-            if (!on_device[s]) continue;
+            if (!on_device[s] && !plain_on_device[s]) continue;
             StageClock::Scope t2("unordered/resident: inflate + record scan on the GPU");
-            if (!finish_on_device(eng.e, stream, format_, packed[s], dev[s])) {         // read it again the host way: that one reports
+            const bool ok = on_device[s] ? finish_on_device(eng.e, stream, format_, packed[s], dev[s])
+                                         : records_on_device(eng.e, stream, format_, plain_bytes[s], dev[s]);
+            if (!ok) {                                                                  // read it again the host way: that one reports
                 dev[s].forget();
                 packed[s] = CompressedOnDevice();
                 load(s);

@@ -1285,7 +1285,9 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
         fqd_stats st{};
         fqd_get_stats(eng->e, &st);
         dups = st.duplicates;
-    } catch (const DeviceOutOfMemory&) {
+    } catch (const std::exception&) {
+        // HBM that does not suffice, a device error: nothing has been written yet, so the streaming run — which needs
+        // a few blocks of HBM only, and reports what is really wrong — takes over
         return false;
     }
     // from here on the run is this one's: outputs are created, filled and closed

@@ -45,8 +45,8 @@ TemporaryDirectory::~TemporaryDirectory()
 namespace {
 
 #define HIP_OK(expr)                                                                        \
-    do { hipError_t e_ = (expr); if (e_ != hipSuccess)                                      \
-        throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError();           /* not sticky: a fallback may follow */ \
+        throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
 
 // RAII over the C ABI
 // Set by a resident run of the CLI after its outputs are closed (Tuning::leave_memory_to_exit): from then on

@@ -11,9 +11,10 @@ resident in HBM: empty the set, encode + insert every read, produce keep flags.
           prefix with an all-to-all over RCCL (fastq-dupaway_amd/sharded.py).
   --config se|pe|sharded1 : only that device-phase measurement (sharded1 = the N > 1 path
           rehearsed on one rank under RCCL).
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under
-python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-Prints ONE JSON line on rank 0.
+Launch: python bench.py [--gpus N --steps K --warmup W].  With N > 1 and no launcher around it the script
+starts its own N ranks (child processes under torch.distributed.run, before any GPU call) and relays rank 0's
+line; started under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it is one
+of those ranks.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -426,8 +427,72 @@ def end_to_end_unordered(a, torch, bases, L):
     return res
 
 
+def launch_command(gpus, argv, port):
+    """The command `python bench.py --gpus N` (N > 1) turns itself into: one rank per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+
+
+def rank0_line(stdout_text):
+    """The ONE JSON line rank 0 printed, picked out of whatever else the ranks wrote to stdout."""
+    for line in reversed(stdout_text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                rec = json.loads(line)
+            except ValueError:
+                continue
+            if "metric" in rec and "value" in rec:
+                return line
+    return None
+
+
+def relaunch_as_ranks(a):
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as CHILD processes — before this
+    process has imported torch or made any GPU call (a process that has initialised the GPU must never exec
+    or be replaced) — and relay rank 0's JSON line and the children's exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = launch_command(a.gpus, sys.argv[1:], port)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = rank0_line(r.stdout)
+    if line is None:
+        sys.stdout.write(r.stdout)
+        sys.exit(r.returncode if r.returncode else 1)
+    print(line, flush=True)
+    sys.exit(r.returncode)
+
+
+def selftest_ranks(a):
+    """FQD_BENCH_SELFTEST=1: the launch path without a GPU — every rank joins a gloo group, the ranks agree on
+    their number, rank 0 prints a line of the bench's shape.  tests/test_bench_launch.py runs this on the CPU."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    dist.init_process_group("gloo")
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    print(f"rank {rank} chatter on stdout {{not json}}", flush=True)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "selftest", "value": 0.0, "unit": "Mreads/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ranks_seen": int(t.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_as_ranks(a)                                   # never returns
+    if os.environ.get("FQD_BENCH_SELFTEST") == "1":
+        return selftest_ranks(a)
     import torch
     import fastq_dupaway_amd as fqd  # noqa: F401  (loads the HIP library or fails loudly)
 
@@ -435,8 +500,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        sys.exit(f"bench.py --gpus {a.gpus} was started with WORLD_SIZE={world}: the two must agree")
     torch.cuda.set_device(local)
     dist = None
     config = "pe" if a.paired else a.config

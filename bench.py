@@ -38,8 +38,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=["all", "se", "pe", "sharded1"], default="all",
-                    help="all (default, N=1): headline configs[1] + pe + pcie_inclusive + end_to_end")
+    ap.add_argument("--config", choices=["all", "se", "pe", "sharded1", "virtual"], default="all",
+                    help="all (default, N=1): headline configs[1] + pe + pcie_inclusive + end_to_end; sharded1: the N > 1 path on one rank under RCCL; "
+                         "virtual: --virtual-ranks ranks of the N > 1 path sharing this one GPU (peer copies)")
+    ap.add_argument("--virtual-ranks", type=int, default=4)
+    ap.add_argument("--round-reads", type=int, default=0, help="reads a rank brings to one round of the sharded exchange (0: 16 Mi, or all of them if fewer)")
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads (pairs) per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--paired", action="store_true", help="same as --config pe")
@@ -96,50 +99,56 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
     expect = torch.empty(n, dtype=torch.uint8, device=dev)
     keep = torch.empty(n, dtype=torch.uint8, device=dev)
 
-    eng = Engine(segments=S, device=local, capacity_reads=n, capacity_bases=S * n * L, profile=True)
-    # Sharded runs move a step's reads in rounds; ShardedDedup itself slices every exchange so that no
-    # rank-to-rank message exceeds its cap (RCCL 2.26.6 / torch 2.10 deliver only the first half of a
-    # message above 1 GiB: tools/a2a_probe.py, profiles/r02_a2a_probe.jsonl), the rounds here only give
-    # the pipeline something to overlap.  The job's input order is (round, rank, position) — file blocks
-    # dealt round-robin to the ranks — so round k of rank r holds the global indices below.
-    rec_bytes = 8 * (eng.key_words(L, L if S == 2 else 0) + (1 if os.environ.get("FQD_SHARDED_WITH_HASH") == "1" else 0))
-    lazy = sharded_mode and os.environ.get("FQD_SHARDED_LAZY") == "1"       # hashes first, keys only for candidates
-    if lazy:
-        rec_bytes = 16
-    rounds = max(1, -(-(n * rec_bytes // world) // (256 << 20))) if sharded_mode else 1
-    if sharded_mode and os.environ.get("FQD_BENCH_ROUNDS"):
-        rounds = int(os.environ["FQD_BENCH_ROUNDS"])
-    m = -(-n // rounds)
-    spans = [(k * m, min(m, n - k * m)) for k in range(rounds)]
-    for k, (lo, cnt) in enumerate(spans):
-        first = (k * world * m + rank * cnt) if sharded_mode else 0
-        for mate in range(S):
-            eng.synth_reads(a.seed, first, cnt, L, a.dup_permille, mate, bases[mate][lo * L:],
-                            expect[lo:] if mate == S - 1 else None)
+    # Sharded runs (fastq-dupaway_amd/shard.py over csrc/fqd_shard.hip): a step's reads go through the exchange in
+    # rounds of `m` reads per rank; the job's input order is (round, rank, position) — file blocks dealt round-robin
+    # to the ranks — so round k of rank r holds the global indices below.  `virtual`: V ranks share this GPU.
+    V = a.virtual_ranks if sharded_mode == "virtual" else 1
+    ranks_here = V if sharded_mode == "virtual" else 1
+    job_world = V if sharded_mode == "virtual" else world
+    n_rank = n // V if sharded_mode == "virtual" else n            # reads per rank and step
+    m = min(n_rank, a.round_reads or (16 << 20)) if sharded_mode else n
+    rounds = -(-n_rank // m) if sharded_mode else 1
+    spans = [(k * m, min(m, n_rank - k * m)) for k in range(rounds)]
+    if sharded_mode:
+        from fastq_dupaway_amd._lib import load_library
+        cap = int(load_library().fqd_shard_slab_capacity(m, job_world, 0))
+        own_reads = rounds * job_world * cap + 4096               # slab slots an owner takes in per step, unused ones included
+    engines = [Engine(segments=S, device=local, capacity_reads=own_reads if sharded_mode else n,
+                      capacity_bases=S * (own_reads if sharded_mode else n) * L, profile=True) for _ in range(ranks_here)]
+    eng = engines[0]
+    for v in range(ranks_here):
+        for k, (lo, cnt) in enumerate(spans):
+            r = v if sharded_mode == "virtual" else rank
+            first = (k * job_world * m + r * cnt) if sharded_mode else 0
+            at = v * n_rank + lo
+            for mate in range(S):
+                eng.synth_reads(a.seed, first, cnt, L, a.dup_permille, mate, bases[mate][at * L:],
+                                expect[at:] if mate == S - 1 else None)
     eng.sync()
     segs = [Reads(bases[mate], uniform_len=L, uniform_stride=L) for mate in range(S)]
 
     sharded = None
-    if lazy:
-        from fastq_dupaway_amd.sharded import LazyShardedDedup
-        owner = Engine(segments=1, device=local, capacity_reads=int(n * 1.1))
-        sharded = LazyShardedDedup(eng, owner, dist, dev, n_max=m, len0=L, len1=(L if S == 2 else 0))
+    if sharded_mode:
+        from fastq_dupaway_amd.shard import ShardGroup, unique_id
+        uid = None
+        if sharded_mode != "virtual":
+            box = [unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)            # control plane only; the keys travel over the library's own RCCL communicator
+            uid = box[0]
+        sharded = ShardGroup(engines, world=job_world, first_rank=0 if sharded_mode == "virtual" else rank, round_reads=m,
+                             len0=L, len1=(L if S == 2 else 0), transport="copy" if sharded_mode == "virtual" else "rccl", uid=uid)
+        round_args = []
+        for lo, cnt in spans:
+            sg = [[Reads(bases[mate][(v * n_rank + lo) * L:], uniform_len=L, uniform_stride=L) for mate in range(S)] for v in range(ranks_here)]
+            round_args.append((sg, [cnt] * ranks_here, [keep[v * n_rank + lo:] for v in range(ranks_here)]))
 
         def step():
-            eng.reset(); owner.reset(); sharded.reset()
-            for lo, cnt in spans:
-                sharded.dedup([Reads(bases[mate][lo * L:], uniform_len=L, uniform_stride=L) for mate in range(S)], cnt, keep[lo:])
-            eng.sync()
-    elif sharded_mode:
-        from fastq_dupaway_amd.sharded import HipOps, ShardedDedup
-        sharded = ShardedDedup(HipOps(eng), dist, dev, n_max=m, len0=L, len1=(L if S == 2 else 0))
-        round_list = [([Reads(bases[mate][lo * L:], uniform_len=L, uniform_stride=L) for mate in range(S)], cnt, keep[lo:])
-                      for lo, cnt in spans]
-
-        def step():
-            eng.reset()
-            sharded.dedup_rounds(round_list)
-            eng.sync()
+            for e in engines:
+                e.reset()
+            for sg, cnts, keeps in round_args:
+                sharded.round(sg, cnts, keeps)
+            sharded.flush()
     else:
         def step():
             eng.reset()
@@ -147,7 +156,8 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
             eng.sync()
 
     def fence():
-        if dist is not None:
+        torch.cuda.synchronize()
+        if dist is not None and world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -161,9 +171,9 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
         if ok is False:
             sys.exit(f"rank {rank}: keep flags differ from the generator's closed form — result invalid")
         parity = "keep flags == closed-form flags of the generator on every rank" if ok else "skipped (no warmup step)"
-    eng.reset_profile()
-    if lazy and sharded.timing is not None:
-        sharded.timing.clear()
+    for e in engines:
+        e.reset_profile()
+    shard_before = sharded.stats(0) if sharded else None
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -175,8 +185,25 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = eng.profile()
-    if lazy and rank == 0 and sharded.timing is not None:
-        print({k: round(v / a.steps, 3) for k, v in sharded.timing.items()}, file=sys.stderr)
+    # what this rank's GPU did, for the per-GPU table of a sharded run
+    mine = {"rank": rank, "device": local, "reads_per_step": n, "ms_per_step": round(dt / a.steps * 1e3, 3)}
+    if sharded:
+        st = sharded.stats(0)
+        d = {k: st[k] - shard_before[k] for k in ("rounds", "overflow_rounds", "bytes_sent", "bytes_received", "exchange_ms")}
+        per_round = max(1, d["rounds"])
+        mine["exchange"] = {"transport": "RCCL: grouped ncclSend/ncclRecv on the library's own communicator" if st["transport"] == 0 else "peer copies (ranks share this process)",
+                            "rccl_ranks": st["ranks_in_comm"], "slab_records": st["slab_records"], "rounds_per_step": rounds,
+                            "overflow_rounds": d["overflow_rounds"],
+                            "bytes_sent_per_round": d["bytes_sent"] // per_round, "bytes_received_per_round": d["bytes_received"] // per_round,
+                            "forward_all_to_all_ms_per_round": round(d["exchange_ms"] / per_round, 3)}
+        mine["kernels_ms_per_step"] = {k: round(prof[f"{k}_ms"] / a.steps, 3) for k in ("encode", "partition", "dedup", "insert", "other") if prof.get(f"{k}_ms")}
+        gbps = n / (dt / a.steps) * S * L / 1e9
+        mine["roofline"] = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBS, 4),
+                            "scope": "this GPU's share of the step: its reads x algorithmic bytes / step time"}
+    per_gpu = [mine]
+    if dist is not None and world > 1:
+        per_gpu = [None] * world
+        dist.all_gather_object(per_gpu, mine)
 
     res = None
     if rank == 0:
@@ -224,10 +251,13 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
                                        f"{n} {what} x {L} bp per GPU"),
                           "input": "150-byte sequence lines extracted from the FASTQ records, resident in HBM when the timed region starts",
                           "reads_per_gpu": n, "read_len": L, "dup_fraction": a.dup_permille / 1000.0,
-                          "sharding": "none" if not sharded_mode else f"hash-prefix all-to-all over {world} GPU(s), {rounds} round(s) per step"
-                                      + (", hashes first / keys for candidates only" if lazy else "")},
+                          "sharding": "none" if not sharded_mode else
+                                      (f"hash-prefix sharding over {job_world} rank(s)" + (f" sharing this GPU ({n_rank} reads each)" if sharded_mode == "virtual" else f" = {world} GPU(s), one process each")
+                                       + f", fixed-size all-to-all slabs, {rounds} round(s) of {m} reads per rank and step")},
                "parity": parity, "roofline": roofline}
-        if world == 1 and cpu_sample > 0:
+        if sharded_mode:
+            res["per_gpu"] = per_gpu
+        if world == 1 and cpu_sample > 0 and sharded_mode != "virtual":
             ms = min(cpu_sample, n)
             cb, cpu_keep = cpu_baseline(bases[0], ms, L, paired, bases[1] if S == 2 else None)
             import numpy as np
@@ -235,6 +265,10 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
                 sys.exit("GPU keep flags differ from the CPU oracle on the baseline sample — result invalid")
             res["cpu_baseline"] = cb
             res["parity"] += f"; == CPU oracle on the first {ms}"
+    if sharded:
+        sharded.close()
+    for e in engines[1:]:
+        e.close()
     return res, eng, bases, expect, keep
 
 
@@ -504,14 +538,19 @@ def main():
     torch.cuda.set_device(local)
     dist = None
     config = "pe" if a.paired else a.config
-    force_sharded = os.environ.get("FQD_BENCH_FORCE_SHARDED") == "1" or config == "sharded1"   # rehearse the N>1 path on one GPU
-    if world > 1 or force_sharded:
+    sharded_mode = False
+    if world > 1:
+        sharded_mode = "ranks"
+    elif config == "sharded1" or os.environ.get("FQD_BENCH_FORCE_SHARDED") == "1":
+        sharded_mode = "ranks"                                  # the N > 1 path rehearsed on one rank: RCCL carries a self exchange
+    elif config == "virtual":
+        sharded_mode = "virtual"
+    if world > 1:
+        # torch.distributed is the control plane (the group's unique id, barriers, the max over ranks of the step time):
+        # gloo.  The data plane — every key and every flag — is RCCL over xGMI through the library's own communicator
+        # (csrc/fqd_shard.hip: ncclCommInitRank + grouped ncclSend/ncclRecv), the same code the CLI's FQD_DEVICES run uses.
         import torch.distributed as dist
-        if force_sharded and world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
-            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    sharded_mode = dist is not None
+        dist.init_process_group("gloo")
     dev = torch.device("cuda", local)
     L = a.read_len
 
@@ -525,6 +564,8 @@ def main():
                "dtype": "u8", "data": "synthetic", "config": res["config"], "parity": res["parity"], "roofline": res["roofline"]}
         if "cpu_baseline" in res:
             out["cpu_baseline"] = res["cpu_baseline"]
+        if "per_gpu" in res:
+            out["per_gpu"] = res["per_gpu"]
     if config == "all" and world == 1 and not sharded_mode:
         # the companions of the headline: a failure in one of them (a full /tmp, say) is reported in its
         # place and never costs the headline line
@@ -554,7 +595,7 @@ def main():
         eng.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
+    if dist is not None and world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -6,7 +6,9 @@ from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
 REPO_ROOT = PKG_DIR.parent
-LIB_PATH = PKG_DIR / "lib" / "libfqdupaway.so"
+import os as _os
+# FQD_LIBRARY: another build of the same library (diagnostics: the phase-stamped one of `make STAMPS=1`)
+LIB_PATH = Path(_os.environ["FQD_LIBRARY"]) if _os.environ.get("FQD_LIBRARY") else PKG_DIR / "lib" / "libfqdupaway.so"
 CLI_PATH = PKG_DIR / "bin" / "fastq-dupaway"
 HEADER = REPO_ROOT / "include" / "fqdupaway.h"
 
@@ -51,6 +53,20 @@ class Profile(C.Structure):
                 ("partition_ms", C.c_double), ("partition_launches", C.c_uint64), ("partition_reads", C.c_uint64),
                 ("dedup_ms", C.c_double), ("dedup_launches", C.c_uint64), ("dedup_reads", C.c_uint64),
                 ("other_ms", C.c_double), ("other_launches", C.c_uint64)]
+
+
+class ShardConfig(C.Structure):
+    _fields_ = [("world", C.c_int32), ("n_local", C.c_int32), ("first_rank", C.c_int32), ("transport", C.c_int32),
+                ("round_reads", C.c_uint64), ("len0", C.c_uint32), ("len1", C.c_uint32), ("slack_permille", C.c_uint32),
+                ("reserved", C.c_uint32), ("slab_records", C.c_uint64), ("unique_id", C.c_void_p)]
+
+
+class ShardStats(C.Structure):
+    _fields_ = [("rounds", C.c_uint64), ("overflow_rounds", C.c_uint64), ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64),
+                ("slab_records", C.c_uint64), ("exchange_ms", C.c_double), ("transport", C.c_int32), ("ranks_in_comm", C.c_int32)]
+
+
+SHARD_RCCL, SHARD_COPY, SHARD_ID_BYTES = 0, 1, 128
 
 
 def build_native(target: str = "all") -> None:
@@ -102,9 +118,6 @@ def load_library():
     L.fqd_key_words.argtypes = [u32, u32]
     L.fqd_key_words.restype = u32
     L.fqd_encode_uniform.argtypes = [vp, C.POINTER(ReadsDesc), u64, vp]
-    L.fqd_partition_records.argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
-    L.fqd_insert_records.argtypes = [vp, vp, u64, u32, u32, vp]
-    L.fqd_reserve_records.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
     L.fqd_sort_tags.argtypes = [vp, C.POINTER(TagsDesc), vp]
     L.fqd_extract_tags.argtypes = [vp, vp, vp, vp, u64, vp, vp]
     L.fqd_join_tags.argtypes = [vp, C.POINTER(TagsDesc), C.POINTER(TagsDesc), C.POINTER(JoinDesc)]
@@ -123,19 +136,24 @@ def load_library():
     L.fqd_partition_keys.argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
     L.fqd_reserve_keys.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
     L.fqd_insert_keys.argtypes = [vp, vp, u64, u32, u32, vp]
-    L.fqd_encode_batch.argtypes = [vp, C.POINTER(ReadsDesc), u64, vp]
-    L.fqd_make_hash_records.argtypes = [vp, vp, u64, u64, vp]
-    L.fqd_reserve_hashes.argtypes = [vp, u64, C.POINTER(vp)]
-    L.fqd_insert_hashes.argtypes = [vp, vp, u64, vp, vp]
-    L.fqd_hash_replies.argtypes = [vp, u64, vp, vp, vp]
-    L.fqd_scatter_u64.argtypes = [vp, vp, vp, u64, vp]
-    L.fqd_build_requests.argtypes = [vp, vp, u64, u64, vp, u64, vp, C.POINTER(u64)]
-    L.fqd_verify_requests.argtypes = [vp, vp, u64, vp]
-    L.fqd_apply_replies.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
     L.fqd_synth_reads.argtypes = [vp, u64, u64, u64, u32, u32, i32, vp, vp]
+    L.fqd_partition_slabs.argtypes = [vp, vp, u64, u32, u32, u64, vp, vp, vp]
+    L.fqd_insert_slabs.argtypes = [vp, vp, u32, u64, vp, u32, u32, vp]
+    L.fqd_shard_unique_id.argtypes = [vp]
+    L.fqd_shard_slab_capacity.argtypes = [u64, C.c_int32, u32]
+    L.fqd_shard_slab_capacity.restype = u64
+    L.fqd_shard_create.argtypes = [C.POINTER(vp), C.POINTER(ShardConfig), C.POINTER(vp)]
+    L.fqd_shard_destroy.argtypes = [vp]
+    L.fqd_shard_round.argtypes = [vp, C.POINTER(ReadsDesc), C.POINTER(u64), C.POINTER(vp)]
+    L.fqd_shard_flush.argtypes = [vp]
+    L.fqd_shard_wait.argtypes = [vp, u64]
+    L.fqd_shard_bad_base.argtypes = [vp, u64, C.POINTER(C.c_int32), C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint8)]
+    L.fqd_shard_get_stats.argtypes = [vp, C.c_int32, C.POINTER(ShardStats)]
+    L.fqd_shard_last_error.argtypes = [vp]
+    L.fqd_shard_last_error.restype = C.c_char_p
     for name in declared_symbols():
         fn = getattr(L, name)          # AttributeError here = header and library disagree
-        if name not in ("fqd_last_error", "fqd_key_words", "fqd_engine_stream", "fqd_bgzf_bound"):
+        if name not in ("fqd_last_error", "fqd_key_words", "fqd_engine_stream", "fqd_bgzf_bound", "fqd_shard_last_error", "fqd_shard_slab_capacity"):
             fn.restype = i32
     _lib = L
     return L

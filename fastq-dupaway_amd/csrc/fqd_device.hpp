@@ -46,11 +46,15 @@ __host__ __device__ inline uint64_t hash_word(uint64_t h, uint64_t w)
 // mate-2's chain (paired): each mate is hashed on its own from hash_begin(len, 0), so the two
 // mates of a pair can be encoded by two lanes.
 __host__ __device__ inline uint64_t hash_pair(uint64_t mate0_chain, uint64_t mate1_chain);
+// kSkipHash in a batch's hash array means "no record at this position" (slab slots the sharded exchange left
+// empty): every insert path passes over it.  No record's own hash ever takes that value.
+constexpr uint64_t kSkipHash = 0xFFFFFFFFFFFFFFFFull;
 __host__ __device__ inline uint64_t hash_end(uint64_t h)
 {
     h ^= h >> 33; h *= 0xff51afd7ed558ccdull;
     h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull;
-    return h ^ (h >> 33);
+    h ^= h >> 33;
+    return h == kSkipHash ? kSkipHash - 1 : h;
 }
 
 __host__ __device__ inline uint64_t hash_pair(uint64_t mate0_chain, uint64_t mate1_chain)

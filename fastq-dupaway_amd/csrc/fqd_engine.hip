@@ -62,8 +62,6 @@ struct fqd_engine {
     DevBuf   keys;     uint64_t keys_used = 0;       // words
     DevBuf   koff;                                   // ragged only: word offset per record
     bool     ragged = false, have_shape = false;
-    bool     rec_layout = false;                     // keys kept as whole records [hash | key] (sharded engines)
-    bool     hash_layout = false;                    // hash engine: store of [hash | payload], keyed by the hash
     uint32_t L0 = 0, L1 = 0, W0 = 0;
     uint64_t n_records = 0;
     uint64_t cap_hint_reads = 0, cap_hint_bases = 0;
@@ -209,8 +207,6 @@ int scan_exclusive(fqd_engine* e, uint64_t* data, uint64_t n, uint64_t add, cons
 
 KeyStore key_store(const fqd_engine* e)
 {
-    if (e->hash_layout) return KeyStore{e->keys.as<uint64_t>(), nullptr, 1, 2, 0};
-    if (e->rec_layout) return KeyStore{e->keys.as<uint64_t>(), nullptr, e->W0, e->W0 + 1, 1};
     return KeyStore{e->keys.as<uint64_t>(), e->ragged ? e->koff.as<uint64_t>() : nullptr, e->W0, e->W0, 0};
 }
 
@@ -266,8 +262,8 @@ int ensure_table(fqd_engine* e, uint64_t records_after, bool exact = false)
         const KeyStore ks = key_store(e);
         hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(e, e->slots)), dim3(kBlock), 0, e->stream,
                            e->table.as<uint64_t>(), e->slots, static_cast<uint64_t*>(nt), want - 1,
-                           (1ull << new_seg_bits) - 1, ks, e->L0, e->L1, uint32_t(e->S == 2), uint32_t(e->hash_layout),
-                           (e->hash_layout || !(e->flags & FQD_FLAG_WEAK_HASH)) ? ~0ull : 0x00000000FFFFFFC0ull,
+                           (1ull << new_seg_bits) - 1, ks, e->L0, e->L1, uint32_t(e->S == 2),
+                           !(e->flags & FQD_FLAG_WEAK_HASH) ? ~0ull : 0x00000000FFFFFFC0ull,
                            new_tag_mask, reinterpret_cast<unsigned long long*>(e->d_state + 1));
         e->table_clear = false; e->table_stale = false;
     } else {
@@ -355,7 +351,11 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
             auto launch = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream, sv[0], n, first_idx, ks, hash_out, err, magic, h1);
             };
-            if (c.lds_out) launch(encode_staged_kernel<true>); else launch(encode_staged_kernel<false>);
+            // FQD_ENCODE_PIPE=0: the encoder that stages, packs and only then asks for the next tile (round 2)
+            static const bool pipe = [] { const char* v = std::getenv("FQD_ENCODE_PIPE"); return v && std::atoi(v) != 0; }();
+            const uint64_t tile_chunks = (uint64_t(c.R) * seg[0].uniform_stride + 15 + 15) / 16;
+            if (c.lds_out && pipe && tile_chunks <= 10ull * c.R) launch(encode_staged_pipe_kernel<10>);
+            else if (c.lds_out) launch(encode_staged_kernel<true>); else launch(encode_staged_kernel<false>);
         } else {
             auto launch = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream,
@@ -494,25 +494,44 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
         hipLaunchKernelGGL(bulk_hist1_kernel, dim3(part_grid), dim3(kPartThreads), 0, e->stream, hashes, hash_stride, n, g, hist1);
     hipLaunchKernelGGL(bulk_scan256_kernel, dim3(1), dim3(320), 0, e->stream,
                        static_cast<const uint32_t*>(hist1), nd1, start1, cursor1, tile_start1);
-    hipLaunchKernelGGL(bulk_scatter_kernel<1>, dim3(part_grid), dim3(kPartThreads), 0, e->stream,
-                       hashes, hash_stride, uint32_t(first_idx), static_cast<const uint64_t*>(nullptr), n, g,
-                       static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor1, recA, g.bits2 > 8 ? static_cast<uint8_t*>(nullptr) : p.digit2);
+    // scatter passes: 0 = one tile at a time, 1024 threads (round 2); 1/2 = software-pipelined with 1024 / 512 threads;
+    // 3/4 = 512 / 1024 threads, not pipelined (the A/B legs of tools/ab_bench.py)
+    static const int scatter_mode = [] { const char* v = std::getenv("FQD_SCATTER_MODE"); return v ? std::atoi(v) : 0; }();
+    auto scatter = [&](auto level, const uint64_t* h, uint32_t hs, uint32_t fi, const uint64_t* in, uint32_t* cursor, uint64_t* out, uint8_t* d2, uint32_t grid) {
+        constexpr int LV = decltype(level)::value;
+        auto go = [&](auto kernel, uint32_t threads) {
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), 0, e->stream, h, hs, fi, in, n, g,
+                               static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor, out, d2);
+        };
+        switch (scatter_mode) {
+            case 1:  go(bulk_scatter_v2_kernel<LV, 1024, true>, 1024u); break;
+            case 2:  go(bulk_scatter_v2_kernel<LV, 512, true>, 512u); break;
+            case 3:  go(bulk_scatter_v2_kernel<LV, 512, false>, 512u); break;
+            case 4:  go(bulk_scatter_v2_kernel<LV, 1024, false>, 1024u); break;
+            default: go(bulk_scatter_kernel<LV>, uint32_t(kPartThreads)); break;
+        }
+    };
+    scatter(std::integral_constant<int, 1>{}, hashes, hash_stride, uint32_t(first_idx), static_cast<const uint64_t*>(nullptr), cursor1, recA,
+            g.bits2 > 8 ? static_cast<uint8_t*>(nullptr) : p.digit2, part_grid);
     if (g.bits2) {
         const uint32_t grid2 = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile + nd1, uint64_t(e->n_cu) * part_per_cu));
+        const uint32_t hgrid = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile + nd1, uint64_t(e->n_cu) * 2u));   // 2 KB of LDS: two 1024-thread blocks fill a CU's wave slots
         if (g.bits2 > 8)
-            hipLaunchKernelGGL(bulk_hist2_kernel<true>, dim3(grid2), dim3(kPartThreads), 0, e->stream,
+            hipLaunchKernelGGL(bulk_hist2_kernel<true>, dim3(hgrid), dim3(kPartThreads), 0, e->stream,
                                static_cast<const uint8_t*>(nullptr), static_cast<const uint64_t*>(recA), g, static_cast<const uint32_t*>(start1),
                                static_cast<const uint32_t*>(tile_start1), hist2);
+        else if (scatter_mode != 0)
+            hipLaunchKernelGGL(bulk_hist2_bytes_kernel, dim3(hgrid), dim3(kPartThreads), 0, e->stream,
+                               static_cast<const uint8_t*>(p.digit2), g, static_cast<const uint32_t*>(start1),
+                               static_cast<const uint32_t*>(tile_start1), hist2);
         else
-            hipLaunchKernelGGL(bulk_hist2_kernel<false>, dim3(grid2), dim3(kPartThreads), 0, e->stream,
+            hipLaunchKernelGGL(bulk_hist2_kernel<false>, dim3(hgrid), dim3(kPartThreads), 0, e->stream,
                                static_cast<const uint8_t*>(p.digit2), static_cast<const uint64_t*>(nullptr), g, static_cast<const uint32_t*>(start1),
                                static_cast<const uint32_t*>(tile_start1), hist2);
         hipLaunchKernelGGL(bulk_scan_buckets_kernel, dim3(nd1), dim3(512), 0, e->stream,
                            static_cast<const uint32_t*>(hist2), g.bits2, static_cast<const uint32_t*>(start1), nd1, start2, cursor2);
-        hipLaunchKernelGGL(bulk_scatter_kernel<2>, dim3(grid2), dim3(kPartThreads), 0, e->stream,
-                           static_cast<const uint64_t*>(nullptr), 0u, 0u, static_cast<const uint64_t*>(recA), n, g,
-                           static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor2, recB,
-                           static_cast<uint8_t*>(nullptr));
+        scatter(std::integral_constant<int, 2>{}, static_cast<const uint64_t*>(nullptr), 0u, 0u, static_cast<const uint64_t*>(recA), cursor2, recB,
+                static_cast<uint8_t*>(nullptr), grid2);
         final_recs = recB; bstart = start2;
     }
     }
@@ -579,6 +598,7 @@ bool seg_is_uniform(const fqd_reads& r) { return r.offsets == nullptr && r.lengt
 FQD_HIDDEN hipStream_t fqd_internal_stream(fqd_engine* e) { return e->stream; }
 FQD_HIDDEN int fqd_internal_device(fqd_engine* e) { return e->device; }
 FQD_HIDDEN int fqd_internal_fail(fqd_engine* e, int code, const char* msg) { return e->fail(code, msg); }
+FQD_HIDDEN uint64_t* fqd_internal_state(fqd_engine* e) { return e->d_state; }
 FQD_HIDDEN int fqd_internal_scratch(fqd_engine* e, int which, size_t bytes, void** out)
 {
     DevBuf& b = which == 0 ? e->scan_scratch : e->part_scratch;
@@ -657,6 +677,23 @@ int fqd_engine_destroy(fqd_engine* e)
     if (!e) return FQD_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+#ifdef FQD_STAMPS
+    {   // diagnostic build: the phase table of the stamped kernels since the last report, in milliseconds of workgroup time
+        unsigned long long t[8][16];
+        if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_stamps), sizeof t) == hipSuccess) {
+            static const char* names[4] = {"scatter1", "scatter2", "dedup", "encode"};
+            for (int k = 0; k < 4; ++k) {
+                unsigned long long tot = 0; for (int q = 0; q < 16; ++q) tot += t[k][q];
+                if (!tot) continue;
+                std::fprintf(stderr, "[stamps] {\"kernel\": \"%s\", \"total_wg_ms\": %.3f, \"phase_frac\": [", names[k], double(tot) * 1e-5);
+                for (int q = 0; q < 12; ++q) std::fprintf(stderr, "%s%.3f", q ? ", " : "", double(t[k][q]) / double(tot));
+                std::fprintf(stderr, "]}\n");
+            }
+            std::memset(t, 0, sizeof t);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), t, sizeof t);
+        }
+    }
+#endif
     drain_profile(e);
     if (e->aux) (void)hipStreamSynchronize(e->aux);
     for (hipEvent_t ev : e->free_events) (void)hipEventDestroy(ev);
@@ -680,22 +717,18 @@ int fqd_engine_reset(fqd_engine* e)
     e->h_state[0] = kNoError; e->h_state[1] = 0; e->h_state[2] = 0; e->h_state[3] = 0;
     HIP_TRY(e, hipMemcpyAsync(e->d_state, e->h_state, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    e->n_records = 0; e->keys_used = 0; e->ragged = false; e->have_shape = false; e->rec_layout = false; e->hash_layout = false;
+    e->n_records = 0; e->keys_used = 0; e->ragged = false; e->have_shape = false;
     e->L0 = e->L1 = e->W0 = 0; e->has_bad = false; e->last_error.clear();
     return FQD_OK;
 }
 
-// hashes_only != nullptr: encode-only mode (fqd_encode_batch): keys are stored, hashes go to the
-// caller, the set is not touched.
-static int submit_impl(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep, uint64_t* hashes_only)
+static int submit_impl(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep)
 {
     if (!e) return FQD_ERR_ARG;
-    if (!seg || (n && !keep && !hashes_only) || (memory != FQD_MEM_HOST && memory != FQD_MEM_DEVICE))
+    if (!seg || (n && !keep) || (memory != FQD_MEM_HOST && memory != FQD_MEM_DEVICE))
         return e->fail(FQD_ERR_ARG, "fqd_submit: bad arguments");
     if (n == 0) return FQD_OK;
     if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
-    if (e->rec_layout || e->hash_layout)
-        return e->fail(FQD_ERR_ARG, "fqd_submit: this engine holds pre-encoded records (fqd_insert_records / fqd_insert_hashes)");
     HIP_TRY(e, hipSetDevice(e->device));
     int rc;
 
@@ -751,9 +784,9 @@ static int submit_impl(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memo
     }
 
     const uint64_t first = e->n_records;
-    if (!hashes_only && (rc = ensure_table(e, first + n))) return rc;
+    if ((rc = ensure_table(e, first + n))) return rc;
     e->hashed_records = nullptr;                              // the scratch is about to be reused
-    if (!hashes_only && (rc = reserve(e, e->hashes, n * sizeof(uint64_t)))) return rc;
+    if ((rc = reserve(e, e->hashes, n * sizeof(uint64_t)))) return rc;
 
     uint64_t new_words = 0;
     if (!e->ragged) {
@@ -782,12 +815,6 @@ static int submit_impl(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memo
     }
 
     KeyStore ks{e->keys.as<uint64_t>(), e->ragged ? e->koff.as<uint64_t>() : nullptr, e->W0, e->W0, 0};
-    if (hashes_only) {
-        if ((rc = launch_encode(e, sv, uniform, seg, n, first, ks, hashes_only))) return rc;
-        e->n_records += n;
-        e->keys_used += new_words;
-        return FQD_OK;
-    }
     BulkPlan plan;
     if (bulk_applies(e, n) && (rc = bulk_plan(e, n, plan))) return rc;
     if (plan.ok) {
@@ -841,14 +868,7 @@ void* fqd_engine_stream(fqd_engine* e) { return e ? static_cast<void*>(e->stream
 
 int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep)
 {
-    return submit_impl(e, seg, n, memory, keep, nullptr);
-}
-
-int fqd_encode_batch(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint64_t* hashes)
-{
-    if (!e) return FQD_ERR_ARG;
-    if (n && !hashes) return e->fail(FQD_ERR_ARG, "fqd_encode_batch: bad arguments");
-    return submit_impl(e, seg, n, FQD_MEM_DEVICE, nullptr, hashes);
+    return submit_impl(e, seg, n, memory, keep);
 }
 
 int fqd_engine_sync(fqd_engine* e)
@@ -922,13 +942,7 @@ int fqd_encode_uniform(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint64_t
 }
 
 static int partition_impl(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
-                          uint32_t n_parts, uint64_t* out, uint64_t* counts, uint32_t* origin, uint32_t strip);
-
-int fqd_partition_records(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
-                          uint32_t n_parts, uint64_t* out, uint64_t* counts, uint32_t* origin)
-{
-    return partition_impl(e, records, n, key_words, n_parts, out, counts, origin, 0u);
-}
+                          uint32_t n_parts, uint64_t* out, uint64_t* counts, uint32_t* origin, uint32_t strip, uint64_t slab_cap = 0);
 
 int fqd_partition_keys(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
                        uint32_t n_parts, uint64_t* out_keys, uint64_t* counts, uint32_t* origin)
@@ -937,20 +951,33 @@ int fqd_partition_keys(fqd_engine* e, const uint64_t* records, uint64_t n, uint3
     return partition_impl(e, records, n, key_words, n_parts, out_keys, counts, origin, 1u);
 }
 
+int fqd_partition_slabs(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
+                        uint32_t n_parts, uint64_t slab_cap, uint64_t* out_keys, uint64_t* counts, uint32_t* origin)
+{
+    if (e && (key_words == 0 || slab_cap == 0)) return e->fail(FQD_ERR_ARG, "fqd_partition_slabs: bad arguments");
+    return partition_impl(e, records, n, key_words, n_parts, out_keys, counts, origin, 1u, slab_cap);
+}
+
 static int partition_impl(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
-                          uint32_t n_parts, uint64_t* out, uint64_t* counts, uint32_t* origin, uint32_t strip)
+                          uint32_t n_parts, uint64_t* out, uint64_t* counts, uint32_t* origin, uint32_t strip, uint64_t slab_cap)
 {
     if (!e) return FQD_ERR_ARG;
-    if (!n_parts || n_parts > 1024 || !counts || (n && (!records || !out || !origin)) || n > 0xFFFFFFFFull)
+    if (!n_parts || n_parts > 1024 || !counts || (n && (!records || !out || !origin)) || n > 0xFFFFFFFFull ||
+        (slab_cap && (!origin || slab_cap * n_parts + n > 0xFFFFFFFFull)))
         return e->fail(FQD_ERR_ARG, "fqd_partition_records: bad arguments");
     HIP_TRY(e, hipSetDevice(e->device));
+    if (slab_cap) {                                          // slab slots no record reaches say so
+        Bracket br(e, K_OTHER, 0);
+        HIP_TRY(e, hipMemsetAsync(origin, 0xFF, slab_cap * n_parts * sizeof(uint32_t), e->stream));
+    }
     if (n == 0) { HIP_TRY(e, hipMemsetAsync(counts, 0, n_parts * sizeof(uint64_t), e->stream)); return FQD_OK; }
     const uint32_t n_blocks = uint32_t((n + kBlock - 1) / kBlock);
     const uint32_t rec_words = key_words + 1;
     const uint64_t cells = uint64_t(n_parts) * n_blocks;
-    int rc = reserve(e, e->part_scratch, cells * sizeof(uint64_t));
+    int rc = reserve(e, e->part_scratch, (cells + 2 * uint64_t(n_parts) + 2) * sizeof(uint64_t));
     if (rc) return rc;
     uint64_t* c2 = e->part_scratch.as<uint64_t>();
+    ulonglong2* slab_of = reinterpret_cast<ulonglong2*>(c2 + ((cells + 1) & ~1ull));
     Bracket br(e, K_OTHER, 0);
     const bool compact = records == e->hashed_records && n == e->hashed_n && rec_words == e->hashed_rec_words;
     hipLaunchKernelGGL(part_count_kernel, dim3(n_blocks), dim3(kBlock), n_parts * sizeof(uint32_t), e->stream,
@@ -959,63 +986,15 @@ static int partition_impl(fqd_engine* e, const uint64_t* records, uint64_t n, ui
     const size_t scatter_lds = size_t(kBlock) * rec_words * sizeof(uint64_t) + kBlock * sizeof(uint64_t) + size_t(n_parts) * 4 * sizeof(uint32_t);
     if (scatter_lds > 64 * 1024) return e->fail(FQD_ERR_ARG, "fqd_partition_records: records too long for the staged partition");
     const uint32_t rw_magic = rec_words > 1 ? uint32_t(((1ull << 32) + rec_words - 1) / rec_words) : 0xFFFFFFFFu;
+    if (slab_cap)
+        hipLaunchKernelGGL(part_slab_offsets_kernel, dim3(1), dim3(64), 0, e->stream,
+                           static_cast<const uint64_t*>(c2), n_parts, n_blocks, n, slab_cap, slab_of);
     hipLaunchKernelGGL(part_scatter_kernel, dim3(n_blocks), dim3(kBlock), scatter_lds, e->stream,
-                       records, n, rec_words, n_parts, static_cast<const uint64_t*>(c2), n_blocks, out, origin, rw_magic, strip);
+                       records, n, rec_words, n_parts, static_cast<const uint64_t*>(c2), n_blocks, out, origin, rw_magic, strip,
+                       slab_cap, static_cast<const ulonglong2*>(slab_of));
     hipLaunchKernelGGL(part_totals_kernel, dim3((n_parts + 63) / 64), dim3(64), 0, e->stream,
                        static_cast<const uint64_t*>(c2), n_parts, n_blocks, n, counts);
     HIP_TRY(e, hipGetLastError());
-    return FQD_OK;
-}
-
-// Common front of the two record entry points: shape, table and key-store capacity.
-static int prepare_records(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1)
-{
-    if (e->S == 1 && len1 != 0) return e->fail(FQD_ERR_ARG, "records: single-end engine given a mate-2 length");
-    if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
-    HIP_TRY(e, hipSetDevice(e->device));
-    if (!e->have_shape) {
-        e->have_shape = true; e->ragged = false; e->rec_layout = true;
-        e->L0 = len0; e->L1 = len1; e->W0 = seg_words(len0) + seg_words(len1);
-    } else if (!e->rec_layout || e->L0 != len0 || e->L1 != len1)
-        return e->fail(FQD_ERR_ARG, "records: engine holds keys of another shape or layout");
-    int rc;
-    if ((rc = ensure_table(e, e->n_records + n))) return rc;
-    const uint64_t need = e->keys_used + n * uint64_t(e->W0 + 1);
-    return reserve(e, e->keys, std::max<uint64_t>(need, 64) * sizeof(uint64_t), e->keys_used * sizeof(uint64_t));
-}
-
-int fqd_reserve_records(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1, uint64_t** slot)
-{
-    if (!e) return FQD_ERR_ARG;
-    if (!slot) return e->fail(FQD_ERR_ARG, "fqd_reserve_records: bad arguments");
-    const int rc = prepare_records(e, n, len0, len1);
-    if (rc) return rc;
-    *slot = e->keys.as<uint64_t>() + e->keys_used;
-    return FQD_OK;
-}
-
-int fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep)
-{
-    if (!e) return FQD_ERR_ARG;
-    if (n && (!records || !keep)) return e->fail(FQD_ERR_ARG, "fqd_insert_records: bad arguments");
-    if (n == 0) return FQD_OK;
-    int rc;
-    if ((rc = prepare_records(e, n, len0, len1))) return rc;
-    const uint64_t first = e->n_records;
-    const uint64_t words = n * uint64_t(e->W0 + 1);
-    uint64_t* tail = e->keys.as<uint64_t>() + e->keys_used;
-    if (records != tail) {                                   // not received in place: one contiguous copy
-        Bracket br(e, K_OTHER, 0);
-        HIP_TRY(e, hipMemcpyAsync(tail, records, words * sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream));
-    }
-    const KeyStore ks = key_store(e);
-    // the hash of record j is word 0 of its slot: hashes = first slot of the batch, stride W0+1
-    const uint64_t* hashes = tail;
-    BulkPlan plan;
-    if (bulk_applies(e, n) && (rc = bulk_plan(e, n, plan))) return rc;
-    if (plan.ok) { if ((rc = launch_bulk_insert(e, ks, hashes, e->W0 + 1, n, first, keep, plan, false))) return rc; }
-    else if ((rc = launch_insert(e, ks, hashes, e->W0 + 1, n, first, keep))) return rc;
-    e->n_records += n; e->keys_used += words;
     return FQD_OK;
 }
 
@@ -1027,9 +1006,9 @@ static int prepare_keys(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1)
     if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
     HIP_TRY(e, hipSetDevice(e->device));
     if (!e->have_shape) {
-        e->have_shape = true; e->ragged = false; e->rec_layout = false;
+        e->have_shape = true; e->ragged = false;
         e->L0 = len0; e->L1 = len1; e->W0 = seg_words(len0) + seg_words(len1);
-    } else if (e->ragged || e->rec_layout || e->hash_layout || e->L0 != len0 || e->L1 != len1)
+    } else if (e->ragged || e->L0 != len0 || e->L1 != len1)
         return e->fail(FQD_ERR_ARG, "keys: engine holds keys of another shape or layout");
     if (e->W0 == 0) return e->fail(FQD_ERR_ARG, "keys: empty keys");
     int rc;
@@ -1048,7 +1027,23 @@ int fqd_reserve_keys(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1, ui
     return FQD_OK;
 }
 
+static int insert_keys_impl(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep,
+                            uint64_t slab_cap, const uint64_t* slab_count);
+
 int fqd_insert_keys(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep)
+{
+    return insert_keys_impl(e, keys, n, len0, len1, keep, 0, nullptr);
+}
+
+int fqd_insert_slabs(fqd_engine* e, const uint64_t* keys, uint32_t n_slabs, uint64_t slab_cap, const uint64_t* slab_count,
+                     uint32_t len0, uint32_t len1, uint8_t* keep)
+{
+    if (e && (!slab_cap || !slab_count)) return e->fail(FQD_ERR_ARG, "fqd_insert_slabs: bad arguments");
+    return insert_keys_impl(e, keys, uint64_t(n_slabs) * slab_cap, len0, len1, keep, slab_cap, slab_count);
+}
+
+static int insert_keys_impl(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep,
+                            uint64_t slab_cap, const uint64_t* slab_count)
 {
     if (!e) return FQD_ERR_ARG;
     if (n && (!keys || !keep)) return e->fail(FQD_ERR_ARG, "fqd_insert_keys: bad arguments");
@@ -1068,7 +1063,8 @@ int fqd_insert_keys(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t le
         Bracket br(e, K_OTHER, 0);
         const uint64_t hash_and = (e->flags & FQD_FLAG_WEAK_HASH) ? 0x00000000FFFFFFC0ull : ~0ull;
         hipLaunchKernelGGL(hash_keys_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
-                           static_cast<const uint64_t*>(tail), e->W0, n, e->L0, e->L1, uint32_t(e->S == 2), hash_and, e->hashes.as<uint64_t>());
+                           static_cast<const uint64_t*>(tail), e->W0, n, e->L0, e->L1, uint32_t(e->S == 2), hash_and, e->hashes.as<uint64_t>(),
+                           slab_cap, slab_count);
     }
     const KeyStore ks = key_store(e);
     BulkPlan plan;
@@ -1088,159 +1084,6 @@ int fqd_scatter_flags(fqd_engine* e, const uint8_t* flags, const uint32_t* origi
     Bracket br(e, K_OTHER, 0);
     hipLaunchKernelGGL(scatter_flags_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream, flags, origin, n, keep_out);
     HIP_TRY(e, hipGetLastError());
-    return FQD_OK;
-}
-
-// ---- optimistic sharding --------------------------------------------------------------
-
-int fqd_make_hash_records(fqd_engine* e, const uint64_t* hashes, uint64_t n, uint64_t payload_base, uint64_t* out)
-{
-    if (!e) return FQD_ERR_ARG;
-    if (n && (!hashes || !out)) return e->fail(FQD_ERR_ARG, "fqd_make_hash_records: bad arguments");
-    if (n == 0) return FQD_OK;
-    HIP_TRY(e, hipSetDevice(e->device));
-    Bracket br(e, K_OTHER, 0);
-    hipLaunchKernelGGL(make_hash_records_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
-                       hashes, n, payload_base, reinterpret_cast<ulonglong2*>(out));
-    HIP_TRY(e, hipGetLastError());
-    return FQD_OK;
-}
-
-// Shape, table and store capacity of a hash engine for n more records.
-static int prepare_hashes(fqd_engine* e, uint64_t n)
-{
-    if (e->S != 1) return e->fail(FQD_ERR_ARG, "hash engines are created with segments = 1");
-    if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
-    HIP_TRY(e, hipSetDevice(e->device));
-    if (!e->have_shape) { e->have_shape = true; e->ragged = false; e->hash_layout = true; e->L0 = e->L1 = 0; e->W0 = 1; }
-    else if (!e->hash_layout) return e->fail(FQD_ERR_ARG, "fqd_insert_hashes: engine already holds sequence keys");
-    int rc;
-    if ((rc = ensure_table(e, e->n_records + n))) return rc;
-    const uint64_t need = e->keys_used + 2 * n;
-    return reserve(e, e->keys, std::max<uint64_t>(need, 64) * sizeof(uint64_t), e->keys_used * sizeof(uint64_t));
-}
-
-int fqd_reserve_hashes(fqd_engine* e, uint64_t n, uint64_t** slot)
-{
-    if (!e) return FQD_ERR_ARG;
-    if (!slot) return e->fail(FQD_ERR_ARG, "fqd_reserve_hashes: bad arguments");
-    const int rc = prepare_hashes(e, n);
-    if (rc) return rc;
-    *slot = e->keys.as<uint64_t>() + e->keys_used;
-    return FQD_OK;
-}
-
-int fqd_insert_hashes(fqd_engine* e, const uint64_t* records, uint64_t n, uint8_t* keep, uint32_t* first)
-{
-    if (!e) return FQD_ERR_ARG;
-    if (n && (!records || !keep)) return e->fail(FQD_ERR_ARG, "fqd_insert_hashes: bad arguments");
-    if (n == 0) return FQD_OK;
-    int rc;
-    if ((rc = prepare_hashes(e, n))) return rc;
-    const uint64_t first_idx = e->n_records;
-    uint64_t* tail = e->keys.as<uint64_t>() + e->keys_used;
-    if (records != tail) {
-        Bracket br(e, K_OTHER, 0);
-        HIP_TRY(e, hipMemcpyAsync(tail, records, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream));
-    }
-    const KeyStore ks = key_store(e);                         // key word = the hash itself
-    BulkPlan plan;
-    if (bulk_applies(e, n) && (rc = bulk_plan(e, n, plan))) return rc;
-    if (plan.ok) { if ((rc = launch_bulk_insert(e, ks, tail, 2, n, first_idx, keep, plan, false, first))) return rc; }
-    else if ((rc = launch_insert(e, ks, tail, 2, n, first_idx, keep, true, 8, first))) return rc;
-    e->n_records += n; e->keys_used += 2 * n;
-    return FQD_OK;
-}
-
-int fqd_hash_replies(fqd_engine* e, uint64_t n, const uint8_t* keep, const uint32_t* first, uint64_t* reply)
-{
-    if (!e) return FQD_ERR_ARG;
-    if (!e->hash_layout || (n && (!keep || !first || !reply)) || n > e->n_records)
-        return e->fail(FQD_ERR_ARG, "fqd_hash_replies: bad arguments");
-    if (n == 0) return FQD_OK;
-    HIP_TRY(e, hipSetDevice(e->device));
-    Bracket br(e, K_OTHER, 0);
-    hipLaunchKernelGGL(hash_replies_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
-                       reinterpret_cast<const ulonglong2*>(e->keys.as<uint64_t>()), uint32_t(e->n_records - n), n, keep, first, reply);
-    HIP_TRY(e, hipGetLastError());
-    return FQD_OK;
-}
-
-int fqd_scatter_u64(fqd_engine* e, const uint64_t* vals, const uint32_t* origin, uint64_t n, uint64_t* out)
-{
-    if (!e) return FQD_ERR_ARG;
-    if (n && (!vals || !origin || !out)) return e->fail(FQD_ERR_ARG, "fqd_scatter_u64: bad arguments");
-    if (n == 0) return FQD_OK;
-    HIP_TRY(e, hipSetDevice(e->device));
-    Bracket br(e, K_OTHER, 0);
-    hipLaunchKernelGGL(scatter_u64_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream, vals, origin, n, out);
-    HIP_TRY(e, hipGetLastError());
-    return FQD_OK;
-}
-
-int fqd_build_requests(fqd_engine* e, const uint64_t* reply, uint64_t n, uint64_t local_base,
-                       uint64_t* req, uint64_t req_capacity, uint32_t* req_local, uint64_t* count)
-{
-    if (!e) return FQD_ERR_ARG;
-    if (!count || (n && !reply) || e->ragged || e->rec_layout || e->hash_layout || !e->have_shape ||
-        local_base + n > e->n_records || n > 0xFFFFFFFFull)
-        return e->fail(FQD_ERR_ARG, "fqd_build_requests: needs a uniform engine filled by fqd_encode_batch");
-    *count = 0;
-    if (n == 0) return FQD_OK;
-    HIP_TRY(e, hipSetDevice(e->device));
-    const uint32_t n_blocks = uint32_t((n + kReqChunk - 1) / kReqChunk);
-    int rc = reserve(e, e->part_scratch, uint64_t(n_blocks) * sizeof(uint64_t));
-    if (rc) return rc;
-    uint64_t* blocks = e->part_scratch.as<uint64_t>();
-    const uint64_t* d_total = nullptr;
-    {
-        Bracket br(e, K_OTHER, 0);
-        hipLaunchKernelGGL(count_requests_kernel, dim3(n_blocks), dim3(kBlock), 0, e->stream, reply, n, blocks);
-        if ((rc = scan_exclusive(e, blocks, n_blocks, 0, &d_total))) return rc;
-    }
-    HIP_TRY(e, hipMemcpyAsync(&e->h_state[3], d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    *count = e->h_state[3];
-    if (*count > req_capacity) return e->fail(FQD_ERR_CAPACITY, "fqd_build_requests: more requests than req_capacity");
-    if (*count == 0) return FQD_OK;
-    if (!req || !req_local) return e->fail(FQD_ERR_ARG, "fqd_build_requests: bad arguments");
-    Bracket br(e, K_OTHER, 0);
-    hipLaunchKernelGGL(build_requests_kernel, dim3(n_blocks), dim3(kBlock), 0, e->stream,
-                       reply, n, uint32_t(local_base), key_store(e), static_cast<const uint64_t*>(blocks), req, req_local);
-    HIP_TRY(e, hipGetLastError());
-    return FQD_OK;
-}
-
-int fqd_verify_requests(fqd_engine* e, const uint64_t* req, uint64_t m, uint8_t* verdict)
-{
-    if (!e) return FQD_ERR_ARG;
-    if ((m && (!req || !verdict)) || e->ragged || e->rec_layout || e->hash_layout || !e->have_shape)
-        return e->fail(FQD_ERR_ARG, "fqd_verify_requests: needs a uniform engine filled by fqd_encode_batch");
-    if (m == 0) return FQD_OK;
-    HIP_TRY(e, hipSetDevice(e->device));
-    Bracket br(e, K_OTHER, 0);
-    hipLaunchKernelGGL(verify_requests_kernel, dim3(grid_for(e, m)), dim3(kBlock), 0, e->stream, req, m, key_store(e), verdict);
-    HIP_TRY(e, hipGetLastError());
-    return FQD_OK;
-}
-
-int fqd_apply_replies(fqd_engine* e, const uint64_t* reply, uint64_t n, uint8_t* keep,
-                      const uint8_t* verdict, uint64_t m, uint64_t* refuted)
-{
-    if (!e) return FQD_ERR_ARG;
-    if (!refuted || (n && (!reply || !keep)) || (m && !verdict)) return e->fail(FQD_ERR_ARG, "fqd_apply_replies: bad arguments");
-    if (n == 0 && m == 0) return FQD_OK;
-    HIP_TRY(e, hipSetDevice(e->device));
-    unsigned long long* d_count = reinterpret_cast<unsigned long long*>(e->d_state + 3);
-    {
-        Bracket br(e, K_OTHER, 0);
-        HIP_TRY(e, hipMemsetAsync(d_count, 0, sizeof(uint64_t), e->stream));
-        hipLaunchKernelGGL(apply_replies_kernel, dim3(grid_for(e, std::max(n, m))), dim3(kBlock), 0, e->stream,
-                           reply, n, keep, verdict, m, d_count);
-    }
-    HIP_TRY(e, hipMemcpyAsync(&e->h_state[3], d_count, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-    *refuted += e->h_state[3];
     return FQD_OK;
 }
 

@@ -15,6 +15,21 @@ namespace fqd {
 
 constexpr int kBlock = 256;
 
+// Diagnostic build only (make STAMPS=1; never the shipped library): thread 0 of every workgroup adds the time it
+// spends in each numbered phase (100 MHz ticks of wall_clock64, barrier waits included) to g_stamps[kernel][phase];
+// the engine prints the table when it is destroyed.  Kernel ids: 0/1 scatter level 1/2, 2 dedup, 3 staged encoder.
+#ifdef FQD_STAMPS
+__device__ unsigned long long g_stamps[8][16];
+#define STAMP_DECL __shared__ unsigned long long st_acc_[16]; __shared__ unsigned long long st_last_; \
+    if (threadIdx.x == 0) { for (int q_ = 0; q_ < 16; ++q_) st_acc_[q_] = 0; st_last_ = wall_clock64(); }
+#define STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); st_acc_[i] += now_ - st_last_; st_last_ = now_; } } while (0)
+#define STAMP_FLUSH(kid) do { if (threadIdx.x == 0) for (int q_ = 0; q_ < 16; ++q_) if (st_acc_[q_]) atomicAdd(&g_stamps[kid][q_], st_acc_[q_]); } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i) do { } while (0)
+#define STAMP_FLUSH(kid) do { } while (0)
+#endif
+
 // One mate's input as the kernels see it.
 struct SegView {
     const uint8_t*  bases;
@@ -289,7 +304,9 @@ void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
     const uint32_t R = blockDim.x;
     const uint32_t row_words = ks.W0 + ks.lead;
     const uint64_t n_tiles = (n + R - 1) / R;
+    STAMP_DECL
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        STAMP(0);
         const uint64_t r0 = tile * R;
         const uint32_t nr = uint32_t(n - r0 < R ? n - r0 : R);
         const uint8_t* g0 = s0.bases + r0 * uint64_t(s0.ustride);
@@ -297,7 +314,9 @@ void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
         const uintptr_t ga = reinterpret_cast<uintptr_t>(g0);
         const uint32_t in0 = uint32_t(ga & 15u);                    // bytes before g0 in its 16-B chunk
         stage_chunks(g0 - in0, lds, (in0 + bytes + 15u) >> 4, R);
+        STAMP(1);                                                   // staging, my wave
         __syncthreads();
+        STAMP(2);                                                   // staging, the others
         const uint32_t t = threadIdx.x;
         const uint64_t i = r0 + t;
         const uint32_t l0 = s0.ulen;
@@ -328,6 +347,7 @@ void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
                 if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
             }
         }
+        STAMP(3);                                                   // pack + hash
         if (LDS_OUT) {
             // the wave's 64 rows -> one contiguous run of key slots
             const uint32_t wave = t >> 6, lane = t & 63u;
@@ -339,7 +359,89 @@ void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
                 __builtin_nontemporal_store(lds64[((in0 + (wave * 64u + rr) * s0.ustride + 4u + 7u) >> 3) + kk], &gout[x]);
             }
         }
+        STAMP(4);                                                   // key stream-out issue
         __syncthreads();
+        STAMP(5);                                                   // barrier
+    }
+    STAMP_FLUSH(3);
+    if (h1.hist) hist1_flush(lhist, h1.hist);
+}
+
+// The same encoder (LDS_OUT form) with the NEXT tile's loads in flight while this tile is packed: a lane keeps
+// NCH 16-byte chunks of the next tile in registers (NCH * R * 16 bytes >= one tile; 10 for 150-byte reads at
+// R = 256), requested right after the current tile has been put into LDS and written there once the workgroup is
+// done with it.  Four workgroups per CU (LDS) then hold four tiles of loads in flight all the time instead of
+// only while they are in their staging phase.  Host side picks it when the tile fits NCH chunks per lane.
+template <int NCH>
+__global__ __launch_bounds__(kBlock)
+void encode_staged_pipe_kernel(SegView s0, uint64_t n, uint64_t first_idx,
+                               KeyStore ks, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err, uint32_t rw_magic, Hist1 h1)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ __attribute__((aligned(16))) uint32_t lhist[256];
+    if (h1.hist) hist1_clear(lhist);
+    uint64_t* lds64 = reinterpret_cast<uint64_t*>(lds);
+    u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
+    const uint32_t R = blockDim.x;
+    const uint32_t row_words = ks.W0 + ks.lead;
+    const uint64_t n_tiles = (n + R - 1) / R;
+    uint64_t tile = blockIdx.x;
+    if (tile < n_tiles) {
+        u32x4 v[NCH];
+        uint32_t n16 = 0, in0 = 0, nr = 0;
+        auto request = [&](uint64_t t) {
+            const uint64_t r0 = t * R;
+            nr = uint32_t(n - r0 < R ? n - r0 : R);
+            const uint8_t* g0 = s0.bases + r0 * uint64_t(s0.ustride);
+            const uint32_t bytes = (nr - 1u) * s0.ustride + s0.ulen;
+            in0 = uint32_t(reinterpret_cast<uintptr_t>(g0) & 15u);
+            n16 = (in0 + bytes + 15u) >> 4;
+            const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(g0 - in0);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) { const uint32_t c = threadIdx.x + uint32_t(k) * R; v[k] = __builtin_nontemporal_load(&src[c < n16 ? c : n16 - 1u]); }
+        };
+        request(tile);
+        for (;;) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) { const uint32_t c = threadIdx.x + uint32_t(k) * R; if (c < n16) lds16[c] = v[k]; }
+            __syncthreads();
+            const uint64_t r0 = tile * R;
+            const uint32_t cur_in0 = in0, cur_nr = nr;
+            const uint64_t next = tile + gridDim.x;
+            if (next < n_tiles) request(next);                 // in flight while this tile is packed
+            const uint32_t t = threadIdx.x;
+            const uint64_t i = r0 + t;
+            const uint32_t l0 = s0.ulen;
+            if (t < cur_nr) {
+                uint64_t h = hash_begin(l0, 0);
+                const uint32_t b0 = cur_in0 + t * s0.ustride;
+                uint64_t* row = lds64 + ((b0 + 4u + 7u) >> 3) + ks.lead;
+                uint64_t* out = row;
+                auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
+                const uint32_t diff = pack_mate(lds + (b0 >> 2), b0 & 3u, l0, sink);
+                h = hash_end(h) & h1.hash_and;
+                if (ks.lead) row[-1] = h;
+                if (hash_out) hash_out[i] = h;
+                if (h1.hist) atomicAdd(&lhist[bucket_of(h, h1.g) >> h1.g.bits2], 1u);
+                if (diff) {
+                    const uint64_t e = locate_bad_base(s0.bases + i * uint64_t(s0.ustride), l0, nullptr, 0, first_idx + i);
+                    if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
+                }
+            }
+            {
+                const uint32_t wave = t >> 6, lane = t & 63u;
+                const uint32_t wave_reads = (cur_nr > wave * 64u) ? ((cur_nr - wave * 64u < 64u) ? cur_nr - wave * 64u : 64u) : 0u;
+                uint64_t* __restrict__ gout = ks.keys + (first_idx + r0 + wave * 64u) * uint64_t(ks.stride);
+                const uint32_t total = wave_reads * row_words;
+                for (uint32_t x = lane; x < total; x += 64u) {
+                    const uint32_t rr = __umulhi(x, rw_magic), kk = x - rr * row_words;
+                    __builtin_nontemporal_store(lds64[((cur_in0 + (wave * 64u + rr) * s0.ustride + 4u + 7u) >> 3) + kk], &gout[x]);
+                }
+            }
+            __syncthreads();
+            if (next >= n_tiles) break;
+            tile = next;
+        }
     }
     if (h1.hist) hist1_flush(lhist, h1.hist);
 }
@@ -488,6 +590,7 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, uint64_t se
     uint32_t dups = 0, lost = 0;
     for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
         const uint64_t h = hashes[i * uint64_t(hash_stride)];
+        if (h == kSkipHash) continue;                           // no record at this position
         const uint32_t idx = out.first_idx + uint32_t(i);
         const uint64_t tag = slot_tag(h, tag_mask);
         const unsigned long long mine = (tag << 32) | idx;
@@ -531,7 +634,7 @@ void insert_kernel(uint64_t* __restrict__ table, uint64_t slot_mask, uint64_t se
 __global__ __launch_bounds__(kBlock)
 void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
                    uint64_t* __restrict__ new_table, uint64_t new_mask, uint64_t new_seg_mask, KeyStore ks,
-                   uint32_t len0, uint32_t len1, uint32_t paired, uint32_t key_is_hash, uint64_t hash_and,
+                   uint32_t len0, uint32_t len1, uint32_t paired, uint64_t hash_and,
                    uint32_t new_tag_mask, unsigned long long* __restrict__ counters /* [1] = table-full */)
 {
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(new_table);
@@ -545,9 +648,7 @@ void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
         const uint32_t w0 = seg_words(l0);
         uint64_t h = hash_begin(l0, 0);
         for (uint32_t k = 0; k < w0; ++k) h = hash_word(h, p[k]);
-        if (key_is_hash) {                                    // hash engines: the stored key IS the placement hash
-            h = p[0];
-        } else if (paired) {                                         // second chain, then combine
+        if (paired) {                                         // second chain, then combine
             uint64_t h1 = hash_begin(l1, 0);
             for (uint32_t k = w0; k < W; ++k) h1 = hash_word(h1, p[k]);
             h = hash_pair(h, h1);
@@ -587,8 +688,10 @@ void bulk_hist1_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stride
     __shared__ uint32_t h[256];
     for (int k = threadIdx.x; k < 256; k += kPartThreads) h[k] = 0;
     __syncthreads();
-    for (uint64_t i = blockIdx.x * uint64_t(kPartThreads) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kPartThreads)
-        atomicAdd(&h[bucket_of(hashes[i * uint64_t(hash_stride)], g) >> g.bits2], 1u);
+    for (uint64_t i = blockIdx.x * uint64_t(kPartThreads) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kPartThreads) {
+        const uint64_t v = hashes[i * uint64_t(hash_stride)];
+        if (v != kSkipHash) atomicAdd(&h[bucket_of(v, g) >> g.bits2], 1u);
+    }
     __syncthreads();
     for (int k = threadIdx.x; k < 256; k += kPartThreads) if (h[k]) atomicAdd(&hist1[k], h[k]);
 }
@@ -637,9 +740,12 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
     __shared__ uint8_t sdig[kPartTile];
     constexpr int kBins = (LEVEL == 1) ? 256 : 512;         // level 1: up to 8 bits, level 2: up to 9
     __shared__ uint32_t cnt[kBins], lstart[kBins], gbase[kBins];
+    __shared__ uint32_t n_valid;
     const uint32_t nd1 = 1u << g.bits1, mask2 = (1u << g.bits2) - 1u;
     const uint64_t n_tiles = (LEVEL == 1) ? (n + kPartTile - 1) / kPartTile : tile_start1[nd1];
+    STAMP_DECL
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        STAMP(0);
         uint64_t lo, hi; uint32_t d1 = 0;
         if (LEVEL == 1) { lo = tile * kPartTile; hi = lo + kPartTile < n ? lo + kPartTile : n; }
         else {
@@ -653,6 +759,7 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
         const uint32_t count = uint32_t(hi - lo);
         for (int k = threadIdx.x; k < kBins; k += kPartThreads) cnt[k] = 0;
         __syncthreads();
+        STAMP(1);                                             // tile lookup + clear + barrier
         uint64_t rec[kPartPer]; uint32_t dig[kPartPer], rank[kPartPer];
 #pragma unroll
         for (int k = 0; k < kPartPer; ++k) {                  // every load of the tile first (index clamped): one round trip
@@ -663,7 +770,8 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
 #pragma unroll
         for (int k = 0; k < kPartPer; ++k) {
             const uint32_t r = threadIdx.x + k * kPartThreads;
-            if (r < count) {
+            dig[k] = 0xFFFFFFFFu;                                // no record: past the tile's end, or a skipped position
+            if (r < count && (LEVEL != 1 || rec[k] != kSkipHash)) {
                 if (LEVEL == 1) {
                     const uint64_t h = rec[k];
                     rec[k] = (uint64_t(part_q(h, g)) << 32) | (first_idx + uint32_t(lo + r));
@@ -674,6 +782,135 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
                 rank[k] = atomicAdd(&cnt[dig[k]], 1u);
             }
         }
+        STAMP(2);                                             // loads + ranks (LDS atomics), my wave
+        __syncthreads();
+        STAMP(3);                                             // ... the other waves
+        if (threadIdx.x < 64) {                               // exclusive scan of the counts by one wave
+            constexpr int kPer = kBins / 64;
+            uint32_t c[kPer], s = 0;
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) { c[k] = cnt[threadIdx.x * kPer + k]; s += c[k]; }
+            uint32_t inc = s;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(inc, d, 64); if (int(threadIdx.x) >= d) inc += up; }
+            uint32_t ex = inc - s;
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) { lstart[threadIdx.x * kPer + k] = ex; ex += c[k]; }
+            if (threadIdx.x == 63) n_valid = inc;
+        }
+        __syncthreads();
+        STAMP(4);                                             // scan + barrier
+        for (int k = threadIdx.x; k < kBins; k += kPartThreads)
+            gbase[k] = cnt[k] ? atomicAdd(&cursor[(LEVEL == 1 ? 0u : (d1 << g.bits2)) + k], cnt[k]) : 0u;
+        STAMP(5);                                             // cursor atomics (wave 0 has them)
+#pragma unroll
+        for (int k = 0; k < kPartPer; ++k)
+            if (dig[k] != 0xFFFFFFFFu) {
+                const uint32_t at = lstart[dig[k]] + rank[k];
+                stage[at] = rec[k];
+                if (LEVEL == 1) sdig[at] = uint8_t(dig[k]);       // level 2 finds its digit in the record itself
+            }
+        STAMP(6);                                             // stage writes
+        __syncthreads();
+        STAMP(7);                                             // barrier
+        const uint32_t valid = n_valid;
+#pragma unroll
+        for (int k = 0; k < kPartPer; ++k) {
+            const uint32_t r = threadIdx.x + k * kPartThreads;
+            if (r < valid) {
+                const uint64_t v = stage[r];
+                const uint32_t d = (LEVEL == 1) ? uint32_t(sdig[r]) : ((uint32_t(v >> 32) >> g.seg_bits) & mask2);
+                out[gbase[d] + (r - lstart[d])] = v;      // plain stores: the short runs of neighbouring tiles combine in L2
+                if (LEVEL == 1 && digit2_out) digit2_out[gbase[d] + (r - lstart[d])] = uint8_t((uint32_t(v >> 32) >> g.seg_bits) & mask2);
+            }
+        }
+        STAMP(8);                                             // write-out issue
+        __syncthreads();
+        STAMP(9);                                             // barrier
+    }
+    STAMP_FLUSH(LEVEL - 1);
+}
+
+// The same pass, software-pipelined (the scatters issued 6-12 % of their cycles, each tile waiting
+// out its own load round trip behind block-wide barriers).  Differences to bulk_scatter_kernel:
+//   * the records of tile t+1 are requested while tile t is ranked, scanned and written out (PIPE), so a
+//     workgroup always has a tile of loads in flight;
+//   * THREADS x (8192 / THREADS) records per lane: at 512 threads a lane holds two tiles' worth of registers
+//     inside the 128-VGPR budget of two workgroups per CU (the 1024-thread level-2 kernel needs 65 VGPRs,
+//     one over what lets two of them share a CU);
+//   * level 2 finds its tile's level-1 digit in an LDS copy of the tile table instead of eight dependent
+//     global loads per tile.
+template <int LEVEL, int THREADS, bool PIPE>
+__global__ __launch_bounds__(THREADS)
+void bulk_scatter_v2_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stride, uint32_t first_idx,
+                            const uint64_t* __restrict__ in, uint64_t n, BulkGeom g,
+                            const uint32_t* __restrict__ start1, const uint32_t* __restrict__ tile_start1,
+                            uint32_t* __restrict__ cursor, uint64_t* __restrict__ out,
+                            uint8_t* __restrict__ digit2_out)
+{
+    constexpr int PER = kPartTile / THREADS;
+    __shared__ uint64_t stage[kPartTile];
+    __shared__ uint8_t sdig[LEVEL == 1 ? kPartTile : 16];
+    constexpr int kBins = (LEVEL == 1) ? 256 : 512;
+    __shared__ uint32_t cnt[kBins], lstart[kBins], gbase[kBins];
+    __shared__ uint32_t ts1[LEVEL == 1 ? 4 : 260], st1[LEVEL == 1 ? 4 : 260];
+    __shared__ uint32_t n_valid;
+    const uint32_t nd1 = 1u << g.bits1, mask2 = (1u << g.bits2) - 1u;
+    if (LEVEL == 2) {
+        for (uint32_t k = threadIdx.x; k <= nd1; k += THREADS) { ts1[k] = tile_start1[k]; st1[k] = start1[k]; }
+        __syncthreads();
+    }
+    const uint64_t n_tiles = (LEVEL == 1) ? (n + kPartTile - 1) / kPartTile : ts1[nd1];
+    auto range_of = [&](uint64_t tile, uint64_t& lo, uint32_t& count, uint32_t& d1) {
+        if (LEVEL == 1) { lo = tile * kPartTile; count = uint32_t(n - lo < kPartTile ? n - lo : kPartTile); d1 = 0; }
+        else {
+            uint32_t a = 0, b = nd1;
+            while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (ts1[m] <= tile) a = m; else b = m; }
+            d1 = a;
+            lo = st1[a] + (tile - ts1[a]) * uint64_t(kPartTile);
+            const uint64_t end = st1[a + 1];
+            count = uint32_t(end - lo < kPartTile ? end - lo : kPartTile);
+        }
+    };
+    auto request = [&](uint64_t lo, uint32_t count, uint64_t (&r)[PER]) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t x = threadIdx.x + k * THREADS;
+            const uint64_t at = lo + (x < count ? x : count - 1u);
+            r[k] = (LEVEL == 1) ? hashes[at * uint64_t(hash_stride)] : in[at];
+        }
+    };
+    uint64_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    uint64_t lo; uint32_t count, d1;
+    range_of(tile, lo, count, d1);
+    uint64_t rec[PER];
+    request(lo, count, rec);
+    for (;;) {
+        const uint64_t next = tile + gridDim.x;
+        const bool more = next < n_tiles;
+        for (int k = threadIdx.x; k < kBins; k += THREADS) cnt[k] = 0;
+        __syncthreads();
+        uint32_t dr[PER];                                       // digit (9 bits) | rank in the tile's digit << 9
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t x = threadIdx.x + k * THREADS;
+            dr[k] = 0xFFFFFFFFu;                                // no record: past the tile's end, or a skipped position
+            if (x < count && (LEVEL != 1 || rec[k] != kSkipHash)) {
+                uint32_t dig;
+                if (LEVEL == 1) {
+                    const uint64_t h = rec[k];
+                    rec[k] = (uint64_t(part_q(h, g)) << 32) | (first_idx + uint32_t(lo + x));
+                    dig = bucket_of(h, g) >> g.bits2;
+                } else {
+                    dig = (uint32_t(rec[k] >> 32) >> g.seg_bits) & mask2;
+                }
+                dr[k] = dig | (atomicAdd(&cnt[dig], 1u) << 9);
+            }
+        }
+        uint64_t nlo = 0; uint32_t ncount = 0, nd = 0;
+        uint64_t nxt[PER];
+        if (PIPE && more) { range_of(next, nlo, ncount, nd); request(nlo, ncount, nxt); }
         __syncthreads();
         if (threadIdx.x < 64) {                               // exclusive scan of the counts by one wave
             constexpr int kPer = kBins / 64;
@@ -686,29 +923,42 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
             uint32_t ex = inc - s;
 #pragma unroll
             for (int k = 0; k < kPer; ++k) { lstart[threadIdx.x * kPer + k] = ex; ex += c[k]; }
+            if (threadIdx.x == 63) n_valid = inc;
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < kBins; k += kPartThreads)
+        for (int k = threadIdx.x; k < kBins; k += THREADS)
             gbase[k] = cnt[k] ? atomicAdd(&cursor[(LEVEL == 1 ? 0u : (d1 << g.bits2)) + k], cnt[k]) : 0u;
 #pragma unroll
-        for (int k = 0; k < kPartPer; ++k)
-            if (threadIdx.x + k * kPartThreads < count) {
-                const uint32_t at = lstart[dig[k]] + rank[k];
+        for (int k = 0; k < PER; ++k)
+            if (dr[k] != 0xFFFFFFFFu) {
+                const uint32_t dig = dr[k] & 511u, at = lstart[dig] + (dr[k] >> 9);
                 stage[at] = rec[k];
-                if (LEVEL == 1) sdig[at] = uint8_t(dig[k]);       // level 2 finds its digit in the record itself
+                if (LEVEL == 1) sdig[at] = uint8_t(dig);
             }
         __syncthreads();
+        const uint32_t valid = n_valid;
 #pragma unroll
-        for (int k = 0; k < kPartPer; ++k) {
-            const uint32_t r = threadIdx.x + k * kPartThreads;
-            if (r < count) {
-                const uint64_t v = stage[r];
-                const uint32_t d = (LEVEL == 1) ? uint32_t(sdig[r]) : ((uint32_t(v >> 32) >> g.seg_bits) & mask2);
-                out[gbase[d] + (r - lstart[d])] = v;      // plain stores: the short runs of neighbouring tiles combine in L2
-                if (LEVEL == 1 && digit2_out) digit2_out[gbase[d] + (r - lstart[d])] = uint8_t((uint32_t(v >> 32) >> g.seg_bits) & mask2);
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t x = threadIdx.x + k * THREADS;
+            if (x < valid) {
+                const uint64_t v = stage[x];
+                const uint32_t d = (LEVEL == 1) ? uint32_t(sdig[x]) : ((uint32_t(v >> 32) >> g.seg_bits) & mask2);
+                const uint32_t to = gbase[d] + (x - lstart[d]);
+                out[to] = v;
+                if (LEVEL == 1 && digit2_out) digit2_out[to] = uint8_t((uint32_t(v >> 32) >> g.seg_bits) & mask2);
             }
         }
         __syncthreads();
+        if (!more) break;
+        if (PIPE) {
+            lo = nlo; count = ncount; d1 = nd;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) rec[k] = nxt[k];
+        } else {
+            range_of(next, lo, count, d1);
+            request(lo, count, rec);
+        }
+        tile = next;
     }
 }
 
@@ -744,6 +994,65 @@ void bulk_hist2_kernel(const uint8_t* __restrict__ digit2_in, const uint64_t* __
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) if (h[k]) atomicAdd(&hist2[(d1 << g.bits2) + k], h[k]);
         __syncthreads();
+    }
+}
+
+// The byte-digit form of the level-2 histogram with the tile table in LDS, eight digits per load and the next
+// tile's load issued before this tile is counted.
+__global__ __launch_bounds__(kPartThreads)
+void bulk_hist2_bytes_kernel(const uint8_t* __restrict__ digit2_in, BulkGeom g, const uint32_t* __restrict__ start1,
+                             const uint32_t* __restrict__ tile_start1, uint32_t* __restrict__ hist2)
+{
+    __shared__ uint32_t h[256];
+    __shared__ uint32_t ts1[260], st1[260];
+    const uint32_t nd1 = 1u << g.bits1, nd2 = 1u << g.bits2;
+    for (uint32_t k = threadIdx.x; k <= nd1; k += kPartThreads) { ts1[k] = tile_start1[k]; st1[k] = start1[k]; }
+    __syncthreads();
+    const uint64_t n_tiles = ts1[nd1];
+    auto range_of = [&](uint64_t tile, uint64_t& lo, uint64_t& hi, uint32_t& d1) {
+        uint32_t a = 0, b = nd1;
+        while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (ts1[m] <= tile) a = m; else b = m; }
+        d1 = a;
+        lo = st1[a] + (tile - ts1[a]) * uint64_t(kPartTile);
+        hi = lo + kPartTile < st1[a + 1] ? lo + kPartTile : st1[a + 1];
+    };
+    // a tile of <= 8192 bytes starting anywhere covers <= 1025 aligned 8-byte words: word t for lane t, the last by lane 0
+    auto request = [&](uint64_t lo, uint64_t hi, uint64_t (&w)[2]) {
+        const uint64_t a0 = lo & ~7ull;
+        const uint64_t at = a0 + 8ull * threadIdx.x;
+        w[0] = at < hi ? *reinterpret_cast<const uint64_t*>(digit2_in + at) : 0ull;
+        const uint64_t at2 = a0 + 8ull * kPartThreads;
+        w[1] = (threadIdx.x == 0 && at2 < hi) ? *reinterpret_cast<const uint64_t*>(digit2_in + at2) : 0ull;
+    };
+    uint64_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    uint64_t lo, hi; uint32_t d1;
+    range_of(tile, lo, hi, d1);
+    uint64_t w[2];
+    request(lo, hi, w);
+    for (;;) {
+        const uint64_t next = tile + gridDim.x;
+        const bool more = next < n_tiles;
+        for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) h[k] = 0;
+        __syncthreads();
+        uint64_t nlo = 0, nhi = 0; uint32_t nd = 0; uint64_t nw[2] = {0, 0};
+        if (more) { range_of(next, nlo, nhi, nd); request(nlo, nhi, nw); }
+        const uint64_t a0 = lo & ~7ull;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const uint64_t at = a0 + 8ull * (part ? uint64_t(kPartThreads) : uint64_t(threadIdx.x));
+            if (part == 1 && threadIdx.x != 0) break;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint64_t idx = at + b;
+                if (idx >= lo && idx < hi) atomicAdd(&h[uint32_t(w[part] >> (8 * b)) & (nd2 - 1u) & 255u], 1u);
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) if (h[k]) atomicAdd(&hist2[(d1 << g.bits2) + k], h[k]);
+        __syncthreads();
+        if (!more) break;
+        tile = next; lo = nlo; hi = nhi; d1 = nd; w[0] = nw[0]; w[1] = nw[1];
     }
 }
 
@@ -791,7 +1100,15 @@ constexpr uint32_t kDedupChunk = 1536;                   // queue entries (candi
 constexpr uint32_t kDedupRecords = 3 * kDedupChunk;      // records per chunk: a segment's whole bucket, normally; a candidate that
                                                          // finds the queue full is verified on the spot
 constexpr uint32_t kDedupFly = 4;
-constexpr uint32_t kDedupLoads = 3;                      // records a lane fetches at once in the probe phase
+#ifndef FQD_DEDUP_LOADS
+#define FQD_DEDUP_LOADS 6
+#endif
+#ifndef FQD_DEDUP_EARLY
+#define FQD_DEDUP_EARLY 1
+#endif
+constexpr uint32_t kDedupLoads = FQD_DEDUP_LOADS;                      // records a lane fetches at once in the probe phase: a whole bucket at 512 threads, one
+                                                         // round trip (3: two round trips per bucket; the phase stamps of round 3 put 48 % of the
+                                                         // kernel's workgroup time in this phase: profiles/r03_phase_stamps_before.txt)
 
 // VL: lanes per candidate in the verify phase of uniform key stores.  VL = 4 / 8: every lane
 // loads 16 bytes of each of the two keys (keys of up to 8 / 16 words with an even word count: 150 bp
@@ -839,7 +1156,9 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
         ++lost;
     };
 
+    STAMP_DECL
     for (uint32_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
+        STAMP(0);
         unsigned long long* gseg = reinterpret_cast<unsigned long long*>(table) + uint64_t(b) * seg_slots;
         const uint32_t lo = bstart[b], hi = bstart[b + 1];
         if (!FRESH && lo == hi) continue;                     // nothing to add: leave the segment alone
@@ -850,6 +1169,13 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
             if (FRESH) for (uint32_t k = threadIdx.x; k < seg_slots; k += blockDim.x) gseg[k] = kEmptySlot;
             if (threadIdx.x == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b;
             continue;
+        }
+        // the bucket's first records are requested before the segment is set up in LDS: the fill hides in their round trip
+        uint64_t v0[kDedupLoads];
+        {
+            const uint32_t first_n = hi - lo < kDedupRecords ? hi - lo : kDedupRecords;
+#pragma unroll
+            for (uint32_t u = 0; u < kDedupLoads; ++u) { const uint32_t c = threadIdx.x + u * blockDim.x; v0[u] = (FQD_DEDUP_EARLY && first_n) ? recs[lo + (c < first_n ? c : first_n - 1u)] : 0ull; }
         }
         {   // 16 bytes per lane and access; loading an existing segment keeps four loads per lane in flight
             ulonglong2* seg2 = reinterpret_cast<ulonglong2*>(seg);
@@ -871,11 +1197,17 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
             const uint32_t chunk_n = hi - chunk_lo < kDedupRecords ? hi - chunk_lo : kDedupRecords;
             if (threadIdx.x == 0) { qn[0] = 0; qn[1] = 0; }
             __syncthreads();
+            STAMP(1);                                         // bucket bounds + segment init/load + barrier
             // 1. probe (a lane's records are all fetched before the first walk: one round trip, not several)
             for (uint32_t c0 = threadIdx.x; c0 < chunk_n; c0 += kDedupLoads * blockDim.x) {
                 uint64_t v[kDedupLoads];
+                if (FQD_DEDUP_EARLY && chunk_lo == lo && c0 == threadIdx.x) {
 #pragma unroll
-                for (uint32_t u = 0; u < kDedupLoads; ++u) { const uint32_t c = c0 + u * blockDim.x; v[u] = recs[chunk_lo + (c < chunk_n ? c : chunk_n - 1u)]; }
+                    for (uint32_t u = 0; u < kDedupLoads; ++u) v[u] = v0[u];
+                } else {
+#pragma unroll
+                    for (uint32_t u = 0; u < kDedupLoads; ++u) { const uint32_t c = c0 + u * blockDim.x; v[u] = recs[chunk_lo + (c < chunk_n ? c : chunk_n - 1u)]; }
+                }
 #pragma unroll
                 for (uint32_t u = 0; u < kDedupLoads; ++u) {
                     if (c0 + u * blockDim.x < chunk_n) {
@@ -884,7 +1216,9 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
                     }
                 }
             }
+            STAMP(2);                                         // probe, my wave
             __syncthreads();
+            STAMP(3);                                         // probe, the others
             // 2. verify: VL (or eight) lanes per candidate, kFly candidates per group in flight
             const uint32_t n_cand = qn[0] < kDedupChunk ? qn[0] : kDedupChunk;
             constexpr uint32_t kFly = RAGGED ? 3u : (VL == 4 ? 6u : kDedupFly);     // ragged keys need more registers per candidate
@@ -992,7 +1326,9 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
                     }
                 }
             }
+            STAMP(4);                                         // verify, my wave
             __syncthreads();
+            STAMP(5);                                         // verify, the others
             // 3. retry the few whose tag matched an unequal key
             const uint32_t n_tried = qn[1];
             const uint32_t n_retry = n_tried < kDedupChunk - n_cand ? n_tried : kDedupChunk - n_cand;   // the rest were settled in phase 2
@@ -1001,6 +1337,7 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
                 walk(uint32_t(ent), uint32_t(ent >> 32) >> seg_bits, uint32_t(ent >> 32) & seg_mask, true);
             }
             __syncthreads();
+            STAMP(6);                                         // retry + barrier
         }
         __syncthreads();
         {
@@ -1012,8 +1349,11 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
                 __builtin_nontemporal_store(v.y, &gseg2[k].y);
             }
         }
+        STAMP(7);                                             // write-back issue
         __syncthreads();
+        STAMP(8);                                             // barrier
     }
+    STAMP_FLUSH(2);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { dups += __shfl_down(dups, d, 64); lost += __shfl_down(lost, d, 64); }
     if ((threadIdx.x & 63) == 0) {
@@ -1205,11 +1545,15 @@ void part_count_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stride
 // lanes write consecutive words, and records bound for one owner are neighbours in the output,
 // so the stores leave as runs instead of one scattered 8-byte store per lane.
 // LDS: 256*rec_words uint64 + 256 uint64 (destinations) + n_parts*4 uint32.  rw_magic = ceil(2^32/rec_words).
+// slab_cap != 0 (fqd_partition_slabs): part p's records go to the fixed-size slab p (slots p*slab_cap ..), the ones
+// beyond its capacity to the overflow region behind the last slab, part after part; slab_of[p] = {first grouped
+// index of part p, first overflow slot of part p} (part_slab_offsets_kernel).
 __global__ __launch_bounds__(kBlock)
 void part_scatter_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t rec_words, uint32_t n_parts,
                          const uint64_t* __restrict__ starts2d, uint32_t n_blocks,
                          uint64_t* __restrict__ out, uint32_t* __restrict__ origin, uint32_t rw_magic,
-                         uint32_t strip /* 1: leave word 0 (the hash) out of the output rows */)
+                         uint32_t strip /* 1: leave word 0 (the hash) out of the output rows */,
+                         uint64_t slab_cap, const ulonglong2* __restrict__ slab_of)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t ptile[];
     uint64_t* dst_of = ptile + size_t(kBlock) * rec_words;
@@ -1239,7 +1583,12 @@ void part_scatter_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t 
     if (live) {
         uint32_t before = 0;
         for (int w = 0; w < wave; ++w) before += wave_cnt[mine * 4 + w];
-        const uint64_t dst = starts2d[uint64_t(mine) * n_blocks + blockIdx.x] + before + rank_in_wave;
+        uint64_t dst = starts2d[uint64_t(mine) * n_blocks + blockIdx.x] + before + rank_in_wave;
+        if (slab_cap) {
+            const ulonglong2 so = slab_of[mine];
+            const uint64_t local = dst - so.x;
+            dst = local < slab_cap ? uint64_t(mine) * slab_cap + local : so.y + (local - slab_cap);
+        }
         dst_of[threadIdx.x] = dst;
         origin[dst] = uint32_t(base + threadIdx.x);
     }
@@ -1247,6 +1596,21 @@ void part_scatter_kernel(const uint64_t* __restrict__ rec, uint64_t n, uint32_t 
     for (uint32_t w = threadIdx.x; w < words; w += kBlock) {
         const uint32_t r = rec_words == 1u ? w : __umulhi(w, rw_magic), k = w - r * rec_words;
         if (k >= strip) out[dst_of[r] * (rec_words - strip) + (k - strip)] = ptile[w];
+    }
+}
+
+// slab_of[p] = {first grouped index of part p, first overflow slot of part p}: parts that exceed slab_cap spill,
+// in part order, into the slots from n_parts * slab_cap on.  One thread: n_parts is the number of GPUs.
+__global__ void part_slab_offsets_kernel(const uint64_t* __restrict__ starts2d, uint32_t n_parts, uint32_t n_blocks,
+                                         uint64_t n, uint64_t slab_cap, ulonglong2* __restrict__ slab_of)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    uint64_t spill = uint64_t(n_parts) * slab_cap;
+    for (uint32_t p = 0; p < n_parts; ++p) {
+        const uint64_t lo = starts2d[uint64_t(p) * n_blocks];
+        const uint64_t hi = (p + 1 < n_parts) ? starts2d[uint64_t(p + 1) * n_blocks] : n;
+        slab_of[p] = ulonglong2{lo, spill};
+        if (hi - lo > slab_cap) spill += hi - lo - slab_cap;
     }
 }
 
@@ -1263,12 +1627,19 @@ __global__ void part_totals_kernel(const uint64_t* __restrict__ starts2d, uint32
 
 // Placement hashes of uniform keys that arrived without them (the sharded exchange sends keys only):
 // the same chains the encoders run, over the stored key words.
+// slab_cap != 0: the keys lie in slabs of slab_cap slots of which only the first slab_count[slab] hold a key (the
+// sharded exchange's fixed-size messages); the other positions get kSkipHash.
 __global__ __launch_bounds__(kBlock)
 void hash_keys_kernel(const uint64_t* __restrict__ keys, uint32_t stride, uint64_t n, uint32_t len0, uint32_t len1,
-                      uint32_t paired, uint64_t hash_and, uint64_t* __restrict__ hashes)
+                      uint32_t paired, uint64_t hash_and, uint64_t* __restrict__ hashes,
+                      uint64_t slab_cap, const uint64_t* __restrict__ slab_count)
 {
     const uint32_t w0 = seg_words(len0), W = w0 + (paired ? seg_words(len1) : 0u);
     for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
+        if (slab_cap) {
+            const uint64_t slab = i / slab_cap;
+            if (i - slab * slab_cap >= slab_count[slab]) { hashes[i] = kSkipHash; continue; }
+        }
         const uint64_t* __restrict__ p = keys + i * uint64_t(stride);
         uint64_t h = hash_begin(len0, 0), h1 = hash_begin(len1, 0);
         for (uint32_t k0 = 0; k0 < W; k0 += 8u) {             // eight words requested at a time, then chained
@@ -1291,132 +1662,10 @@ __global__ __launch_bounds__(kBlock)
 void scatter_flags_kernel(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ origin, uint64_t n,
                           uint8_t* __restrict__ keep_out)
 {
-    for (uint64_t k = blockIdx.x * uint64_t(kBlock) + threadIdx.x; k < n; k += uint64_t(gridDim.x) * kBlock)
-        keep_out[origin[k]] = flags[k];
-}
-
-// ---------------------------------------------------------------------------
-// Optimistic sharded exchange ("hashes first, keys only for candidate duplicates").
-constexpr uint64_t kNoReply = 0xFFFFFFFFFFFFFFFFull;
-
-// records[i] = [hashes[i] | payload_base + i]
-__global__ __launch_bounds__(kBlock)
-void make_hash_records_kernel(const uint64_t* __restrict__ hashes, uint64_t n, uint64_t payload_base, ulonglong2* __restrict__ out)
-{
-    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock)
-        out[i] = ulonglong2{hashes[i], payload_base + i};
-}
-
-// Owner: reply[j] = kNoReply when record first_idx+j was the first with its hash, else the payload
-// of THE first record with that hash.  first[j] names the record that beat j in the table; that
-// one may have been displaced later in the same batch by a still earlier record, so the chain is
-// followed (indices strictly fall) to the record that kept its flag or came with an earlier batch.
-__global__ __launch_bounds__(kBlock)
-void hash_replies_kernel(const ulonglong2* __restrict__ store, uint32_t first_idx, uint64_t n, const uint8_t* __restrict__ keep,
-                         const uint32_t* __restrict__ first, uint64_t* __restrict__ reply)
-{
-    for (uint64_t j = blockIdx.x * uint64_t(kBlock) + threadIdx.x; j < n; j += uint64_t(gridDim.x) * kBlock) {
-        if (keep[j]) { reply[j] = kNoReply; continue; }
-        uint32_t f = first[j];
-        while (f >= first_idx && !keep[f - first_idx]) f = first[f - first_idx];
-        reply[j] = store[f].y;
+    for (uint64_t k = blockIdx.x * uint64_t(kBlock) + threadIdx.x; k < n; k += uint64_t(gridDim.x) * kBlock) {
+        const uint32_t to = origin[k];
+        if (to != 0xFFFFFFFFu) keep_out[to] = flags[k];        // 0xFFFFFFFF: a slab slot no record went to
     }
-}
-
-__global__ __launch_bounds__(kBlock)
-void scatter_u64_kernel(const uint64_t* __restrict__ vals, const uint32_t* __restrict__ origin, uint64_t n, uint64_t* __restrict__ out)
-{
-    for (uint64_t k = blockIdx.x * uint64_t(kBlock) + threadIdx.x; k < n; k += uint64_t(gridDim.x) * kBlock)
-        out[origin[k]] = vals[k];
-}
-
-// Source: every local read whose reply names an earlier holder becomes a request
-// [reply | its own key words]; req_local remembers which read asked.  Requests keep the order of
-// the reads: a block owns kReqChunk consecutive reads, count_requests_kernel leaves the number of
-// candidates per block (scanned by the host code into block offsets), build_requests_kernel
-// ranks the candidates inside the block with wave ballots.
-constexpr uint32_t kReqChunk = kBlock * 16;
-
-__global__ __launch_bounds__(kBlock)
-void count_requests_kernel(const uint64_t* __restrict__ reply, uint64_t n, uint64_t* __restrict__ block_counts)
-{
-    __shared__ uint32_t wave_sum[kBlock / 64];
-    const uint64_t lo = blockIdx.x * uint64_t(kReqChunk);
-    uint32_t c = 0;
-    for (uint32_t t = threadIdx.x; t < kReqChunk; t += kBlock) {
-        const uint64_t i = lo + t;
-        c += (i < n && reply[i] != kNoReply) ? 1u : 0u;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
-    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (uint32_t w = 0; w < kBlock / 64; ++w) tot += wave_sum[w];
-        block_counts[blockIdx.x] = tot;
-    }
-}
-
-__global__ __launch_bounds__(kBlock)
-void build_requests_kernel(const uint64_t* __restrict__ reply, uint64_t n, uint32_t local_base, KeyStore ks,
-                           const uint64_t* __restrict__ block_offsets, uint64_t* __restrict__ req, uint32_t* __restrict__ req_local)
-{
-    __shared__ uint32_t wave_cnt[kBlock / 64];
-    const uint32_t rw = ks.W0 + 1u;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t lo = blockIdx.x * uint64_t(kReqChunk);
-    uint64_t at = block_offsets[blockIdx.x];
-    for (uint32_t t = 0; t < kReqChunk; t += kBlock) {
-        const uint64_t i = lo + t + threadIdx.x;
-        const uint64_t r = i < n ? reply[i] : kNoReply;
-        const bool cand = r != kNoReply;
-        const uint64_t mask = __ballot(cand);
-        if (lane == 0) wave_cnt[wave] = uint32_t(__popcll(mask));
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-        for (uint32_t w = 0; w < kBlock / 64; ++w) { const uint32_t c = wave_cnt[w]; before += w < wave ? c : 0u; total += c; }
-        if (cand) {
-            const uint64_t k = at + before + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
-            uint64_t* dst = req + k * rw;
-            const uint64_t* key = ks.slot(local_base + uint32_t(i));
-            dst[0] = r;
-            for (uint32_t q = 0; q < ks.W0; ++q) dst[1u + q] = key[q];
-            req_local[k] = uint32_t(i);
-        }
-        at += total;
-        __syncthreads();
-    }
-}
-
-// Holder: verdict[j] = 1 iff the carried key equals the local key the request names.
-__global__ __launch_bounds__(kBlock)
-void verify_requests_kernel(const uint64_t* __restrict__ req, uint64_t m, KeyStore ks, uint8_t* __restrict__ verdict)
-{
-    const uint32_t rw = ks.W0 + 1u;
-    for (uint64_t j = blockIdx.x * uint64_t(kBlock) + threadIdx.x; j < m; j += uint64_t(gridDim.x) * kBlock) {
-        const uint64_t* r = req + j * rw;
-        const uint64_t* key = ks.slot(uint32_t(r[0] & 0xFFFFFFFFFFull));
-        uint64_t d = 0;
-        for (uint32_t k = 0; k < ks.W0; ++k) d |= key[k] ^ r[1u + k];
-        verdict[j] = d == 0 ? 1 : 0;
-    }
-}
-
-// Source: keep[i] = 1 iff no earlier record had read i's hash; every refuted verdict (two unequal
-// keys with one 64-bit hash) is counted: the caller must then redo the step with full keys.
-__global__ __launch_bounds__(kBlock)
-void apply_replies_kernel(const uint64_t* __restrict__ reply, uint64_t n, uint8_t* __restrict__ keep,
-                          const uint8_t* __restrict__ verdict, uint64_t m, unsigned long long* __restrict__ refuted)
-{
-    uint32_t bad = 0;
-    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < (n > m ? n : m); i += uint64_t(gridDim.x) * kBlock) {
-        if (i < n) keep[i] = reply[i] == kNoReply ? 1 : 0;
-        if (i < m && !verdict[i]) ++bad;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) bad += __shfl_down(bad, d, 64);
-    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(refuted, static_cast<unsigned long long>(bad));
 }
 
 // ---------------------------------------------------------------------------

@@ -145,19 +145,6 @@ class Engine:
     def encode_uniform(self, segs: Sequence[Reads], n: int, records):
         self._check(self._L.fqd_encode_uniform(self._h, _desc_array(segs), n, _addr(records)))
 
-    def partition_records(self, records, n: int, key_words: int, n_parts: int, out, counts, origin):
-        self._check(self._L.fqd_partition_records(self._h, _addr(records), n, key_words, n_parts,
-                                                  _addr(out), _addr(counts), _addr(origin)))
-
-    def reserve_records(self, n: int, len0: int, len1: int) -> int:
-        """Device address of room for n records at the tail of the key store (receive in place)."""
-        slot = C.c_void_p()
-        self._check(self._L.fqd_reserve_records(self._h, n, len0, len1, C.byref(slot)))
-        return slot.value
-
-    def insert_records(self, records, n: int, len0: int, len1: int, keep):
-        self._check(self._L.fqd_insert_records(self._h, _addr(records), n, len0, len1, _addr(keep)))
-
     def partition_keys(self, records, n: int, key_words: int, n_parts: int, out_keys, counts, origin):
         self._check(self._L.fqd_partition_keys(self._h, _addr(records), n, key_words, n_parts,
                                                _addr(out_keys), _addr(counts), _addr(origin)))
@@ -171,43 +158,12 @@ class Engine:
     def insert_keys(self, keys, n: int, len0: int, len1: int, keep):
         self._check(self._L.fqd_insert_keys(self._h, _addr(keys), n, len0, len1, _addr(keep)))
 
-    # -- optimistic sharding (hashes first) ------------------------------------------------------
-    def encode_batch(self, segs: Sequence[Reads], n: int, hashes):
-        self._check(self._L.fqd_encode_batch(self._h, _desc_array(segs), n, _addr(hashes)))
+    def partition_slabs(self, records, n: int, key_words: int, n_parts: int, slab_cap: int, out_keys, counts, origin):
+        self._check(self._L.fqd_partition_slabs(self._h, _addr(records), n, key_words, n_parts, slab_cap,
+                                                _addr(out_keys), _addr(counts), _addr(origin)))
 
-    def make_hash_records(self, hashes, n: int, payload_base: int, out):
-        self._check(self._L.fqd_make_hash_records(self._h, _addr(hashes), n, payload_base, _addr(out)))
-
-    def reserve_hashes(self, n: int) -> int:
-        slot = C.c_void_p()
-        self._check(self._L.fqd_reserve_hashes(self._h, n, C.byref(slot)))
-        return slot.value
-
-    def insert_hashes(self, records, n: int, keep, first):
-        self._check(self._L.fqd_insert_hashes(self._h, _addr(records), n, _addr(keep), _addr(first)))
-
-    def hash_replies(self, n: int, keep, first, reply):
-        self._check(self._L.fqd_hash_replies(self._h, n, _addr(keep), _addr(first), _addr(reply)))
-
-    def scatter_u64(self, vals, origin, n: int, out):
-        self._check(self._L.fqd_scatter_u64(self._h, _addr(vals), _addr(origin), n, _addr(out)))
-
-    def build_requests(self, reply, n: int, local_base: int, req, req_capacity: int, req_local):
-        """Returns (count, fits): when the requests do not fit req_capacity nothing is written."""
-        count = C.c_uint64(0)
-        rc = self._L.fqd_build_requests(self._h, _addr(reply), n, local_base, _addr(req), req_capacity, _addr(req_local), C.byref(count))
-        if rc == _lib.ERR_CAPACITY and int(count.value) > req_capacity:
-            return int(count.value), False
-        self._check(rc)
-        return int(count.value), True
-
-    def verify_requests(self, req, m: int, verdict):
-        self._check(self._L.fqd_verify_requests(self._h, _addr(req), m, _addr(verdict)))
-
-    def apply_replies(self, reply, n: int, keep, verdict, m: int) -> int:
-        refuted = C.c_uint64(0)
-        self._check(self._L.fqd_apply_replies(self._h, _addr(reply), n, _addr(keep), _addr(verdict), m, C.byref(refuted)))
-        return int(refuted.value)
+    def insert_slabs(self, keys, n_slabs: int, slab_cap: int, slab_count, len0: int, len1: int, keep):
+        self._check(self._L.fqd_insert_slabs(self._h, _addr(keys), n_slabs, slab_cap, _addr(slab_count), len0, len1, _addr(keep)))
 
     # -- --unordered ID join ---------------------------------------------------------------
     @staticmethod

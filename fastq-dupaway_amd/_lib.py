@@ -58,7 +58,7 @@ class Profile(C.Structure):
 class ShardConfig(C.Structure):
     _fields_ = [("world", C.c_int32), ("n_local", C.c_int32), ("first_rank", C.c_int32), ("transport", C.c_int32),
                 ("round_reads", C.c_uint64), ("len0", C.c_uint32), ("len1", C.c_uint32), ("slack_permille", C.c_uint32),
-                ("reserved", C.c_uint32), ("slab_records", C.c_uint64), ("unique_id", C.c_void_p)]
+                ("flags", C.c_uint32), ("slab_records", C.c_uint64), ("unique_id", C.c_void_p)]
 
 
 class ShardStats(C.Structure):
@@ -66,7 +66,7 @@ class ShardStats(C.Structure):
                 ("slab_records", C.c_uint64), ("exchange_ms", C.c_double), ("transport", C.c_int32), ("ranks_in_comm", C.c_int32)]
 
 
-SHARD_RCCL, SHARD_COPY, SHARD_ID_BYTES = 0, 1, 128
+SHARD_RCCL, SHARD_COPY, SHARD_ID_BYTES, SHARD_PADDED, OPAQUE_KEYS = 0, 1, 128, 1, 0xFFFFFFFF
 
 
 def build_native(target: str = "all") -> None:
@@ -137,6 +137,9 @@ def load_library():
     L.fqd_reserve_keys.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
     L.fqd_insert_keys.argtypes = [vp, vp, u64, u32, u32, vp]
     L.fqd_synth_reads.argtypes = [vp, u64, u64, u64, u32, u32, i32, vp, vp]
+    L.fqd_padded_key_words.argtypes = [u32, u32]
+    L.fqd_padded_key_words.restype = u32
+    L.fqd_encode_padded.argtypes = [vp, C.POINTER(ReadsDesc), u64, u32, u32, vp]
     L.fqd_partition_slabs.argtypes = [vp, vp, u64, u32, u32, u64, vp, vp, vp]
     L.fqd_insert_slabs.argtypes = [vp, vp, u32, u64, vp, u32, u32, vp]
     L.fqd_shard_unique_id.argtypes = [vp]
@@ -153,7 +156,7 @@ def load_library():
     L.fqd_shard_last_error.restype = C.c_char_p
     for name in declared_symbols():
         fn = getattr(L, name)          # AttributeError here = header and library disagree
-        if name not in ("fqd_last_error", "fqd_key_words", "fqd_engine_stream", "fqd_bgzf_bound", "fqd_shard_last_error", "fqd_shard_slab_capacity"):
+        if name not in ("fqd_last_error", "fqd_key_words", "fqd_engine_stream", "fqd_bgzf_bound", "fqd_shard_last_error", "fqd_shard_slab_capacity", "fqd_padded_key_words"):
             fn.restype = i32
     _lib = L
     return L

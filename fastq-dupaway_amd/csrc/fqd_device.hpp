@@ -49,6 +49,7 @@ __host__ __device__ inline uint64_t hash_pair(uint64_t mate0_chain, uint64_t mat
 // kSkipHash in a batch's hash array means "no record at this position" (slab slots the sharded exchange left
 // empty): every insert path passes over it.  No record's own hash ever takes that value.
 constexpr uint64_t kSkipHash = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint32_t kOpaqueKeys = 0xFFFFFFFFu;            // FQD_OPAQUE_KEYS of the ABI: len1 of an engine whose keys are len0 opaque words
 __host__ __device__ inline uint64_t hash_end(uint64_t h)
 {
     h ^= h >> 33; h *= 0xff51afd7ed558ccdull;

@@ -67,10 +67,11 @@ struct fqd_engine {
     uint64_t cap_hint_reads = 0, cap_hint_bases = 0;
 
     DevBuf   hashes;                                 // per-batch placement hashes
+    DevBuf   pad_koff;                               // fqd_encode_padded: slot offsets of a batch
     DevBuf   scan_scratch;
     DevBuf   part_scratch;
     DevBuf   st_bases[2], st_off[2], st_len[2], st_keep;   // staging for host-space submits
-    uint64_t* d_state = nullptr;                     // [0] error word, [1] dups, [2] table-full
+    uint64_t* d_state = nullptr;                     // [0] error word, [1] dups, [2] table-full, [3] scratch, [4] reads longer than a padded key slot
     uint64_t* h_state = nullptr;                     // pinned mirror
 
     std::string last_error;
@@ -571,11 +572,13 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
 // Reads back the state words after the stream is idle and turns them into a status.
 int check_state(fqd_engine* e)
 {
-    HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->h_state, e->d_state, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (e->flags & FQD_FLAG_PROFILE) drain_profile(e);
     if (e->h_state[2] != 0)
         return e->fail(FQD_ERR_HIP, "internal: hash set overflowed its table");
+    if (e->h_state[4] != 0)
+        return e->fail(FQD_ERR_ARG, "fqd_encode_padded: a read is longer than the key width the caller set (max_len0 / max_len1)");
     if (e->h_state[0] != kNoError) {
         const uint64_t w = e->h_state[0];
         e->has_bad = true;
@@ -657,8 +660,8 @@ int fqd_engine_create(const fqd_config* cfg, fqd_engine** out)
     if (const char* v = std::getenv("FQD_BULK_MIN")) { const long long x = std::atoll(v); e->bulk_min = x >= 0 ? uint64_t(x) : ~0ull; }
     if (const char* v = std::getenv("FQD_ENC_BLOCKS_PER_CU")) e->enc_blocks_per_cu = uint32_t(std::max(1, std::atoi(v)));
     if (const char* v = std::getenv("FQD_INS_BLOCKS_PER_CU")) e->ins_blocks_per_cu = uint32_t(std::max(1, std::atoi(v)));
-    if ((err = hipMalloc(reinterpret_cast<void**>(&e->d_state), 4 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc(state)", err);
-    if ((err = hipHostMalloc(reinterpret_cast<void**>(&e->h_state), 4 * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess)
+    if ((err = hipMalloc(reinterpret_cast<void**>(&e->d_state), 8 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc(state)", err);
+    if ((err = hipHostMalloc(reinterpret_cast<void**>(&e->h_state), 8 * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc(state)", err);
     int rc = fqd_engine_reset(e);
     if (rc == FQD_OK && cfg->capacity_reads) rc = ensure_table(e, cfg->capacity_reads, true);
@@ -700,7 +703,7 @@ int fqd_engine_destroy(fqd_engine* e)
     for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
     if (e->aux) (void)hipStreamDestroy(e->aux);
     release(e->table); release(e->keys); release(e->koff); release(e->hashes);
-    release(e->scan_scratch); release(e->part_scratch); release(e->st_keep); release(e->bulk_recs); release(e->bulk_meta);
+    release(e->scan_scratch); release(e->part_scratch); release(e->pad_koff); release(e->st_keep); release(e->bulk_recs); release(e->bulk_meta);
     for (int s = 0; s < 2; ++s) { release(e->st_bases[s]); release(e->st_off[s]); release(e->st_len[s]); }
     if (e->d_state) (void)hipFree(e->d_state);
     if (e->h_state) (void)hipHostFree(e->h_state);
@@ -714,8 +717,8 @@ int fqd_engine_reset(fqd_engine* e)
     if (!e) return FQD_ERR_ARG;
     HIP_TRY(e, hipSetDevice(e->device));
     if (e->table.p && !e->table_clear) e->table_stale = true;     // cleared (or rebuilt by the bulk path) on first use
-    e->h_state[0] = kNoError; e->h_state[1] = 0; e->h_state[2] = 0; e->h_state[3] = 0;
-    HIP_TRY(e, hipMemcpyAsync(e->d_state, e->h_state, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+    e->h_state[0] = kNoError; e->h_state[1] = 0; e->h_state[2] = 0; e->h_state[3] = 0; e->h_state[4] = 0;
+    HIP_TRY(e, hipMemcpyAsync(e->d_state, e->h_state, 5 * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     e->n_records = 0; e->keys_used = 0; e->ragged = false; e->have_shape = false;
     e->L0 = e->L1 = e->W0 = 0; e->has_bad = false; e->last_error.clear();
@@ -729,6 +732,8 @@ static int submit_impl(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memo
         return e->fail(FQD_ERR_ARG, "fqd_submit: bad arguments");
     if (n == 0) return FQD_OK;
     if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
+    if (e->have_shape && e->L1 == FQD_OPAQUE_KEYS)
+        return e->fail(FQD_ERR_ARG, "fqd_submit: this engine holds opaque keys (fqd_insert_keys / fqd_insert_slabs with FQD_OPAQUE_KEYS)");
     HIP_TRY(e, hipSetDevice(e->device));
     int rc;
 
@@ -941,6 +946,38 @@ int fqd_encode_uniform(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint64_t
     return rc;
 }
 
+uint32_t fqd_padded_key_words(uint32_t max_len0, uint32_t max_len1) { return 1u + seg_words(max_len0) + seg_words(max_len1); }
+
+int fqd_encode_padded(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t max_len0, uint32_t max_len1, uint64_t* records)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!seg || (n && !records) || max_len0 == 0 || (e->S == 1 && max_len1 != 0)) return e->fail(FQD_ERR_ARG, "fqd_encode_padded: bad arguments");
+    if (n == 0) return FQD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    bool uniform = true;
+    SegView sv[2] = {{nullptr, nullptr, nullptr, 0, 0}, {nullptr, nullptr, nullptr, 0, 0}};
+    for (int s = 0; s < e->S; ++s) {
+        if (!seg_is_uniform(seg[s])) { if (!seg[s].offsets || !seg[s].lengths) return e->fail(FQD_ERR_ARG, "fqd_encode_padded: offsets and lengths go together"); uniform = false; }
+        sv[s].bases = seg[s].bases; sv[s].offsets = seg[s].offsets; sv[s].lengths = seg[s].lengths;
+        sv[s].ulen = seg[s].uniform_len; sv[s].ustride = seg[s].uniform_stride; sv[s].clamp = s ? max_len1 : max_len0;
+    }
+    const uint32_t K = fqd_padded_key_words(max_len0, e->S == 2 ? max_len1 : 0u), stride = K + 1u;
+    int rc = reserve(e, e->hashes, n * sizeof(uint64_t));
+    if (rc) return rc;
+    if ((rc = reserve(e, e->pad_koff, n * sizeof(uint64_t)))) return rc;
+    {
+        Bracket br(e, K_OTHER, 0);
+        HIP_TRY(e, hipMemsetAsync(records, 0, n * uint64_t(stride) * sizeof(uint64_t), e->stream));      // what a shorter read leaves of its slot is zeros
+        hipLaunchKernelGGL(padded_slots_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream, sv[0], sv[1], uint32_t(e->S == 2), n,
+                           max_len0, e->S == 2 ? max_len1 : 0u, stride, e->pad_koff.as<uint64_t>(), reinterpret_cast<unsigned long long*>(e->d_state + 4));
+    }
+    KeyStore ks{records, e->pad_koff.as<uint64_t>(), 0, 0, 1};
+    fqd_reads padded[2] = {seg[0], seg[1]};
+    rc = launch_encode(e, sv, uniform, padded, n, 0, ks, e->hashes.as<uint64_t>());
+    e->hashed_records = rc == FQD_OK ? records : nullptr; e->hashed_n = n; e->hashed_rec_words = stride;
+    return rc;
+}
+
 static int partition_impl(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words,
                           uint32_t n_parts, uint64_t* out, uint64_t* counts, uint32_t* origin, uint32_t strip, uint64_t slab_cap = 0);
 
@@ -1002,12 +1039,13 @@ static int partition_impl(fqd_engine* e, const uint64_t* records, uint64_t n, ui
 // engine, the keys lie back to back at the tail of its key store.
 static int prepare_keys(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1)
 {
-    if (e->S == 1 && len1 != 0) return e->fail(FQD_ERR_ARG, "keys: single-end engine given a mate-2 length");
+    const bool opaque = len1 == FQD_OPAQUE_KEYS;
+    if (e->S == 1 && len1 != 0 && !opaque) return e->fail(FQD_ERR_ARG, "keys: single-end engine given a mate-2 length");
     if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
     HIP_TRY(e, hipSetDevice(e->device));
     if (!e->have_shape) {
         e->have_shape = true; e->ragged = false;
-        e->L0 = len0; e->L1 = len1; e->W0 = seg_words(len0) + seg_words(len1);
+        e->L0 = len0; e->L1 = len1; e->W0 = opaque ? len0 : seg_words(len0) + seg_words(len1);
     } else if (e->ragged || e->L0 != len0 || e->L1 != len1)
         return e->fail(FQD_ERR_ARG, "keys: engine holds keys of another shape or layout");
     if (e->W0 == 0) return e->fail(FQD_ERR_ARG, "keys: empty keys");

@@ -37,9 +37,10 @@ struct SegView {
     const uint32_t* lengths;   // nullptr: uniform
     uint32_t        ulen;
     uint32_t        ustride;
+    uint32_t        clamp = 0xFFFFFFFFu;   // fqd_encode_padded: no read is taken longer than the key slot has room for (a longer one is an error reported apart)
     __device__ __forceinline__ const uint8_t* ptr(uint64_t i) const
     { return bases + (offsets ? offsets[i] : i * uint64_t(ustride)); }
-    __device__ __forceinline__ uint32_t len(uint64_t i) const { return lengths ? lengths[i] : ulen; }
+    __device__ __forceinline__ uint32_t len(uint64_t i) const { const uint32_t l = lengths ? lengths[i] : ulen; return l < clamp ? l : clamp; }
 };
 
 // Where keys live.  Uniform engines: key j = keys + j*stride + lead, all with
@@ -645,7 +646,9 @@ void rehash_kernel(const uint64_t* __restrict__ old_table, uint64_t old_slots,
         const uint64_t* p = ks.slot(idx);
         uint32_t l0 = len0, l1 = len1, W = ks.W0;
         if (ks.koff) { l0 = uint32_t(p[0]); l1 = uint32_t(p[0] >> 32); W = seg_words(l0) + seg_words(l1); ++p; }
-        const uint32_t w0 = seg_words(l0);
+        const bool opaque = !ks.koff && len1 == kOpaqueKeys;      // see hash_keys_kernel
+        if (opaque) paired = 0;
+        const uint32_t w0 = opaque ? W : seg_words(l0);
         uint64_t h = hash_begin(l0, 0);
         for (uint32_t k = 0; k < w0; ++k) h = hash_word(h, p[k]);
         if (paired) {                                         // second chain, then combine
@@ -1625,6 +1628,21 @@ __global__ void part_totals_kernel(const uint64_t* __restrict__ starts2d, uint32
     counts[p] = hi - lo;
 }
 
+// Key slots of fqd_encode_padded: record i = [hash][len0 | len1 << 32][key words, zeros up to the widest key]: the
+// encoders write it as a ragged slot at koff[i] (header first); a read longer than the slots have room for is counted.
+__global__ __launch_bounds__(kBlock)
+void padded_slots_kernel(SegView s0, SegView s1, uint32_t paired, uint64_t n, uint32_t max0, uint32_t max1, uint32_t stride,
+                         uint64_t* __restrict__ koff, unsigned long long* __restrict__ too_long)
+{
+    uint32_t bad = 0;
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
+        koff[i] = i * uint64_t(stride) + 1u;
+        const uint32_t l0 = s0.lengths ? s0.lengths[i] : s0.ulen, l1 = paired ? (s1.lengths ? s1.lengths[i] : s1.ulen) : 0u;
+        if (l0 > max0 || l1 > max1) ++bad;
+    }
+    if (bad) atomicAdd(too_long, static_cast<unsigned long long>(bad));
+}
+
 // Placement hashes of uniform keys that arrived without them (the sharded exchange sends keys only):
 // the same chains the encoders run, over the stored key words.
 // slab_cap != 0: the keys lie in slabs of slab_cap slots of which only the first slab_count[slab] hold a key (the
@@ -1634,7 +1652,11 @@ void hash_keys_kernel(const uint64_t* __restrict__ keys, uint32_t stride, uint64
                       uint32_t paired, uint64_t hash_and, uint64_t* __restrict__ hashes,
                       uint64_t slab_cap, const uint64_t* __restrict__ slab_count)
 {
-    const uint32_t w0 = seg_words(len0), W = w0 + (paired ? seg_words(len1) : 0u);
+    // len1 == kOpaqueKeys: the keys are len0 words of which nothing is known but that equal keys are equal words
+    // (padded keys of reads of several lengths, header word first): one chain over all of them
+    const bool opaque = len1 == kOpaqueKeys;
+    if (opaque) paired = 0;
+    const uint32_t w0 = opaque ? len0 : seg_words(len0), W = opaque ? len0 : w0 + (paired ? seg_words(len1) : 0u);
     for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
         if (slab_cap) {
             const uint64_t slab = i / slab_cap;

@@ -85,6 +85,7 @@ struct fqd_shard {
     fqd_shard_config cfg{};
     std::vector<Local> lr;
     uint32_t S = 1, K = 0;
+    bool padded = false; uint32_t own_len0 = 0, own_len1 = 0;
     uint64_t cap = 0;
     uint64_t rounds = 0;                 // rounds started
     int64_t  pending = -1;               // round whose receive side has not been finished yet
@@ -164,7 +165,7 @@ int exchange_forward(fqd_shard* s, uint64_t k)
     for (Local& l : s->lr) {
         Round& r = l.rb[k & 1];
         SH_HIP(s, hipSetDevice(l.device));
-        SH_ENG(s, l, fqd_reserve_keys(l.e, uint64_t(W) * s->cap, s->cfg.len0, s->cfg.len1, &r.slot));
+        SH_ENG(s, l, fqd_reserve_keys(l.e, uint64_t(W) * s->cap, s->own_len0, s->own_len1, &r.slot));
         SH_HIP(s, hipEventRecord(r.t0, l.cs));
     }
     std::vector<Xfer> xs;
@@ -250,14 +251,14 @@ int finish_receive(fqd_shard* s, uint64_t k)
         SH_HIP(s, hipSetDevice(l.device));
         if (!r.compact) {
             SH_HIP(s, hipStreamWaitEvent(l.es, r.ev_xchg, 0));
-            SH_ENG(s, l, fqd_insert_slabs(l.e, r.slot, uint32_t(W), cap, r.d_counts + W, s->cfg.len0, s->cfg.len1, r.keep_recv));
+            SH_ENG(s, l, fqd_insert_slabs(l.e, r.slot, uint32_t(W), cap, r.d_counts + W, s->own_len0, s->own_len1, r.keep_recv));
             r.n_inserted = uint64_t(W) * cap;
         } else {
             // this owner received a spill: the round is laid out again, exactly, in (source, position) order
             const uint64_t total = fqd_plan::owner_records(r.h_counts + W, uint32_t(W), cap);
             SH_HIP(s, hipStreamWaitEvent(l.es, r.ev_spill, 0));
             uint64_t* slot = nullptr;
-            SH_ENG(s, l, fqd_reserve_keys(l.e, total, s->cfg.len0, s->cfg.len1, &slot));
+            SH_ENG(s, l, fqd_reserve_keys(l.e, total, s->own_len0, s->own_len1, &slot));
             uint64_t at = 0, spill_at = uint64_t(W) * cap;
             for (int p = 0; p < W; ++p) {
                 const uint64_t c = r.h_counts[W + p], head = std::min(c, cap);
@@ -268,7 +269,7 @@ int finish_receive(fqd_shard* s, uint64_t k)
                     at += c - cap; spill_at += c - cap;
                 }
             }
-            if (total) SH_ENG(s, l, fqd_insert_keys(l.e, slot, total, s->cfg.len0, s->cfg.len1, r.keep_recv));
+            if (total) SH_ENG(s, l, fqd_insert_keys(l.e, slot, total, s->own_len0, s->own_len1, r.keep_recv));
             r.n_inserted = total;
         }
         SH_HIP(s, hipEventRecord(r.ev_ins, l.es));
@@ -384,8 +385,11 @@ int fqd_shard_create(fqd_engine* const* engines, const fqd_shard_config* cfg, fq
     *out = nullptr;
     fqd_shard* s = new fqd_shard();
     s->cfg = *cfg;
-    s->K = fqd_key_words(cfg->len0, cfg->len1);
+    s->padded = (cfg->flags & FQD_SHARD_PADDED) != 0;
+    s->K = s->padded ? fqd_padded_key_words(cfg->len0, cfg->len1) : fqd_key_words(cfg->len0, cfg->len1);
     s->S = cfg->len1 ? 2u : 1u;
+    s->own_len0 = s->padded ? s->K : cfg->len0;                   // what the owners' engines are told their keys are
+    s->own_len1 = s->padded ? FQD_OPAQUE_KEYS : cfg->len1;
     s->cap = fqd_shard_slab_capacity(cfg->round_reads, cfg->world, cfg->slack_permille);
     if (cfg->slab_records) s->cap = cfg->slab_records;
     bool distinct = true;
@@ -477,13 +481,16 @@ int fqd_shard_round(fqd_shard* s, const fqd_reads* seg, const uint64_t* n, uint8
         if (n[a] && !keep[a]) return s->fail(FQD_ERR_ARG, "fqd_shard_round: null keep");
         for (uint32_t m = 0; m < s->S; ++m) {
             const fqd_reads& x = seg[a * s->S + m];
-            if (n[a] && (x.offsets || x.lengths || x.uniform_len != (m ? s->cfg.len1 : s->cfg.len0)))
-                return s->fail(FQD_ERR_ARG, "fqd_shard_round: reads of the group's fixed length(s), equally spaced, are expected");
+            if (n[a] && !s->padded && (x.offsets || x.lengths || x.uniform_len != (m ? s->cfg.len1 : s->cfg.len0)))
+                return s->fail(FQD_ERR_ARG, "fqd_shard_round: reads of the group's fixed length(s), equally spaced, are expected (FQD_SHARD_PADDED takes any)");
+            if (n[a] && s->padded && !x.lengths && x.uniform_len > (m ? s->cfg.len1 : s->cfg.len0))
+                return s->fail(FQD_ERR_ARG, "fqd_shard_round: reads longer than the group's maximum");
         }
         SH_HIP(s, hipSetDevice(l.device));
         if (r.used) SH_HIP(s, hipStreamWaitEvent(l.es, r.ev_done, 0));     // round k-2 has left these buffers
         r.used = true; r.n = n[a]; r.keep_dst = keep[a]; r.compact = false;
-        SH_ENG(s, l, fqd_encode_uniform(l.e, seg + a * s->S, n[a], l.records));
+        if (s->padded) SH_ENG(s, l, fqd_encode_padded(l.e, seg + a * s->S, n[a], s->cfg.len0, s->cfg.len1, l.records));
+        else           SH_ENG(s, l, fqd_encode_uniform(l.e, seg + a * s->S, n[a], l.records));
         SH_ENG(s, l, fqd_partition_slabs(l.e, l.records, n[a], s->K, uint32_t(W), s->cap, r.grouped, r.d_counts, r.origin));
         SH_HIP(s, hipMemcpyAsync(r.h_counts, r.d_counts, size_t(W) * 8, hipMemcpyDeviceToHost, l.es));
         SH_HIP(s, hipMemcpyAsync(r.h_bad, fqd_internal_state(l.e), 8, hipMemcpyDeviceToHost, l.es));     // first bad byte so far, this round's encoder included

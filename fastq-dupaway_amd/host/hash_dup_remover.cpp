@@ -441,8 +441,9 @@ void HashDupRemover::run_ordered(int S, const std::string* in, const std::string
 // group of include/fqdupaway.h (fqd_shard_*; csrc/fqd_shard.hip) — the same code bench.py measures with one process
 // per GPU.  A round deals the next batches to the ranks in file order (global order = round, rank, position), the
 // group moves the keys to their owners in fixed-size slabs over RCCL (FQD_EXCHANGE=copy: peer copies) and brings the
-// flags back; rounds are pipelined, so the writers get round k-1 while round k is on the GPUs.  Needs fixed-length
-// reads in equally spaced records (what travels are fixed-size keys); anything else is refused with a clear message.
+// flags back; rounds are pipelined, so the writers get round k-1 while round k is on the GPUs.  What travels are
+// fixed-size keys: of exactly the reads' length when the first round's reads all have one (per mate), otherwise
+// (trimmed reads) padded to the longest read of the first round, rounded up (include/fqdupaway.h, fqd_encode_padded).
 void HashDupRemover::run_ordered_multi(int S, const std::string* in, const std::string* out)
 {
     const std::vector<int>& devs = tuning_.devices;
@@ -485,7 +486,9 @@ void HashDupRemover::run_ordered_multi(int S, const std::string* in, const std::
 
     uint64_t next_index = 0, total_dups = 0;
     bool bad_base = false; uint8_t bad_byte = 0; uint64_t bad_at = ~0ull;
-    uint32_t len0 = 0, len1 = 0; bool have_shape = false;
+    // the group's key shape is fixed by the first round: one length per mate everywhere -> fixed-size keys of exactly that
+    // length; anything else (trimmed reads) -> keys padded to the longest read seen there, rounded up (FQD_SHARD_PADDED)
+    uint32_t len0 = 0, len1 = 0; bool have_shape_of[2] = {false, false}; bool all_uniform = true, padded = false;
     constexpr size_t kMaxBatch = 8u << 20;
     size_t round_reads = kMaxBatch;                            // most records a rank brings to a round: fixed when the group is made
     std::vector<Work*> round, previous;                        // this round's batch per rank (null: none), last round's
@@ -496,8 +499,9 @@ void HashDupRemover::run_ordered_multi(int S, const std::string* in, const std::
     auto deliver = [&](std::vector<Work*>& batch, uint64_t round_no) {
         const int rc = fqd_shard_wait(shard.g, round_no);
         if (rc == FQD_ERR_BAD_BASE) {
+            // the engines remember their first bad byte for good: only the first round that reports one places the cut
             int32_t lr = 0; uint64_t rec = 0; uint32_t sg = 0, pos = 0; uint8_t byte = 0;
-            if (fqd_shard_bad_base(shard.g, round_no, &lr, &rec, &sg, &pos, &byte) == FQD_OK && batch[size_t(lr)]) {
+            if (!bad_base && fqd_shard_bad_base(shard.g, round_no, &lr, &rec, &sg, &pos, &byte) == FQD_OK && batch[size_t(lr)]) {
                 bad_base = true; bad_byte = byte; bad_at = batch[size_t(lr)]->first_index + rec;
             }
         } else shard_ok(rc);
@@ -536,26 +540,45 @@ void HashDupRemover::run_ordered_multi(int S, const std::string* in, const std::
                     const RecordRef* rr = &b->recs[side[s].pos];
                     const uint64_t text_lo = rr[0].start, text_hi = rr[n - 1].start + rr[n - 1].size;
                     const uint64_t stride = n > 1 ? rr[1].seq_start() - rr[0].seq_start() : rr[0].size;
-                    bool uniform = stride <= 0xFFFFFFFFull;
-                    for (size_t i = 1; i < n && uniform; ++i)
-                        uniform = rr[i].seq_len == rr[0].seq_len && rr[i].seq_start() - rr[i - 1].seq_start() == stride;
-                    const uint32_t L = rr[0].seq_len;
-                    if (!uniform || L == 0 || (have_shape && L != (s ? len1 : len0))) {
+                    bool uniform = stride <= 0xFFFFFFFFull && rr[0].seq_len > 0;
+                    uint32_t longest = rr[0].seq_len;
+                    for (size_t i = 1; i < n; ++i) {
+                        uniform = uniform && rr[i].seq_len == rr[0].seq_len && rr[i].seq_start() - rr[i - 1].seq_start() == stride;
+                        longest = std::max(longest, rr[i].seq_len);
+                    }
+                    // what the group was made for: one fixed length per mate, or (padded keys) anything up to a maximum
+                    const char* refuse = nullptr;
+                    if (shard.g && !padded && (!uniform || rr[0].seq_len != (s ? len1 : len0)))
+                        refuse = "FQD_DEVICES: the first blocks held reads of one fixed length, a later one does not: run again with FQD_SHARD_PADDED=1";
+                    if (shard.g && padded && longest > (s ? len1 : len0))
+                        refuse = "FQD_DEVICES: a read longer than any in the first blocks turned up: run again with FQD_SHARD_MAX_LEN=<longest read>";
+                    if (refuse) {
                         for (int q = 0; q <= s; ++q) w->blk[q]->release();
                         k.pool.push(w);
-                        throw std::runtime_error("FQD_DEVICES: sharding over several GPUs needs reads of one fixed length in equally "
-                                                 "spaced records; this input is not (run it on one GPU: unset FQD_DEVICES)");
+                        throw std::runtime_error(refuse);
                     }
-                    if (!have_shape) (s ? len1 : len0) = L;
+                    if (!shard.g) {
+                        all_uniform = all_uniform && uniform && (!have_shape_of[s] || rr[0].seq_len == (s ? len1 : len0));
+                        have_shape_of[s] = true;
+                        (s ? len1 : len0) = std::max(s ? len1 : len0, longest);
+                    }
                     w->d_text[s].reserve(text_hi - text_lo + 32);
                     HIP_OK(hipMemcpyAsync(w->d_text[s].p, b->text.p + text_lo, text_hi - text_lo, hipMemcpyHostToDevice, k.stream));
                     fqd_reads& d = seg[size_t(r) * size_t(S) + size_t(s)];
                     d = fqd_reads{};
-                    d.bases = reinterpret_cast<const uint8_t*>(w->d_text[s].p) + (rr[0].seq_start() - text_lo);
-                    d.uniform_len = L; d.uniform_stride = static_cast<uint32_t>(stride);
+                    if (uniform) {
+                        d.bases = reinterpret_cast<const uint8_t*>(w->d_text[s].p) + (rr[0].seq_start() - text_lo);
+                        d.uniform_len = rr[0].seq_len; d.uniform_stride = static_cast<uint32_t>(stride);
+                    } else {
+                        w->off[s].reserve(n); w->len[s].reserve(n); w->d_off[s].reserve(n); w->d_len[s].reserve(n);
+                        for (size_t i = 0; i < n; ++i) { w->off[s].p[i] = rr[i].seq_start() - text_lo; w->len[s].p[i] = rr[i].seq_len; }
+                        HIP_OK(hipMemcpyAsync(w->d_off[s].p, w->off[s].p, n * sizeof(uint64_t), hipMemcpyHostToDevice, k.stream));
+                        HIP_OK(hipMemcpyAsync(w->d_len[s].p, w->len[s].p, n * sizeof(uint32_t), hipMemcpyHostToDevice, k.stream));
+                        d.bases = reinterpret_cast<const uint8_t*>(w->d_text[s].p);
+                        d.offsets = w->d_off[s].p; d.lengths = w->d_len[s].p;
+                    }
                     side[s].pos += n;
                 }
-                have_shape = true;
                 round[size_t(r)] = w; n_of[size_t(r)] = n; keep_of[size_t(r)] = w->d_keep.p;
                 next_index += n;
                 any = true;
@@ -573,6 +596,14 @@ void HashDupRemover::run_ordered_multi(int S, const std::string* in, const std::
                 size_t most = 0;
                 for (uint64_t x : n_of) most = std::max<size_t>(most, size_t(x));
                 round_reads = std::min(kMaxBatch, most + most / 4 + 1024);
+                const char* force = std::getenv("FQD_SHARD_PADDED");
+                padded = !all_uniform || (force && force[0] == '1');
+                if (padded) {
+                    // room to spare above the longest read of the first blocks: a whole 32-base group costs one key word
+                    len0 = (len0 + 31u) / 32u * 32u; len1 = (len1 + 31u) / 32u * 32u;
+                    if (const char* v = std::getenv("FQD_SHARD_MAX_LEN")) { const uint32_t x = uint32_t(std::strtoul(v, nullptr, 10)); len0 = std::max(len0, x); if (S == 2) len1 = std::max(len1, x); }
+                    cfg.flags |= FQD_SHARD_PADDED;
+                }
                 cfg.round_reads = round_reads; cfg.len0 = len0; cfg.len1 = S == 2 ? len1 : 0;
                 if (const char* v = std::getenv("FQD_SHARD_SLAB")) cfg.slab_records = std::strtoull(v, nullptr, 10);    // tests: force slab overflows
                 if (tuning_.use_rccl) { if (fqd_shard_unique_id(id) != FQD_OK) throw std::runtime_error(std::string("GPU exchange: ") + fqd_shard_last_error(nullptr)); cfg.unique_id = id; }

@@ -23,7 +23,9 @@ class ShardGroup:
     """The ranks of a shard group that live in this process.  engines: one Engine per local rank."""
 
     def __init__(self, engines: Sequence[Engine], world: int, first_rank: int, round_reads: int, len0: int, len1: int = 0,
-                 transport: str = "rccl", uid: Optional[bytes] = None, slack_permille: int = 0, slab_records: int = 0):
+                 transport: str = "rccl", uid: Optional[bytes] = None, slack_permille: int = 0, slab_records: int = 0,
+                 padded: bool = False):
+        """padded: len0/len1 are the longest reads allowed and batches may hold reads of any lengths up to them."""
         self._L = load_library()
         self.engines = list(engines)
         self.world, self.first_rank, self.S = world, first_rank, (2 if len1 else 1)
@@ -31,7 +33,7 @@ class ShardGroup:
         cfg = _lib.ShardConfig(world=world, n_local=len(self.engines), first_rank=first_rank,
                                transport=_lib.SHARD_RCCL if transport == "rccl" else _lib.SHARD_COPY,
                                round_reads=round_reads, len0=len0, len1=len1, slack_permille=slack_permille,
-                               slab_records=slab_records,
+                               flags=_lib.SHARD_PADDED if padded else 0, slab_records=slab_records,
                                unique_id=C.cast(self._uid, C.c_void_p) if self._uid is not None else None)
         handles = (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
         h = C.c_void_p()
@@ -54,7 +56,7 @@ class ShardGroup:
             for m in range(self.S):
                 s = segs[r][m]
                 d = arr[r * self.S + m]
-                d.bases, d.offsets, d.lengths = _addr(s.bases), None, None
+                d.bases, d.offsets, d.lengths = _addr(s.bases), _addr(s.offsets), _addr(s.lengths)
                 d.uniform_len, d.uniform_stride = s.uniform_len, s.uniform_stride
         ns = (C.c_uint64 * nl)(*[int(x) for x in n])
         ks = (C.c_void_p * nl)(*[_addr(k) for k in keep])

@@ -147,6 +147,16 @@ uint32_t fqd_key_words(uint32_t len0, uint32_t len1);
  * record i = [hash, key words...].  Does not touch the set (any engine of the right `segments` serves). */
 int  fqd_encode_uniform(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint64_t* records);
 
+/* The same for reads of SEVERAL lengths (trimmed reads; any descriptors, ragged or uniform): record i = [hash,
+ * len0 | len1 << 32, key words..., zeros] with every key padded to the width of the longest read the caller allows
+ * (max_len0, max_len1): fqd_padded_key_words(max_len0, max_len1) words after the hash.  Equal padded keys <=> equal
+ * sequences of equal lengths, so such records travel through the fixed-size exchange like any others; their owner
+ * holds them as opaque keys: fqd_reserve_keys / fqd_insert_keys / fqd_insert_slabs with len0 = fqd_padded_key_words(..)
+ * and len1 = FQD_OPAQUE_KEYS.  A read longer than the maxima is an error (FQD_ERR_ARG at the next fqd_engine_sync). */
+#define FQD_OPAQUE_KEYS 0xFFFFFFFFu
+uint32_t fqd_padded_key_words(uint32_t max_len0, uint32_t max_len1);
+int  fqd_encode_padded(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t max_len0, uint32_t max_len1, uint64_t* records);
+
 /* Stable partition of n records by owner = (hash >> 40) % n_parts: `out_keys` gets the KEY WORDS of the records
  * grouped by owner in input order (the hash is left out: 8 bytes less per record on the wire; the owner recomputes
  * it), `counts` (device, n_parts uint64) the group sizes, `origin` (device, n uint32) the input position of each
@@ -190,6 +200,7 @@ typedef struct fqd_shard fqd_shard;
 #define FQD_SHARD_ID_BYTES 128
 #define FQD_SHARD_RCCL 0    /* ncclSend/ncclRecv in one group per exchange: a direct all-to-all over xGMI */
 #define FQD_SHARD_COPY 1    /* peer copies; every rank must live in this process (always used when ranks share a GPU) */
+#define FQD_SHARD_PADDED 1u /* fqd_shard_config.flags: reads of several lengths, exchanged as padded keys (fqd_encode_padded) */
 
 typedef struct fqd_shard_config {
     int32_t  world;            /* ranks of the job                                                        */
@@ -197,9 +208,10 @@ typedef struct fqd_shard_config {
     int32_t  first_rank;       /* global rank of engines[0]                                                */
     int32_t  transport;        /* FQD_SHARD_RCCL / FQD_SHARD_COPY                                          */
     uint64_t round_reads;      /* most records (pairs) one rank brings to a round                          */
-    uint32_t len0, len1;       /* the job's fixed read lengths (len1 = 0: single-end)                      */
+    uint32_t len0, len1;       /* the job's fixed read lengths (len1 = 0: single-end); with FQD_SHARD_PADDED the
+                                  longest reads allowed: batches of any lengths up to them, ragged or uniform */
     uint32_t slack_permille;   /* slab capacity over a fair share, 0 = 30                                  */
-    uint32_t reserved;
+    uint32_t flags;            /* FQD_SHARD_PADDED                                                         */
     uint64_t slab_records;     /* 0 = fqd_shard_slab_capacity(...); tests force overflows with a small one */
     const uint8_t* unique_id;  /* RCCL: FQD_SHARD_ID_BYTES from fqd_shard_unique_id, the same in every process */
 } fqd_shard_config;

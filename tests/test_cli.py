@@ -631,13 +631,58 @@ def test_multi_gpu_cli_errors(exe, oracle, tmp_path):
     assert r.stderr == ("Error: unknown character in DNA sequence: x\nAn error occured during fastq-dupaway execution:\n"
                         "Supported sequence character set: {A, N, C, G, T}!\n")
     assert got.read_bytes() == exp.read_bytes()
-    # reads of several lengths cannot be sharded: refused, not mangled
     rag = tmp_path / "ragged.fq"
     rag.write_bytes(fastq([(b"a", b"ACGT"), (b"b", b"ACGTA"), (b"c", b"ACG")]))
-    r = run(exe, "-i", rag, "-o", tmp_path / "o.fq", "--fast", env={"FQD_DEVICES": "0,0"})
-    assert r.returncode == 1 and "FQD_DEVICES" in r.stderr and "fixed length" in r.stderr
     r = run(exe, "-i", rag, "-o", tmp_path / "o.fq", "--fast", env={"FQD_DEVICES": "0,x"})
     assert r.returncode == 1 and "FQD_DEVICES" in r.stderr
+    # the key shape is fixed by the first round of blocks: what does not fit it later is refused with the way out, not mangled
+    recs = [(b"u%05d" % k, bytes(rnd.choice(b"ACGT") for _ in range(60))) for k in range(40000)]
+    recs[35000] = (recs[35000][0], recs[35000][1][:41])
+    late = tmp_path / "late.fq"; late.write_bytes(fastq(recs))
+    r = run(exe, "-i", late, "-o", tmp_path / "o.fq", "--fast", env={"FQD_DEVICES": "0,0", "FQD_BLOCK_MB": "1"})
+    assert r.returncode == 1 and "FQD_SHARD_PADDED=1" in r.stderr
+    tot, dup = oracle.filter_single(late, exp, FASTQ)
+    r = run(exe, "-i", late, "-o", got, "--fast", "-v", env={"FQD_DEVICES": "0,0", "FQD_BLOCK_MB": "1", "FQD_SHARD_PADDED": "1"})
+    assert r.returncode == 0 and got.read_bytes() == exp.read_bytes(), r.stderr
+    recs[35000] = (recs[35000][0], recs[35000][1] + b"ACGTACGTAC")                      # 70 > 64 = the first round's 60 rounded up
+    recs[100] = (recs[100][0], recs[100][1][:33])                                           # (the first round is ragged: padded keys)
+    late.write_bytes(fastq(recs))
+    r = run(exe, "-i", late, "-o", tmp_path / "o.fq", "--fast", env={"FQD_DEVICES": "0,0", "FQD_BLOCK_MB": "1"})
+    assert r.returncode == 1 and "FQD_SHARD_MAX_LEN" in r.stderr
+    tot, dup = oracle.filter_single(late, exp, FASTQ)
+    r = run(exe, "-i", late, "-o", got, "--fast", "-v", env={"FQD_DEVICES": "0,0", "FQD_BLOCK_MB": "1", "FQD_SHARD_MAX_LEN": "70"})
+    assert r.returncode == 0 and got.read_bytes() == exp.read_bytes(), r.stderr
+
+
+def trimmed_fastq(rnd, n, lo, hi, pool, ident):
+    seqs = [bytes(rnd.choice(b"ACGTN") for _ in range(rnd.randint(lo, hi))) for _ in range(pool)]
+    return fastq([(ident(k), rnd.choice(seqs)) for k in range(n)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,slab", [("0,0", ""), ("0,0,0,0", "32"), ("0", "")])
+def test_multi_gpu_cli_trimmed_reads(exe, oracle, tmp_path, devices, slab):
+    """Reads of lengths 30..160: the multi-GPU run takes them as padded keys; single-end and
+    paired, same bytes and -v lines as the oracle."""
+    rnd = random.Random(91)
+    src = tmp_path / "in.fq"
+    src.write_bytes(trimmed_fastq(rnd, 50000, 30, 160, 8000, lambda k: b"t%07d" % k))
+    exp, got = tmp_path / "exp.fq", tmp_path / "got.fq"
+    tot, dup = oracle.filter_single(src, exp, FASTQ)
+    env = {"FQD_DEVICES": devices, "FQD_EXCHANGE": "copy", "FQD_BLOCK_MB": "1", "FQD_SHARD_SLAB": slab}
+    r = run(exe, "-i", src, "-o", got, "--fast", "-v", env=env)
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(got, exp, shallow=False)
+    assert r.stdout == f"{tot} reads processed, out of which {dup} duplicates were removed.\n" and dup > 5000
+    f1, f2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    f1.write_bytes(trimmed_fastq(rnd, 30000, 30, 160, 2500, lambda k: b"p%06d/1" % k))
+    f2.write_bytes(trimmed_fastq(rnd, 30000, 40, 120, 30, lambda k: b"p%06d/2" % k))
+    e1, e2, g1, g2 = (tmp_path / x for x in ("e1.fq", "e2.fq", "g1.fq", "g2.fq"))
+    tot, dup, _ = oracle.filter_paired(f1, f2, e1, e2, FASTQ)
+    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "-v", env=env)
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(g1, e1, shallow=False) and filecmp.cmp(g2, e2, shallow=False)
+    assert r.stdout == f"{tot} read pairs processed, out of which {dup} duplicates were removed.\n" and dup > 500
 
 
 # ---------------------------------------------------------------- GPU: error behaviour (SURVEY Appendix A, C)

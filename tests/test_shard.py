@@ -279,3 +279,75 @@ class _Words:
 
     def __init__(self, ptr, n_words):
         self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i8", "data": (ptr, False), "version": 3, "strides": None}
+
+
+@pytest.mark.parametrize("world,paired,slab", [(2, False, 0), (3, True, 0), (4, False, 64), (1, True, 0)])
+def test_shard_group_reads_of_several_lengths(oracle, world, paired, slab):
+    """Trimmed reads (lengths 30..160, ragged descriptors) through the exchange as padded keys (FQD_SHARD_PADDED):
+    the flags must equal the oracle's on the global order, also when every slab spills and with a uniform batch
+    in between."""
+    from fastq_dupaway_amd import Engine, Reads
+    from fastq_dupaway_amd.shard import ShardGroup
+    S = 2 if paired else 1
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(17 + world)
+    rounds, n_per, max_len = 3, 12000, (160, 130)
+    pool = [rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=(n_per // 3, max_len[m]), p=[.245, .245, .245, .245, .02]) for m in range(S)]
+    batches = {}
+    for k in range(rounds):
+        for r in range(world):
+            pick = rng.integers(0, n_per // 3, n_per)
+            per_mate = []
+            for m in range(S):
+                # a third of the pool rows are cut to a length drawn per ROW (so copies stay copies), lengths 30..max
+                row_len = (np.abs(np.arange(n_per // 3) * 2654435761 % (max_len[m] - 29)) + 30).astype(np.uint32)
+                lens = row_len[pick] if not (k == 1 and r == 0) else np.full(n_per, max_len[m], np.uint32)     # one uniform batch
+                offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+                flat = np.concatenate([pool[m][pick[i], : lens[i]] for i in range(n_per)] + [np.zeros(16, np.uint8)])
+                per_mate.append((flat, offs, lens))
+            batches[(k, r)] = per_mate
+    engines = [Engine(segments=S) for _ in range(world)]
+    keeps = {key: torch.full((n_per,), 9, dtype=torch.uint8, device=dev) for key in batches}
+    dev_b = {key: [(torch.from_numpy(f).to(dev), torch.from_numpy(o.view(np.int64)).to(dev), torch.from_numpy(l.view(np.int32)).to(dev)) for f, o, l in v] for key, v in batches.items()}
+    with ShardGroup(engines, world=world, first_rank=0, round_reads=n_per, len0=max_len[0], len1=max_len[1] if paired else 0,
+                    transport="copy", padded=True, slab_records=slab) as g:
+        for k in range(rounds):
+            segs = []
+            for r in range(world):
+                if k == 1 and r == 0:
+                    segs.append([Reads(dev_b[(k, r)][m][0], uniform_len=max_len[m], uniform_stride=max_len[m]) for m in range(S)])
+                else:
+                    segs.append([Reads(dev_b[(k, r)][m][0], offsets=dev_b[(k, r)][m][1], lengths=dev_b[(k, r)][m][2]) for m in range(S)])
+            g.round(segs, [n_per] * world, [keeps[(k, r)] for r in range(world)])
+        g.flush()
+        if slab:
+            assert all(g.stats(r)["overflow_rounds"] == rounds for r in range(world))
+    for e in engines:
+        e.close()
+    order = [(k, r) for k in range(rounds) for r in range(world)]
+    cat = []
+    for m in range(S):
+        flat = np.concatenate([batches[key][m][0][:-16] for key in order] + [np.zeros(16, np.uint8)])
+        lens = np.concatenate([batches[key][m][2] for key in order])
+        offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+        cat.append((flat, offs, lens))
+    exp = oracle.dedup_paired(*cat[0], *cat[1]) if paired else oracle.dedup_single(*cat[0])
+    got = np.concatenate([keeps[key].cpu().numpy() for key in order])
+    assert np.array_equal(got, exp), f"{int((got != exp).sum())} flags differ"
+    assert 0 < int((exp == 0).sum()) < len(exp)
+
+
+def test_shard_group_refuses_a_read_longer_than_its_maximum():
+    from fastq_dupaway_amd import Engine, Reads, FqdError
+    from fastq_dupaway_amd.shard import ShardGroup
+    dev = torch.device("cuda", 0)
+    n = 1000
+    lens = torch.full((n,), 40, dtype=torch.int32, device=dev); lens[777] = 90
+    offs = (torch.arange(n, dtype=torch.int64, device=dev) * 100)
+    bases = torch.full((n * 100 + 16,), ord("A"), dtype=torch.uint8, device=dev)
+    keep = torch.zeros(n, dtype=torch.uint8, device=dev)
+    with Engine(segments=1) as e, ShardGroup([e], world=1, first_rank=0, round_reads=n, len0=64, transport="copy", padded=True) as g:
+        g.round([[Reads(bases, offsets=offs, lengths=lens)]], [n], [keep])
+        with pytest.raises(FqdError) as ei:
+            g.flush()
+        assert ei.value.code == 1 and "longer" in str(ei.value)

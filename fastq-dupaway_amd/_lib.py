@@ -140,6 +140,10 @@ def load_library():
     L.fqd_padded_key_words.argtypes = [u32, u32]
     L.fqd_padded_key_words.restype = u32
     L.fqd_encode_padded.argtypes = [vp, C.POINTER(ReadsDesc), u64, u32, u32, vp]
+    L.fqd_sample_tags.argtypes = [vp, C.POINTER(TagsDesc), u32, u32, vp, vp]
+    L.fqd_classify_tags.argtypes = [vp, C.POINTER(TagsDesc), vp, u32, vp, u32, vp]
+    L.fqd_range_keep.argtypes = [vp, vp, u64, u32, vp, C.POINTER(u64)]
+    L.fqd_max_u32.argtypes = [vp, vp, u64, C.POINTER(u32)]
     L.fqd_partition_slabs.argtypes = [vp, vp, u64, u32, u32, u64, vp, vp, vp]
     L.fqd_insert_slabs.argtypes = [vp, vp, u32, u64, vp, u32, u32, vp]
     L.fqd_shard_unique_id.argtypes = [vp]

@@ -646,6 +646,71 @@ void count_le_kernel(fqd_tags t, const uint8_t* __restrict__ probe, uint32_t pro
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, static_cast<unsigned long long>(c));
 }
 
+// ---- `--unordered` over several GPUs (host: run_unordered_multi): records are dealt to the GPU that owns their tag's
+// RANGE (splitters picked from a sample of tags), so that every GPU joins a contiguous stretch of the tag order.
+// range of a tag = number of splitters that are < the tag (FastqViewWithId::cmp order; splitters ascending): equal tags
+// always share a range.
+__device__ __forceinline__ bool tag_less(const uint8_t* __restrict__ a, uint32_t la, const uint8_t* __restrict__ b, uint32_t lb)
+{
+    const uint32_t m = la < lb ? la : lb;
+    uint32_t k = 0;
+    while (k < m && a[k] == b[k]) ++k;
+    return k < m ? a[k] < b[k] : la < lb;
+}
+
+__global__ __launch_bounds__(kBlock)
+void classify_tags_kernel(fqd_tags t, const uint8_t* __restrict__ split_bytes, uint32_t split_stride, const uint32_t* __restrict__ split_len,
+                          uint32_t n_split, uint32_t* __restrict__ range_out)
+{
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < t.n; i += uint64_t(gridDim.x) * kBlock) {
+        const uint8_t* __restrict__ a = t.bytes + t.offsets[i];
+        const uint32_t L = t.lengths[i];
+        uint32_t lo = 0, hi = n_split;                       // splitters [0, lo) are < tag, [hi, n) are not
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (tag_less(split_bytes + uint64_t(mid) * split_stride, split_len[mid], a, L)) lo = mid + 1; else hi = mid;
+        }
+        range_out[i] = lo;
+    }
+}
+
+__global__ __launch_bounds__(kBlock)
+void range_keep_kernel(const uint32_t* __restrict__ range, uint64_t n, uint32_t which, uint8_t* __restrict__ keep, unsigned long long* __restrict__ count)
+{
+    uint32_t c = 0;
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
+        const bool k = range[i] == which;
+        keep[i] = k ? 1 : 0;
+        c += k ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, static_cast<unsigned long long>(c));
+}
+
+// Sample k of n_samples = the tag of record k * n / n_samples, cut to `stride` bytes (a cut tag still splits the order).
+__global__ __launch_bounds__(kBlock)
+void sample_tags_kernel(fqd_tags t, uint32_t n_samples, uint32_t stride, uint8_t* __restrict__ out_bytes, uint32_t* __restrict__ out_len)
+{
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n_samples) return;
+    const uint64_t i = uint64_t(k) * t.n / n_samples;
+    const uint8_t* __restrict__ a = t.bytes + t.offsets[i];
+    const uint32_t L = t.lengths[i] < stride ? t.lengths[i] : stride;
+    for (uint32_t b = 0; b < L; ++b) out_bytes[uint64_t(k) * stride + b] = a[b];
+    out_len[k] = L;
+}
+
+__global__ __launch_bounds__(kBlock)
+void max_u32_kernel(const uint32_t* __restrict__ v, uint64_t n, uint32_t* __restrict__ out)
+{
+    uint32_t m = 0;
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) m = v[i] > m ? v[i] : m;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_down(m, d, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
 // Output offsets: pair k (tag order) is written iff keep[k]; its record idx[k] of this file then
 // starts at the sum of the sizes of the kept records before it.  dest[] (per record of the file) is
 // preset to ~0 by the host code.
@@ -1067,6 +1132,72 @@ int fqd_gather_seqs(fqd_engine* e, const uint32_t* idx, uint64_t n, const uint64
     hipLaunchKernelGGL(gather_seq_kernel, dim3(grid_for(n, kBlock, 4096)), dim3(kBlock), 0, fqd_internal_stream(e),
                        idx, n, off_table, len_table, off_out, len_out);
     JOIN_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+int fqd_classify_tags(fqd_engine* e, const fqd_tags* t, const uint8_t* split_bytes, uint32_t split_stride, const uint32_t* split_len,
+                      uint32_t n_split, uint32_t* range_out)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!t || (t->n && (!t->offsets || !t->lengths || !range_out)) || (n_split && (!split_bytes || !split_len)))
+        return fqd_internal_fail(e, FQD_ERR_ARG, "fqd_classify_tags: bad arguments");
+    if (t->n == 0) return FQD_OK;
+    JOIN_TRY(e, hipSetDevice(fqd_internal_device(e)));
+    hipLaunchKernelGGL(classify_tags_kernel, dim3(grid_for(t->n, kBlock, 4096)), dim3(kBlock), 0, fqd_internal_stream(e),
+                       *t, split_bytes, split_stride, split_len, n_split, range_out);
+    JOIN_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+int fqd_range_keep(fqd_engine* e, const uint32_t* range, uint64_t n, uint32_t which, uint8_t* keep, uint64_t* count)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!count || (n && (!range || !keep))) return fqd_internal_fail(e, FQD_ERR_ARG, "fqd_range_keep: bad arguments");
+    *count = 0;
+    if (n == 0) return FQD_OK;
+    JOIN_TRY(e, hipSetDevice(fqd_internal_device(e)));
+    hipStream_t stream = fqd_internal_stream(e);
+    void* base = nullptr;
+    int rc = fqd_internal_scratch(e, 1, 4096, &base);
+    if (rc) return rc;
+    unsigned long long* d_count = static_cast<unsigned long long*>(base);
+    JOIN_TRY(e, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(range_keep_kernel, dim3(grid_for(n, kBlock, 2048)), dim3(kBlock), 0, stream, range, n, which, keep, d_count);
+    unsigned long long got = 0;
+    JOIN_TRY(e, hipMemcpyAsync(&got, d_count, sizeof got, hipMemcpyDeviceToHost, stream));
+    JOIN_TRY(e, hipStreamSynchronize(stream));
+    *count = got;
+    return FQD_OK;
+}
+
+int fqd_sample_tags(fqd_engine* e, const fqd_tags* t, uint32_t n_samples, uint32_t stride, uint8_t* out_bytes, uint32_t* out_len)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!t || !t->n || !n_samples || !stride || !out_bytes || !out_len || !t->offsets || !t->lengths)
+        return fqd_internal_fail(e, FQD_ERR_ARG, "fqd_sample_tags: bad arguments");
+    JOIN_TRY(e, hipSetDevice(fqd_internal_device(e)));
+    hipLaunchKernelGGL(sample_tags_kernel, dim3((n_samples + kBlock - 1) / kBlock), dim3(kBlock), 0, fqd_internal_stream(e),
+                       *t, n_samples, stride, out_bytes, out_len);
+    JOIN_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
+int fqd_max_u32(fqd_engine* e, const uint32_t* values, uint64_t n, uint32_t* max_out)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!max_out || (n && !values)) return fqd_internal_fail(e, FQD_ERR_ARG, "fqd_max_u32: bad arguments");
+    *max_out = 0;
+    if (n == 0) return FQD_OK;
+    JOIN_TRY(e, hipSetDevice(fqd_internal_device(e)));
+    hipStream_t stream = fqd_internal_stream(e);
+    void* base = nullptr;
+    int rc = fqd_internal_scratch(e, 1, 4096, &base);
+    if (rc) return rc;
+    uint32_t* d = static_cast<uint32_t*>(base);
+    JOIN_TRY(e, hipMemsetAsync(d, 0, sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(max_u32_kernel, dim3(grid_for(n, kBlock, 2048)), dim3(kBlock), 0, stream, values, n, d);
+    JOIN_TRY(e, hipMemcpyAsync(max_out, d, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    JOIN_TRY(e, hipStreamSynchronize(stream));
     return FQD_OK;
 }
 

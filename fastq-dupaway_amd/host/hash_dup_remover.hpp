@@ -67,6 +67,7 @@ private:
     void run_unordered_in_memory(const std::string* in, const std::string* out);
     void run_unordered_resident(const std::string* in, const std::string* out);
     void run_unordered_streaming(const std::string* in, const std::string* out);
+    void run_unordered_multi(const std::string* in, const std::string* out);
     Format              format_;
     ssize_t             memlimit_;
     TemporaryDirectory* tempdir_;

@@ -310,6 +310,21 @@ int  fqd_copy_spans(fqd_engine* e, const uint8_t* src, const uint64_t* src_off, 
  * stands when a record without a partner is consumed (the end-of-file rule needs it, hpp:281,317-340). */
 int  fqd_count_tags_le(fqd_engine* e, const fqd_tags* t, const fqd_tags* other, uint64_t other_index, uint64_t* count);
 
+/* ---- `--unordered` over several GPUs: every GPU joins one contiguous RANGE of the tag order ------------------------
+ * The reference's two sorted files are one global order (external_sort.hpp, FastqViewWithId::cmp); here it is cut at
+ * n_split splitters (tags picked from a sample: fqd_sample_tags writes the tag of every (n / n_samples)-th record, cut
+ * to `stride` bytes, into out_bytes + k * stride / out_len[k]; the host sorts them and picks).  fqd_classify_tags:
+ * range_out[i] = number of splitters that are < tag i (splitter j = split_bytes + j * split_stride, split_len[j] bytes,
+ * ascending) — records with equal tags always land in the same range.  fqd_range_keep: keep[i] = (range[i] == which),
+ * *count (host) = how many: with fqd_output_plan (idx = NULL) and fqd_copy_spans that moves a range's whole records,
+ * in input order, into one contiguous piece of text for the GPU that owns the range.  fqd_max_u32: the largest of n
+ * values (the longest sequence: the key width of the pair exchange).  All device pointers unless said otherwise. */
+int  fqd_sample_tags(fqd_engine* e, const fqd_tags* t, uint32_t n_samples, uint32_t stride, uint8_t* out_bytes, uint32_t* out_len);
+int  fqd_classify_tags(fqd_engine* e, const fqd_tags* t, const uint8_t* split_bytes, uint32_t split_stride, const uint32_t* split_len,
+                       uint32_t n_split, uint32_t* range_out);
+int  fqd_range_keep(fqd_engine* e, const uint32_t* range, uint64_t n, uint32_t which, uint8_t* keep, uint64_t* count);
+int  fqd_max_u32(fqd_engine* e, const uint32_t* values, uint64_t n, uint32_t* max_out);
+
 /* Where the survivors go: pair k (tag order, k < n) is written iff keep[k]; dest[idx[k]] = sum of
  * sizes[idx[j]] over the kept pairs j < k (byte offset of record idx[k] in this file's output), entries
  * of records that are not written keep what the caller preset; *total (host) = output size in bytes.

@@ -644,7 +644,7 @@ def test_multi_gpu_cli_errors(exe, oracle, tmp_path):
     tot, dup = oracle.filter_single(late, exp, FASTQ)
     r = run(exe, "-i", late, "-o", got, "--fast", "-v", env={"FQD_DEVICES": "0,0", "FQD_BLOCK_MB": "1", "FQD_SHARD_PADDED": "1"})
     assert r.returncode == 0 and got.read_bytes() == exp.read_bytes(), r.stderr
-    recs[35000] = (recs[35000][0], recs[35000][1] + b"ACGTACGTAC")                      # 70 > 64 = the first round's 60 rounded up
+    recs[35000] = (recs[35000][0], recs[34999][1] + b"ACGTACGTAC")                      # 70 > 64 = the first round's 60 rounded up
     recs[100] = (recs[100][0], recs[100][1][:33])                                           # (the first round is ragged: padded keys)
     late.write_bytes(fastq(recs))
     r = run(exe, "-i", late, "-o", tmp_path / "o.fq", "--fast", env={"FQD_DEVICES": "0,0", "FQD_BLOCK_MB": "1"})
@@ -683,6 +683,152 @@ def test_multi_gpu_cli_trimmed_reads(exe, oracle, tmp_path, devices, slab):
     assert r.returncode == 0, r.stderr
     assert filecmp.cmp(g1, e1, shallow=False) and filecmp.cmp(g2, e2, shallow=False)
     assert r.stdout == f"{tot} read pairs processed, out of which {dup} duplicates were removed.\n" and dup > 500
+
+
+# ---------------------------------------------------------------- GPU: --unordered over several GPUs
+
+MULTI = [("0,0", ""), ("0,0,0,0", ""), ("0,0,0", "8"), ("0", "")]      # (FQD_DEVICES, FQD_SHARD_SLAB): ranks sharing the one card; tiny slabs: every pair exchange spills
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["shuffled", "skewed", "deletion", "interleaved", "not_overlapped"])
+@pytest.mark.parametrize("full_join", ["0", "1"])
+@pytest.mark.parametrize("devices,slab", MULTI)
+def test_multi_gpu_unordered_reference_fixtures(exe, golden_dir, tmp_path, name, full_join, devices, slab):
+    """reference test/test_unordered.py:7-48 with the tag order cut into one range per rank (run_unordered_multi)."""
+    fx = golden_dir / "reference_fixtures"
+    o1, o2 = tmp_path / "r1.fa", tmp_path / "r2.fa"
+    r = run(exe, "-i", fx / "inputs" / f"unordered_{name}_r1.fa", "-u", fx / "inputs" / f"unordered_{name}_r2.fa",
+            "-o", o1, "-p", o2, *FAST, "--unordered",
+            env={"FQD_FULL_JOIN": full_join, "FQD_DEVICES": devices, "FQD_EXCHANGE": "copy", "FQD_SHARD_SLAB": slab}, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(o1, fx / "expected" / f"unordered_{name}_r1.fa", shallow=False)
+    assert filecmp.cmp(o2, fx / "expected" / f"unordered_{name}_r2.fa", shallow=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("style", ["illumina", "sra", "slash"])
+@pytest.mark.parametrize("full_join", ["0", "1"])
+@pytest.mark.parametrize("devices,slab", MULTI[:3])
+def test_multi_gpu_unordered_fastq_matches_oracle_bytes(exe, oracle, tmp_path, style, full_join, devices, slab):
+    rnd = random.Random(52)
+    n = 3000
+    seqs1 = random_reads(rnd, n, 400, 20, 60); seqs2 = random_reads(rnd, n, 10, 20, 60)
+
+    def ident(k, mate):
+        if style == "illumina":
+            return b"M01:7:FC:1:%d:%d:%d %d:N:0:ACGT" % (1100 + k % 7, 1000 + k, 2000 + 3 * k, mate)
+        if style == "sra":
+            return b"SRR99.%d len=%d" % (k + 1, 50 + mate)
+        return b"read%d/%d" % (k, mate)
+    r1 = [(ident(k, 1), seqs1[k]) for k in range(n)]
+    r2 = [(ident(k, 2), seqs2[k]) for k in range(n)]
+    del r1[100:130]; del r2[2000:2050]
+    r1 += r1[500:520]                                      # repeated IDs in file 1: paired rank by rank with file 2's
+    rnd.shuffle(r2)
+    f1, f2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    f1.write_bytes(fastq(r1)); f2.write_bytes(fastq(r2))
+    e1, e2, g1, g2 = (tmp_path / x for x in ("e1.fq", "e2.fq", "g1.fq", "g2.fq"))
+    tot, dup, un = oracle.filter_paired(f1, f2, e1, e2, FASTQ, unordered=True, tail_rule=(full_join == "0"))
+    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v",
+            env={"FQD_FULL_JOIN": full_join, "FQD_DEVICES": devices, "FQD_EXCHANGE": "copy", "FQD_SHARD_SLAB": slab, "FQD_BLOCK_MB": "1", "FQD_STREAM_WINDOW_KB": "64"}, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(g1, e1, shallow=False) and filecmp.cmp(g2, e2, shallow=False)
+    assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
+                        f"{un} Non-matching entries from both files were skipped.\n")
+    assert (tot == 0) if style == "slash" else (tot > 2000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_multi_gpu_unordered_tail_rule_fuzz(exe, oracle, tmp_path, devices):
+    """Tiny inputs (1..9 records per file): most ranges are empty or hold one file only, and the reference's end-of-file
+    rule has to look across them."""
+    rnd = random.Random(20260303)
+    seqs = [b"ACGT", b"GGCC", b"TTAA", b"ACGT", b"NNAC"]
+    for case in range(30):
+        ids = rnd.sample(range(1, 13), rnd.randrange(1, 10))
+        ids2 = rnd.sample(range(1, 13), rnd.randrange(1, 10))
+        def fa(idlist, salt):
+            return b"".join(b">%02d x\n%s\n" % (i, seqs[(i * salt) % len(seqs)]) for i in idlist)
+        f1, f2 = tmp_path / f"a{case}.fa", tmp_path / f"b{case}.fa"
+        f1.write_bytes(fa(ids, 1)); f2.write_bytes(fa(ids2, 3))
+        for full in ("0", "1"):
+            e1, e2, g1, g2 = (tmp_path / f"{x}{case}{full}" for x in ("e1", "e2", "g1", "g2"))
+            tot, dup, un = oracle.filter_paired(f1, f2, e1, e2, FASTA, unordered=True, tail_rule=(full == "0"))
+            r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--format", "fasta", "--fast", "--unordered", "-v",
+                    env={"FQD_FULL_JOIN": full, "FQD_DEVICES": devices, "FQD_EXCHANGE": "copy"})
+            assert r.returncode == 0, r.stderr
+            assert g1.read_bytes() == e1.read_bytes() and g2.read_bytes() == e2.read_bytes(), (ids, ids2, full)
+            assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
+                                f"{un} Non-matching entries from both files were skipped.\n"), (ids, ids2, full)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,gz", [("0,0,0,0", False), ("0,0", True)])
+def test_multi_gpu_unordered_2m_pairs_shuffled_with_orphans(exe, oracle, tmp_path, devices, gz):
+    """2 M pairs, Illumina-style IDs, file 2 shuffled, orphans on both sides, mates of different lengths, about a fifth
+    duplicate pairs: outputs and -v lines equal the oracle's, plain and `.gz` out."""
+    import numpy as np
+    rng = np.random.default_rng(77)
+    n, L1, L2 = 2_000_000, 100, 76
+    pool1 = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(n // 4, L1)); pool2 = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(64, L2))
+    pick1 = rng.integers(0, n // 4, n); pick2 = rng.integers(0, 64, n)
+
+    def build(mate, pool, pick, L, keep):
+        idx = np.flatnonzero(keep)
+        ids = np.char.add(np.char.add("@A00:1:FC:1:", np.char.zfill(idx.astype(str), 8)), f" {mate}:N:0\n").astype("S")
+        idl = len(ids[0])
+        rec = np.empty((len(idx), idl + L + 1 + 2 + L + 1), np.uint8)
+        rec[:, :idl] = np.frombuffer(b"".join(ids.tolist()), np.uint8).reshape(len(idx), idl)
+        rec[:, idl:idl + L] = pool[pick[idx]]
+        rec[:, idl + L] = 10; rec[:, idl + L + 1] = ord("+"); rec[:, idl + L + 2] = 10
+        rec[:, idl + L + 3: idl + 2 * L + 3] = ord("F"); rec[:, idl + 2 * L + 3] = 10
+        return rec
+    keep1 = rng.random(n) > 0.01; keep2 = rng.random(n) > 0.01
+    r1 = build(1, pool1, pick1, L1, keep1); r2 = build(2, pool2, pick2, L2, keep2)
+    r2 = r2[rng.permutation(len(r2))]
+    f1, f2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    r1.tofile(f1); r2.tofile(f2)
+    ext = ".fq.gz" if gz else ".fq"
+    e1, e2, g1, g2 = tmp_path / "e1.fq", tmp_path / "e2.fq", tmp_path / ("g1" + ext), tmp_path / ("g2" + ext)
+    tot, dup, un = oracle.filter_paired(f1, f2, e1, e2, FASTQ, unordered=True, tail_rule=True)
+    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", env={"FQD_DEVICES": devices, "FQD_EXCHANGE": "copy"}, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
+                        f"{un} Non-matching entries from both files were skipped.\n")
+    assert tot > 1_900_000 and dup > 100_000 and un > 10_000
+    if gz:
+        for g, e in ((g1, e1), (g2, e2)):
+            assert subprocess.run(f"gzip -dc '{g}' | cmp -s - '{e}'", shell=True).returncode == 0
+    else:
+        assert filecmp.cmp(g1, e1, shallow=False) and filecmp.cmp(g2, e2, shallow=False)
+
+
+@pytest.mark.gpu
+def test_multi_gpu_unordered_errors(exe, oracle, tmp_path):
+    """An unknown base (the output is cut at that pair, in tag order), an empty file, a malformed record: as the
+    single-GPU run and the oracle have it."""
+    rnd = random.Random(88)
+    n = 4000
+    r1 = [(b"q.%04d a" % k, bytes(rnd.choice(b"ACGT") for _ in range(40))) for k in range(n)]
+    r2 = [(b"q.%04d b" % k, bytes(rnd.choice(b"ACGT") for _ in range(30))) for k in range(n)]
+    r2[2500] = (r2[2500][0], r2[2500][1][:10] + b"x" + r2[2500][1][11:])
+    rnd.shuffle(r2)
+    f1, f2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    f1.write_bytes(fastq(r1)); f2.write_bytes(fastq(r2))
+    e1, e2, g1, g2 = (tmp_path / x for x in ("e1.fq", "e2.fq", "g1.fq", "g2.fq"))
+    with pytest.raises(RuntimeError):
+        oracle.filter_paired(f1, f2, e1, e2, FASTQ, unordered=True, tail_rule=True)
+    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", env={"FQD_DEVICES": "0,0,0", "FQD_EXCHANGE": "copy"}, cwd=tmp_path)
+    assert r.returncode == 1
+    assert r.stderr == ("Error: unknown character in DNA sequence: x\nAn error occured during fastq-dupaway execution:\n"
+                        "Supported sequence character set: {A, N, C, G, T}!\n")
+    assert g1.read_bytes() == e1.read_bytes() and g2.read_bytes() == e2.read_bytes()
+    empty = tmp_path / "empty.fq"; empty.write_bytes(b"")
+    single = run(exe, "-i", f1, "-u", empty, "-o", g1, "-p", g2, "--fast", "--unordered", cwd=tmp_path)
+    multi = run(exe, "-i", f1, "-u", empty, "-o", g1, "-p", g2, "--fast", "--unordered", env={"FQD_DEVICES": "0,0"}, cwd=tmp_path)
+    assert multi.returncode == single.returncode == 1 and multi.stderr == single.stderr
 
 
 # ---------------------------------------------------------------- GPU: error behaviour (SURVEY Appendix A, C)

@@ -50,6 +50,7 @@ void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __res
     GlobalLens lens{lens_scratch + gid, threads};
     uint32_t bad = 0;
     for (uint64_t m = gid; m < members; m += threads) {
+        if (out_len[m] > 65536u) { ++bad; continue; }         // no BGZF member holds more (the CLI's header walk says so too; an ABI caller may not)
         const uint32_t st = fqd::inflate::inflate_member(comp + comp_off[m], comp_len[m], text + out_off[m], out_len[m], t, lens);
         bad += st != fqd::inflate::kOk ? 1u : 0u;
     }
@@ -72,6 +73,7 @@ void bgzf_check_crc_kernel(const uint8_t* __restrict__ text, const uint64_t* __r
     __syncthreads();
     for (uint64_t m = blockIdx.x; m < members; m += gridDim.x) {
         const uint32_t L = out_len[m];
+        if (L > 65536u) continue;                             // counted as bad by the inflater; more would not fit `data`
         const uint8_t* __restrict__ p = text + out_off[m];
         // aligned 16-byte loads from the first aligned address on; the ragged head byte by byte
         const uint32_t head = uint32_t((16u - (reinterpret_cast<uintptr_t>(p) & 15u)) & 15u);
@@ -323,6 +325,7 @@ int fqd_scan_records(fqd_engine* e, const uint8_t* text, uint64_t n, uint32_t li
     // (the scratch may have moved when it grew: the counts are made again, it takes microseconds)
     hipLaunchKernelGGL(count_newlines_kernel, dim3(uint32_t(std::min<uint64_t>(tiles, 8192))), dim3(kScanThreads), 0, stream, text, n, tiles, counts);
     hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, stream, static_cast<const uint32_t*>(counts), tiles, offs);
+    INF_TRY(e, hipGetLastError());
     INF_TRY(e, hipMemsetAsync(d_flags, 0, 256, stream));
     hipLaunchKernelGGL(newline_positions_kernel, dim3(uint32_t(std::min<uint64_t>(tiles, 8192))), dim3(kScanThreads), 0, stream, text, n, tiles,
                        static_cast<const uint64_t*>(offs), nl_pos);

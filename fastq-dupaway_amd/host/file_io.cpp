@@ -158,6 +158,7 @@ size_t InputFile::read_bgzf(char* dst, size_t n, unsigned threads)
         if (avail < total) return 0;
         const unsigned char* tail = p + total - 4;
         m = Member{at, off, total, tail[0] | (size_t(tail[1]) << 8) | (size_t(tail[2]) << 16) | (size_t(tail[3]) << 24)};
+        if (m.isize > 65536) return -1;                       // a BGZF member never holds more: a damaged trailer, not a size to allocate
         return 1;
     };
     size_t got = 0;
@@ -450,7 +451,9 @@ void OutputFile::write_members(const char* p, size_t n, unsigned threads)
                 part(0);
                 for (std::thread& th : pool) th.join();
                 ::munmap(map, lead + n);
-                if (::lseek(fd, at + static_cast<off_t>(n), SEEK_SET) < 0) throw std::runtime_error("write failed: " + name_);
+                // the stream itself is told where the file now ends (moving the descriptor behind stdio's back
+                // only works while glibc does not re-seek a write-only stream)
+                if (::fseeko(f_, at + static_cast<off_t>(n), SEEK_SET) != 0) throw std::runtime_error("write failed: " + name_);
                 return;
             }
         }

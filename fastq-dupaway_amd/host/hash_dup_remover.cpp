@@ -44,9 +44,22 @@ TemporaryDirectory::~TemporaryDirectory()
 
 namespace {
 
+// What went wrong on the GPU side, told apart so that a run that can hand over to another way of running knows why it
+// does: out of HBM (hand over silently: the other way needs less) or a device / engine error (hand over, but SAY so).
+struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct DeviceOutOfMemory : DeviceError { using DeviceError::DeviceError; };
+
 #define HIP_OK(expr)                                                                        \
     do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError();           /* not sticky: a fallback may follow */ \
-        throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+        if (e_ == hipErrorOutOfMemory) throw DeviceOutOfMemory(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        throw DeviceError(std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+
+// One line on stderr when a GPU-resident run gives up because of a DEVICE ERROR (not because it does not apply, and not
+// for lack of HBM) and the streaming run takes over: the user learns that the fast path failed and on which call.
+void announce_handover(const char* run, const std::exception& e)
+{
+    std::cerr << "[fastq-dupaway] " << run << " gave up on a GPU error (" << e.what() << "); continuing with the streaming run\n";
+}
 
 // RAII over the C ABI
 // Set by a resident run of the CLI after its outputs are closed (Tuning::leave_memory_to_exit): from then on
@@ -756,9 +769,8 @@ void join_and_dedup(fqd_engine* e, hipStream_t stream, const DeviceSide (&side)[
     } else engine_ok(rc);
 }
 
-// A device allocation failed while the inputs were still being read: the caller may fall back to a
-// way of running that needs less HBM.
-struct DeviceOutOfMemory : std::runtime_error { using std::runtime_error::runtime_error; };
+// (DeviceOutOfMemory, above: a device allocation failed while the inputs were still being read — the caller may fall
+// back to a way of running that needs less HBM.)
 
 // Device memory that grows and keeps its contents.
 template <class T>
@@ -1111,29 +1123,67 @@ static bool deflate_on_device()
 // The outputs of a run whose text is in HBM: pair k < upto (record idx[s][k] of file s; idx[s] == nullptr: record k)
 // is written iff keep[k].  The device assembles windows of survivors in output order (and deflates them, for `.gz`
 // outputs: deflate_on_device), the host writes what comes back, a writer thread per file.  Closes the sinks.
-static void write_survivors(fqd_engine* e, hipStream_t stream, int S, FileOnDevice* const* file, const uint32_t* const* idx,
-                            const uint8_t* keep, uint64_t upto, uint64_t dups, OutputFile* const* sinks, Format format, long long memlimit,
-                            bool close_sinks = true)
-{
-    auto engine_ok = [&](int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(e)); };
-    uint64_t window = std::max<uint64_t>(4u << 20, static_cast<uint64_t>(memlimit > 0 ? memlimit : (2ll << 30)) / 16);   // bytes per buffer, two per file
-    if (const char* v = std::getenv("FQD_STREAM_WINDOW_KB")) { const long kb = std::atol(v); if (kb > 0) window = static_cast<uint64_t>(kb) << 10; }
-    const uint32_t lines_per_record = format == Format::Fastq ? 4u : 2u;
-    struct Out {
+// Everything write_survivors allocates — the output plan of each file, the window and member buffers on the device,
+// the pinned buffers the windows come back in — so that a run can have it all BEFORE it creates an output (ADVICE r2:
+// an allocation that fails after the sinks exist leaves truncated files and no way back to the streaming run).
+struct SurvivorBuffers {
+    struct PerFile {
         Device<uint64_t> src_off, dst_off; Device<uint32_t> len; uint64_t total = 0;
         Pinned<char> buf[2]; Device<char> d_win, d_members;
-        Channel<int> free_bufs, full_bufs; int slot_id[2] = {0, 1}; size_t bytes[2] = {0, 0};
         bool on_device = false;                       // .gz: windows leave the device as finished BGZF members
-        std::thread writer; std::exception_ptr error;
-    } o[2];
-    static int kStop = -1;
-    const uint64_t roomy = window + window / 4;             // the most a window may hold
+    } f[2];
+    uint64_t window = 0, roomy = 0;
+    bool planned = false;
+};
+
+static void plan_survivors(fqd_engine* e, int S, FileOnDevice* const* file, const uint32_t* const* idx, const uint8_t* keep, uint64_t upto,
+                           const bool* gz_out, long long memlimit, SurvivorBuffers& b)
+{
+    auto engine_ok = [&](int rc) { if (rc != FQD_OK) throw DeviceError(std::string("GPU engine: ") + fqd_last_error(e)); };
+    b.window = std::max<uint64_t>(4u << 20, static_cast<uint64_t>(memlimit > 0 ? memlimit : (2ll << 30)) / 16);   // bytes per buffer, two per file
+    if (const char* v = std::getenv("FQD_STREAM_WINDOW_KB")) { const long kb = std::atol(v); if (kb > 0) b.window = static_cast<uint64_t>(kb) << 10; }
+    b.roomy = b.window + b.window / 4;                      // the most a window may hold
     for (int s = 0; s < S; ++s) {
-        o[s].src_off.reserve(upto); o[s].dst_off.reserve(upto + 1); o[s].len.reserve(upto);
-        engine_ok(fqd_output_plan(e, keep, idx[s], upto, file[s]->start.p, file[s]->size.p,
-                                  o[s].src_off.p, o[s].len.p, o[s].dst_off.p, &o[s].total));
+        SurvivorBuffers::PerFile& o = b.f[s];
+        o.src_off.reserve(upto); o.dst_off.reserve(upto + 1); o.len.reserve(upto);
+        engine_ok(fqd_output_plan(e, keep, idx[s], upto, file[s]->start.p, file[s]->size.p, o.src_off.p, o.len.p, o.dst_off.p, &o.total));
+        o.on_device = gz_out[s] && deflate_on_device();
+        // every buffer is sized once, for the largest window the writer lets through (a single record larger than that is the
+        // one case that grows them later): a window a little larger than all before it must not cost a new pinned allocation
+        const uint64_t room = std::min<uint64_t>(b.roomy, std::max<uint64_t>(o.total, 1));
+        o.d_win.reserve(room + 64);
+        for (int k = 0; k < 2; ++k) o.buf[k].reserve((o.on_device ? std::max<uint64_t>(room / 2, 1u << 20) : room) + 64);
+        if (o.on_device) o.d_members.reserve(fqd_bgzf_bound(room));
+    }
+    b.planned = true;
+}
+
+static void write_survivors(fqd_engine* e, hipStream_t stream, int S, FileOnDevice* const* file, const uint32_t* const* idx,
+                            const uint8_t* keep, uint64_t upto, uint64_t dups, OutputFile* const* sinks, Format format, long long memlimit,
+                            bool close_sinks = true, SurvivorBuffers* planned = nullptr)
+{
+    auto engine_ok = [&](int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(e)); };
+    SurvivorBuffers own;
+    if (!planned || !planned->planned) {
+        bool gz_out[2] = {false, false};
+        for (int s = 0; s < S; ++s) gz_out[s] = sinks[s]->is_gz();
+        plan_survivors(e, S, file, idx, keep, upto, gz_out, memlimit, own);
+        planned = &own;
+    }
+    const uint64_t window = planned->window, roomy = planned->roomy;
+    const uint32_t lines_per_record = format == Format::Fastq ? 4u : 2u;
+    struct Out {
+        Device<uint64_t>& src_off; Device<uint64_t>& dst_off; Device<uint32_t>& len; uint64_t total;
+        Pinned<char>* buf; Device<char>& d_win; Device<char>& d_members;
+        Channel<int> free_bufs, full_bufs; int slot_id[2] = {0, 1}; size_t bytes[2] = {0, 0};
+        bool on_device = false;
+        std::thread writer; std::exception_ptr error;
+        explicit Out(SurvivorBuffers::PerFile& p) : src_off(p.src_off), dst_off(p.dst_off), len(p.len), total(p.total), buf(p.buf), d_win(p.d_win), d_members(p.d_members), on_device(p.on_device) {}
+    };
+    Out o[2] = {Out(planned->f[0]), Out(planned->f[1])};
+    static int kStop = -1;
+    for (int s = 0; s < S; ++s) {
         o[s].free_bufs.push(&o[s].slot_id[0]); o[s].free_bufs.push(&o[s].slot_id[1]);
-        o[s].on_device = sinks[s]->is_gz() && deflate_on_device();
         o[s].writer = std::thread([&, s] {
             for (;;) {
                 int* id = o[s].full_bufs.pop();
@@ -1269,9 +1319,11 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
     Device<uint8_t> keep;
     uint64_t n = 0, dups = 0;
     std::unique_ptr<EngineHandle> eng;
+    SurvivorBuffers buffers;
     try {
         CompressedOnDevice packed[2];
         bool fetched[2] = {false, false};
+        std::exception_ptr fetch_error[2];
         uint64_t plain_bytes[2] = {0, 0};
         {
             StageClock::Scope t("ordered/resident: files to HBM");
@@ -1280,13 +1332,15 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
                     fetched[s] = has_gz_extension(in[s]) ? fetch_bgzf(in[s], block_bytes, tuning_.device, packed[s])
                                                          : fetch_plain(in[s], block_bytes, tuning_.device, dev[s], plain_bytes[s]);
                 } catch (const DeviceOutOfMemory&) { fetched[s] = false; }
-                catch (const std::exception&) { fetched[s] = false; }
+                catch (const DeviceError&) { fetched[s] = false; fetch_error[s] = std::current_exception(); }
+                catch (const std::exception&) { fetched[s] = false; }      // the host reader will say what is wrong with the file
             };
             std::thread second;
             if (S == 2) second = std::thread(fetch, 1);
             fetch(0);
             if (S == 2) second.join();
         }
+        for (int s = 0; s < S; ++s) if (fetch_error[s]) std::rethrow_exception(fetch_error[s]);
         for (int s = 0; s < S; ++s) if (!fetched[s]) return false;
         eng = std::make_unique<EngineHandle>(S, tuning_.device, stream);
         {
@@ -1313,14 +1367,24 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
         }
         if (rc == FQD_OK) rc = fqd_engine_sync(eng->e);
         if (rc == FQD_ERR_BAD_BASE) return false;                 // the streaming run cuts the output where the reference does
-        if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng->e));
+        if (rc != FQD_OK) throw DeviceError(std::string("GPU engine: ") + fqd_last_error(eng->e));
+        if (std::getenv("FQD_TEST_FAIL_RESIDENT")) throw DeviceError("GPU engine: forced by FQD_TEST_FAIL_RESIDENT");      // tests: the hand-over is announced
         fqd_stats st{};
         fqd_get_stats(eng->e, &st);
         dups = st.duplicates;
-    } catch (const std::exception&) {
-        // HBM that does not suffice, a device error: nothing has been written yet, so the streaming run — which needs
-        // a few blocks of HBM only, and reports what is really wrong — takes over
+        // everything the writer needs is reserved HERE, while the run can still hand over: once an output exists it cannot
+        bool gz_out[2] = {false, false};
+        for (int s = 0; s < S; ++s) gz_out[s] = has_gz_extension(out[s]);
+        FileOnDevice* files[2] = {&dev[0], &dev[1]};
+        const uint32_t* idx[2] = {nullptr, nullptr};
+        plan_survivors(eng->e, S, files, idx, keep.p, n, gz_out, memlimit_, buffers);
+    } catch (const DeviceOutOfMemory&) {
+        return false;                                             // HBM that does not suffice: the streaming run needs a few blocks of it only
+    } catch (const DeviceError& e) {
+        announce_handover("the GPU-resident ordered run", e);     // nothing has been written yet
         return false;
+    } catch (const std::exception&) {
+        return false;                                             // an input the host reader will report on in the reference's words
     }
     // from here on the run is this one's: outputs are created, filled and closed
     OutputFile sink0(out[0]);
@@ -1331,7 +1395,7 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
         StageClock::Scope t("ordered/resident: survivors out of HBM");
         FileOnDevice* files[2] = {&dev[0], &dev[1]};
         const uint32_t* idx[2] = {nullptr, nullptr};
-        write_survivors(eng->e, stream, S, files, idx, keep.p, n, dups, sinks, format_, memlimit_);
+        write_survivors(eng->e, stream, S, files, idx, keep.p, n, dups, sinks, format_, memlimit_, true, &buffers);
     }
     if (tuning_.leave_memory_to_exit) g_leave_memory_to_exit = true;
     StageClock::report();
@@ -1442,16 +1506,16 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
         }
     }
 
-    // outputs are opened after the sort phase (hpp:265-266)
-    OutputFile sink0(out[0]), sink1(out[1]);
-    OutputFile* sinks[2] = {&sink0, &sink1};
-
     DeviceSide side[2];
     for (int s = 0; s < 2; ++s) {
         side[s].tag_bytes = side[s].seq_bytes = reinterpret_cast<const uint8_t*>(dev[s].text.p);
         side[s].tag_off = dev[s].tag_off.p; side[s].tag_len = dev[s].tag_len.p;
         side[s].seq_off = dev[s].seq_off.p; side[s].seq_len = dev[s].seq_len.p; side[s].n = dev[s].n;
     }
+    // The join, the dedup and every buffer the writer needs come BEFORE the outputs exist: HBM that does not suffice for
+    // them (DeviceOutOfMemory) still hands the job to the two-pass run.  On disk nothing differs from the reference's
+    // order — outputs opened after the sort phase, then the merge (hpp:265-266) — a bad base found by the dedup cuts the
+    // output at the same pair either way.
     JoinedPairs jp;
     join_and_dedup(eng.e, stream, side, tuning_.reference_tail_rule, jp);
     const uint64_t n_proc = jp.n_proc, upto = std::min<uint64_t>(n_proc, jp.written_below);
@@ -1462,13 +1526,21 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
         HIP_OK(hipStreamSynchronize(stream));
         for (uint64_t k = 0; k < upto; ++k) dups += keep[k] == 0;
     }
+    FileOnDevice* files[2] = {&dev[0], &dev[1]};
+    const uint32_t* idx[2] = {jp.pair[0].p, jp.pair[1].p};
+    SurvivorBuffers buffers;
+    {
+        const bool gz_out[2] = {has_gz_extension(out[0]), has_gz_extension(out[1])};
+        plan_survivors(eng.e, 2, files, idx, jp.keep.p, upto, gz_out, memlimit_, buffers);
+    }
+
+    OutputFile sink0(out[0]), sink1(out[1]);
+    OutputFile* sinks[2] = {&sink0, &sink1};
 
     // ---- outputs: the device assembles windows of survivors in output order, the host writes them -----
     {
         StageClock::Scope t("unordered/resident: survivors out of HBM");
-        FileOnDevice* files[2] = {&dev[0], &dev[1]};
-        const uint32_t* idx[2] = {jp.pair[0].p, jp.pair[1].p};
-        write_survivors(eng.e, stream, 2, files, idx, jp.keep.p, upto, dups, sinks, format_, memlimit_);
+        write_survivors(eng.e, stream, 2, files, idx, jp.keep.p, upto, dups, sinks, format_, memlimit_, true, &buffers);
     }
     if (tuning_.leave_memory_to_exit) g_leave_memory_to_exit = true;
     StageClock::report();

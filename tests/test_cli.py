@@ -685,6 +685,26 @@ def test_multi_gpu_cli_trimmed_reads(exe, oracle, tmp_path, devices, slab):
     assert r.stdout == f"{tot} read pairs processed, out of which {dup} duplicates were removed.\n" and dup > 500
 
 
+@pytest.mark.gpu
+def test_resident_run_announces_a_device_error_before_handing_over(exe, oracle, tmp_path):
+    """a GPU error inside the resident ordered run is not swallowed — one line names it, then the streaming
+    run does the job (nothing had been written yet), with the oracle's bytes."""
+    from inflate_cases import bgzf
+    rnd = random.Random(5)
+    recs = [(b"h%05d" % k, s) for k, s in enumerate(random_reads(rnd, 4000, 600, 30, 90))]
+    src = tmp_path / "in.fq.gz"; src.write_bytes(bgzf(fastq(recs), level=1))
+    plain = tmp_path / "in.fq"; plain.write_bytes(fastq(recs))
+    exp, got = tmp_path / "exp.fq", tmp_path / "got.fq.gz"
+    tot, dup = oracle.filter_single(plain, exp, FASTQ)
+    r = run(exe, "-i", src, "-o", got, "--fast", "-v", env={"FQD_TEST_FAIL_RESIDENT": "1"}, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.count("[fastq-dupaway] the GPU-resident ordered run gave up on a GPU error (GPU engine: forced by FQD_TEST_FAIL_RESIDENT)") == 1
+    assert gzip.decompress(got.read_bytes()) == exp.read_bytes()
+    assert r.stdout == f"{tot} reads processed, out of which {dup} duplicates were removed.\n"
+    r = run(exe, "-i", src, "-o", got, "--fast", "-v", cwd=tmp_path)                 # and without the forced error: not a word
+    assert r.returncode == 0 and r.stderr == "" and gzip.decompress(got.read_bytes()) == exp.read_bytes()
+
+
 # ---------------------------------------------------------------- GPU: --unordered over several GPUs (VERDICT r2 row e2)
 
 MULTI = [("0,0", ""), ("0,0,0,0", ""), ("0,0,0", "8"), ("0", "")]      # (FQD_DEVICES, FQD_SHARD_SLAB): ranks sharing the one card; tiny slabs: every pair exchange spills
@@ -797,7 +817,7 @@ def test_multi_gpu_unordered_2m_pairs_shuffled_with_orphans(exe, oracle, tmp_pat
     assert r.returncode == 0, r.stderr
     assert r.stdout == (f"{tot} valid read pairs processed, out of which {dup} duplicates were removed.\n"
                         f"{un} Non-matching entries from both files were skipped.\n")
-    assert tot > 1_900_000 and dup > 100_000 and un > 10_000
+    assert tot > 1_900_000 and dup > 20_000 and un > 10_000
     if gz:
         for g, e in ((g1, e1), (g2, e2)):
             assert subprocess.run(f"gzip -dc '{g}' | cmp -s - '{e}'", shell=True).returncode == 0

@@ -345,7 +345,10 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
     if (c.staged) {
         const uint32_t per_tile = e->S == 2 ? c.R / 2 : c.R;
         const uint32_t grid = uint32_t(std::min<uint64_t>((n + per_tile - 1) / per_tile, uint64_t(e->n_cu) * blocks_per_cu));
-        const size_t lds = size_t(c.tile0) + c.tile1;
+        // FQD_ENC_EXTRA_LDS: bytes of LDS a workgroup asks for on top of its tile (A/B only: what the 12-16 KB of record queues
+        // of an encoder that partitions as it goes would cost in resident workgroups — profiles/r03_ab_encoder_lds.jsonl)
+        static const size_t extra_lds = [] { const char* v = std::getenv("FQD_ENC_EXTRA_LDS"); return v ? size_t(std::max(0, std::atoi(v))) : size_t(0); }();
+        const size_t lds = size_t(c.tile0) + c.tile1 + extra_lds;
         const uint32_t rw = ks.W0 + ks.lead;
         const uint32_t magic = rw > 1 ? uint32_t(((1ull << 32) + rw - 1) / rw) : 0xFFFFFFFFu;   // x/rw for x < 2^16
         if (e->S == 1) {

@@ -233,6 +233,38 @@ void fill_crc_tables(CrcTables& c)
 
 extern "C" {
 
+// One batch of members queued on the engine's stream, nothing waited for: bad members are ADDED to the two counters at
+// bad_counters (device; the caller zeroes them once and reads them when it likes).
+int fqd_bgzf_inflate_async(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* comp_len,
+                           const uint64_t* out_off, const uint32_t* out_len, const uint32_t* crc, uint64_t n_members,
+                           uint8_t* text, uint64_t* bad_counters)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (!bad_counters || (n_members && (!comp || !comp_off || !comp_len || !out_off || !out_len || !crc || !text)))
+        return fqd_internal_fail(e, FQD_ERR_ARG, "fqd_bgzf_inflate_async: bad arguments");
+    if (n_members == 0) return FQD_OK;
+    INF_TRY(e, hipSetDevice(fqd_internal_device(e)));
+    hipStream_t stream = fqd_internal_stream(e);
+    const uint32_t grid = uint32_t(std::min<uint64_t>((n_members + kWave - 1) / kWave, 256u * 6u * 2u));
+    const size_t lens_bytes = round_up(size_t(fqd::inflate::kLitSymbols + fqd::inflate::kDistSymbols + 2) * grid * kWave, 256);
+    const size_t tabs_bytes = round_up(sizeof(CrcTables), 256);
+    void* base = nullptr;
+    const int rc = fqd_internal_scratch(e, 1, 256 + tabs_bytes + lens_bytes, &base);     // batches of one stream share it: they run one after the other
+    if (rc != FQD_OK) return rc;
+    CrcTables* d_tabs = reinterpret_cast<CrcTables*>(static_cast<uint8_t*>(base) + 256);
+    uint8_t* d_lens = static_cast<uint8_t*>(base) + 256 + tabs_bytes;
+    static const CrcTables tabs = [] { CrcTables c; fill_crc_tables(c); return c; }();
+    INF_TRY(e, hipMemcpyAsync(d_tabs, &tabs, sizeof tabs, hipMemcpyHostToDevice, stream));
+    unsigned long long* d_bad = reinterpret_cast<unsigned long long*>(bad_counters);
+    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(grid), dim3(kWave), 0, stream, comp, comp_off, comp_len, out_off, out_len, n_members,
+                       text, d_lens, d_bad);
+    INF_TRY(e, hipGetLastError());
+    hipLaunchKernelGGL(bgzf_check_crc_kernel, dim3(uint32_t(std::min<uint64_t>(n_members, 2048))), dim3(fqd::bgzf::kThreads), 0, stream,
+                       static_cast<const uint8_t*>(text), out_off, out_len, crc, n_members, static_cast<const CrcTables*>(d_tabs), d_bad + 1);
+    INF_TRY(e, hipGetLastError());
+    return FQD_OK;
+}
+
 int fqd_bgzf_inflate(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* comp_len,
                      const uint64_t* out_off, const uint32_t* out_len, const uint32_t* crc, uint64_t n_members,
                      uint8_t* text, uint64_t* n_bad)

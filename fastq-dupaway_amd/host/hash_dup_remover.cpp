@@ -68,10 +68,11 @@ static std::atomic<bool> g_leave_memory_to_exit{false};
 
 struct EngineHandle {
     fqd_engine* e = nullptr;
-    EngineHandle(int segments, int device, hipStream_t stream)
+    EngineHandle(int segments, int device, hipStream_t stream, uint64_t capacity_reads = 0, uint64_t capacity_bases = 0)
     {
         fqd_config cfg{};
         cfg.device = device; cfg.segments = segments; cfg.stream = stream;
+        cfg.capacity_reads = capacity_reads; cfg.capacity_bases = capacity_bases;
         const int rc = fqd_engine_create(&cfg, &e);
         if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(nullptr));
     }
@@ -992,6 +993,8 @@ struct CompressedOnDevice {
     std::vector<uint64_t> comp_off, out_off;
     std::vector<uint32_t> comp_len, out_len, crc;
     uint64_t text_bytes = 0;
+    bool inflated = false;                    // fetch_bgzf already inflated the members into the file's text (batch by batch, under the read)
+    uint64_t bad_members = 0;
 };
 
 static bool inflate_on_device()
@@ -1001,7 +1004,13 @@ static bool inflate_on_device()
 }
 
 // false: not such a file (nothing is reported; the caller reads it the host way).
-static bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, CompressedOnDevice& c)
+// `into` given: the members are inflated into into->text batch by batch WHILE the file is still being read (a batch =
+// enough members to fill the chip, one thread each: fqd_bgzf_inflate_async on a small engine of this thread's own), and
+// the room for the text — sized from the file's size before anything is known about its members, regrown if that was
+// too little — is allocated by a helper thread under the first reads: on a device whose free memory another process
+// has just given back, hipMalloc clears tens of gigabytes of pages and takes seconds (0.36 - 3.07 s of
+// configs[4]'s wall).
+static bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, CompressedOnDevice& c, FileOnDevice* into = nullptr)
 {
     uint64_t size = 0;
     if (!has_gz_extension(name) || !is_regular_file(name, size) || size < 28) return false;
@@ -1013,6 +1022,61 @@ static bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, 
     Pinned<char> block;
     block.reserve(block_bytes);
     c.bytes.reserve(size + 64);
+    // ---- inflate under the read ---------------------------------------------------------------------------------
+    static const bool overlap = [] { const char* v = std::getenv("FQD_INFLATE_OVERLAP"); return !v || std::atoi(v) != 0; }();
+    const bool inflating = into != nullptr && overlap;
+    constexpr uint64_t kBatchMembers = 256u * 6u * 64u;       // what the chip holds at one thread per member
+    std::unique_ptr<EngineHandle> codec;                      // this thread's engine: scratch and stream of the inflate launches
+    hipStream_t codec_stream = nullptr;
+    struct CodecGuard { hipStream_t& s; std::unique_ptr<EngineHandle>& e; ~CodecGuard() { e.reset(); if (s) (void)hipStreamDestroy(s); } } cg{codec_stream, codec};
+    std::thread room;                                          // allocates into->text
+    std::exception_ptr room_error;
+    struct RoomGuard { std::thread& t; ~RoomGuard() { if (t.joinable()) t.join(); } } rg{room};
+    struct Batch { Device<uint64_t> comp_off, out_off; Device<uint32_t> comp_len, out_len, crc; };
+    std::vector<std::unique_ptr<Batch>> batches;              // alive until the stream has drained
+    Device<uint64_t> d_bad;
+    uint64_t launched = 0, launched_bytes = 0;                // members / text bytes handed to the device so far
+    hipEvent_t copied = nullptr;
+    struct EventGuard { hipEvent_t& e; ~EventGuard() { if (e) (void)hipEventDestroy(e); } } eg{copied};
+    if (inflating) {
+        HIP_OK(hipStreamCreateWithFlags(&codec_stream, hipStreamNonBlocking));
+        codec = std::make_unique<EngineHandle>(1, device, codec_stream);
+        HIP_OK(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+        d_bad.reserve(2);
+        HIP_OK(hipMemsetAsync(d_bad.p, 0, 2 * sizeof(uint64_t), codec_stream));
+        const uint64_t guess = size * 6 + (64u << 20);        // level-1 FASTQ inflates 4-5.6x
+        room = std::thread([&, guess] {
+            try { HIP_OK(hipSetDevice(device)); StageClock::Scope t("  on the GPU: room for the text (under the read)"); into->text.room_for(guess, nullptr); }
+            catch (...) { room_error = std::current_exception(); }
+        });
+    }
+    auto launch_batch = [&](bool last) {
+        const uint64_t have = c.comp_off.size();
+        if (!inflating || have == launched || (!last && have - launched < kBatchMembers)) return;
+        if (room.joinable()) { room.join(); if (room_error) std::rethrow_exception(room_error); }
+        const uint64_t n = have - launched, need = c.text_bytes + 64;
+        if (need > into->text.cap) {                           // the guess was too small: everything inflated so far moves
+            HIP_OK(hipStreamSynchronize(codec_stream));
+            into->text.used = launched_bytes;
+            into->text.room_for(std::max<uint64_t>(need, into->text.cap + into->text.cap / 2) - into->text.used, codec_stream);
+        }
+        batches.emplace_back(new Batch());
+        Batch& b = *batches.back();
+        b.comp_off.reserve(n); b.out_off.reserve(n); b.comp_len.reserve(n); b.out_len.reserve(n); b.crc.reserve(n);
+        // the member arrays go up on the COPY stream: waiting for them must not wait for the batch before this one
+        HIP_OK(hipMemcpyAsync(b.comp_off.p, c.comp_off.data() + launched, n * sizeof(uint64_t), hipMemcpyHostToDevice, up));
+        HIP_OK(hipMemcpyAsync(b.out_off.p, c.out_off.data() + launched, n * sizeof(uint64_t), hipMemcpyHostToDevice, up));
+        HIP_OK(hipMemcpyAsync(b.comp_len.p, c.comp_len.data() + launched, n * sizeof(uint32_t), hipMemcpyHostToDevice, up));
+        HIP_OK(hipMemcpyAsync(b.out_len.p, c.out_len.data() + launched, n * sizeof(uint32_t), hipMemcpyHostToDevice, up));
+        HIP_OK(hipMemcpyAsync(b.crc.p, c.crc.data() + launched, n * sizeof(uint32_t), hipMemcpyHostToDevice, up));
+        HIP_OK(hipStreamSynchronize(up));                      // (the vectors may grow and move under the next block's walk)
+        HIP_OK(hipEventRecord(copied, up));                    // arrays and compressed bytes of these members are on the device
+        HIP_OK(hipStreamWaitEvent(codec_stream, copied, 0));
+        if (fqd_bgzf_inflate_async(codec->e, reinterpret_cast<const uint8_t*>(c.bytes.p), b.comp_off.p, b.comp_len.p, b.out_off.p, b.out_len.p,
+                                   b.crc.p, n, reinterpret_cast<uint8_t*>(into->text.p), d_bad.p) != FQD_OK)
+            throw DeviceError(std::string("GPU engine: ") + fqd_last_error(codec->e));
+        launched = have; launched_bytes = c.text_bytes;
+    };
     std::string tail;                          // bytes already read from `tail_at` on: a member may straddle two blocks
     uint64_t tail_at = 0, at = 0, member = 0;  // file offsets: of the tail, of the current block, of the member being parsed
     for (;;) {
@@ -1045,7 +1109,8 @@ static bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, 
             member += total;
         }
         HIP_OK(hipStreamSynchronize(up));
-        if (!ok) return false;
+        if (!ok) { if (inflating) (void)hipStreamSynchronize(codec_stream); return false; }
+        launch_batch(false);
         std::string keep;
         if (member < at + got) {
             if (member < at) keep.assign(tail, static_cast<size_t>(member - tail_at), std::string::npos);
@@ -1055,7 +1120,21 @@ static bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, 
         tail.swap(keep); tail_at = member;
         at += got;
     }
-    return at == size && member == size && c.text_bytes > 0;
+    const bool whole = at == size && member == size && c.text_bytes > 0;
+    if (inflating) {
+        if (whole) launch_batch(true);
+        HIP_OK(hipStreamSynchronize(codec_stream));
+        if (room.joinable()) { room.join(); if (room_error) std::rethrow_exception(room_error); }
+        if (whole) {
+            uint64_t bad[2] = {0, 0};
+            HIP_OK(hipMemcpy(bad, d_bad.p, sizeof bad, hipMemcpyDeviceToHost));
+            c.bad_members = bad[0] + bad[1];
+            c.inflated = true;
+            StageClock::Scope t("  on the GPU: compressed bytes freed");
+            c.bytes.release();
+        }
+    }
+    return whole;
 }
 
 static bool records_on_device(fqd_engine* e, hipStream_t stream, Format format, uint64_t text_bytes, FileOnDevice& f);
@@ -1065,6 +1144,10 @@ static bool records_on_device(fqd_engine* e, hipStream_t stream, Format format, 
 static bool finish_on_device(fqd_engine* e, hipStream_t stream, Format format, CompressedOnDevice& c, FileOnDevice& f)
 {
     auto engine_ok = [&](int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(e)); };
+    if (c.inflated) {                                         // fetch_bgzf did it under the read
+        if (c.bad_members) return false;
+        return records_on_device(e, stream, format, c.text_bytes, f);
+    }
     const uint64_t members = c.comp_off.size();
     Device<uint64_t> d_comp_off, d_out_off; Device<uint32_t> d_comp_len, d_out_len, d_crc;
     d_comp_off.reserve(members); d_out_off.reserve(members); d_comp_len.reserve(members); d_out_len.reserve(members); d_crc.reserve(members);
@@ -1263,6 +1346,24 @@ static void write_survivors(fqd_engine* e, hipStream_t stream, int S, FileOnDevi
     for (int s = 0; s < S; ++s) { if (o[s].error) std::rethrow_exception(o[s].error); if (close_sinks) sinks[s]->close(); }
 }
 
+// What the dedup engine of a resident run will hold, guessed from the sizes of the input files before anything of them has
+// been read, so that its key store and table can be allocated — and their pages cleared by the driver — on a helper thread
+// under the reads (the key store's first hipMalloc was 1.05 s of a 1.13 s "pair dedup" stage).  A guess
+// that is too small costs what it always cost (the store grows); one too large costs HBM nobody else wants.
+static void guess_capacity(int S, const std::string* in, uint64_t& reads, uint64_t& bases)
+{
+    reads = bases = 0;
+    uint64_t text[2] = {0, 0};
+    for (int s = 0; s < S; ++s) {
+        uint64_t size = 0;
+        if (!is_regular_file(in[s], size)) { reads = bases = 0; return; }
+        text[s] = has_gz_extension(in[s]) ? size * 5 : size;
+    }
+    const uint64_t least = S == 2 ? std::min(text[0], text[1]) : text[0];
+    reads = least / 280 + 1024;                                // a 150-base FASTQ record is ~316 bytes
+    bases = (text[0] + text[1]) / 2 + 4096;                    // about half of FASTQ text is sequence
+}
+
 // A plain regular file as it is to the tail of f.text (a pinned block, parallel preads, H2D); false: not such a file.
 static bool fetch_plain(const std::string& name, size_t block_bytes, int device, FileOnDevice& f, uint64_t& text_bytes)
 {
@@ -1320,16 +1421,25 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
     uint64_t n = 0, dups = 0;
     std::unique_ptr<EngineHandle> eng;
     SurvivorBuffers buffers;
+    std::thread make_engine; std::exception_ptr engine_error;
+    struct JoinGuard { std::thread& t; ~JoinGuard() { if (t.joinable()) t.join(); } } join_guard{make_engine};
     try {
         CompressedOnDevice packed[2];
         bool fetched[2] = {false, false};
         std::exception_ptr fetch_error[2];
         uint64_t plain_bytes[2] = {0, 0};
+        // the engine — its key store and table sized from the files' sizes — is made on a helper thread under the reads
+        uint64_t cap_reads = 0, cap_bases = 0;
+        guess_capacity(S, in, cap_reads, cap_bases);
+        make_engine = std::thread([&] {
+            try { HIP_OK(hipSetDevice(tuning_.device)); StageClock::Scope t("  on the GPU: engine, key store, table (under the read)"); eng = std::make_unique<EngineHandle>(S, tuning_.device, stream, cap_reads, cap_bases); }
+            catch (...) { engine_error = std::current_exception(); }
+        });
         {
             StageClock::Scope t("ordered/resident: files to HBM");
             auto fetch = [&](int s) {
                 try {
-                    fetched[s] = has_gz_extension(in[s]) ? fetch_bgzf(in[s], block_bytes, tuning_.device, packed[s])
+                    fetched[s] = has_gz_extension(in[s]) ? fetch_bgzf(in[s], block_bytes, tuning_.device, packed[s], &dev[s])
                                                          : fetch_plain(in[s], block_bytes, tuning_.device, dev[s], plain_bytes[s]);
                 } catch (const DeviceOutOfMemory&) { fetched[s] = false; }
                 catch (const DeviceError&) { fetched[s] = false; fetch_error[s] = std::current_exception(); }
@@ -1340,9 +1450,10 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
             fetch(0);
             if (S == 2) second.join();
         }
+        if (make_engine.joinable()) make_engine.join();
         for (int s = 0; s < S; ++s) if (fetch_error[s]) std::rethrow_exception(fetch_error[s]);
         for (int s = 0; s < S; ++s) if (!fetched[s]) return false;
-        eng = std::make_unique<EngineHandle>(S, tuning_.device, stream);
+        if (engine_error) std::rethrow_exception(engine_error);
         {
             StageClock::Scope t("ordered/resident: inflate + record scan on the GPU");
             for (int s = 0; s < S; ++s) {
@@ -1413,8 +1524,22 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
     hipStream_t stream = nullptr;
     HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
-    EngineHandle eng(2, tuning_.device, stream);
-    auto engine_ok = [&](int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng.e)); };
+    // the engine — key store and table sized from the files' sizes — is made on a helper thread under the reads of the
+    // inputs: its first use comes after them (guess_capacity)
+    struct LazyEngine {
+        std::unique_ptr<EngineHandle> holder; std::thread maker; std::exception_ptr error;
+        ~LazyEngine() { if (maker.joinable()) maker.join(); }
+        fqd_engine* get() { if (maker.joinable()) maker.join(); if (error) std::rethrow_exception(error); return holder->e; }
+    } eng;
+    {
+        uint64_t cap_reads = 0, cap_bases = 0;
+        guess_capacity(2, in, cap_reads, cap_bases);
+        eng.maker = std::thread([this, &eng, stream, cap_reads, cap_bases] {
+            try { HIP_OK(hipSetDevice(tuning_.device)); StageClock::Scope t("  on the GPU: engine, key store, table (under the read)"); eng.holder = std::make_unique<EngineHandle>(2, tuning_.device, stream, cap_reads, cap_bases); }
+            catch (...) { eng.error = std::current_exception(); }
+        });
+    }
+    auto engine_ok = [&](int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng.get())); };
     const size_t block_bytes = std::max<size_t>(1u << 20, std::min<size_t>(tuning_.block_bytes, static_cast<size_t>(memlimit_ > 0 ? memlimit_ / 16 : tuning_.block_bytes)));
 
     FileOnDevice dev[2];
@@ -1473,7 +1598,7 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
         auto fetch_or_load = [&](int s) {
             if (inflate_on_device()) {
                 try {
-                    if (has_gz_extension(in[s])) on_device[s] = fetch_bgzf(in[s], block_bytes, tuning_.device, packed[s]);
+                    if (has_gz_extension(in[s])) on_device[s] = fetch_bgzf(in[s], block_bytes, tuning_.device, packed[s], &dev[s]);
                     else plain_on_device[s] = fetch_plain(in[s], block_bytes, tuning_.device, dev[s], plain_bytes[s]);
                 }
                 catch (const DeviceOutOfMemory&) { err[s] = std::current_exception(); return; }   // rethrown below: the two-pass run takes over
@@ -1487,8 +1612,8 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
         for (int s = 0; s < 2; ++s) {
             if (!on_device[s] && !plain_on_device[s]) continue;
             StageClock::Scope t2("unordered/resident: inflate + record scan on the GPU");
-            const bool ok = on_device[s] ? finish_on_device(eng.e, stream, format_, packed[s], dev[s])
-                                         : records_on_device(eng.e, stream, format_, plain_bytes[s], dev[s]);
+            const bool ok = on_device[s] ? finish_on_device(eng.get(), stream, format_, packed[s], dev[s])
+                                         : records_on_device(eng.get(), stream, format_, plain_bytes[s], dev[s]);
             if (!ok) {                                                                  // read it again the host way: that one reports
                 dev[s].forget();
                 packed[s] = CompressedOnDevice();
@@ -1502,7 +1627,7 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
         for (int s = 0; s < 2; ++s) {
             FileOnDevice& f = dev[s];
             f.tag_off.reserve(f.n); f.tag_len.reserve(f.n);
-            engine_ok(fqd_extract_tags(eng.e, reinterpret_cast<const uint8_t*>(f.text.p), f.start.p, f.id_len.p, f.n, f.tag_off.p, f.tag_len.p));
+            engine_ok(fqd_extract_tags(eng.get(), reinterpret_cast<const uint8_t*>(f.text.p), f.start.p, f.id_len.p, f.n, f.tag_off.p, f.tag_len.p));
         }
     }
 
@@ -1517,7 +1642,7 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
     // order — outputs opened after the sort phase, then the merge (hpp:265-266) — a bad base found by the dedup cuts the
     // output at the same pair either way.
     JoinedPairs jp;
-    join_and_dedup(eng.e, stream, side, tuning_.reference_tail_rule, jp);
+    join_and_dedup(eng.get(), stream, side, tuning_.reference_tail_rule, jp);
     const uint64_t n_proc = jp.n_proc, upto = std::min<uint64_t>(n_proc, jp.written_below);
     uint64_t dups = 0;
     {
@@ -1531,7 +1656,7 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
     SurvivorBuffers buffers;
     {
         const bool gz_out[2] = {has_gz_extension(out[0]), has_gz_extension(out[1])};
-        plan_survivors(eng.e, 2, files, idx, jp.keep.p, upto, gz_out, memlimit_, buffers);
+        plan_survivors(eng.get(), 2, files, idx, jp.keep.p, upto, gz_out, memlimit_, buffers);
     }
 
     OutputFile sink0(out[0]), sink1(out[1]);
@@ -1540,7 +1665,7 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
     // ---- outputs: the device assembles windows of survivors in output order, the host writes them -----
     {
         StageClock::Scope t("unordered/resident: survivors out of HBM");
-        write_survivors(eng.e, stream, 2, files, idx, jp.keep.p, upto, dups, sinks, format_, memlimit_, true, &buffers);
+        write_survivors(eng.get(), stream, 2, files, idx, jp.keep.p, upto, dups, sinks, format_, memlimit_, true, &buffers);
     }
     if (tuning_.leave_memory_to_exit) g_leave_memory_to_exit = true;
     StageClock::report();

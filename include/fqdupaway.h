@@ -362,6 +362,12 @@ int  fqd_bgzf_deflate(fqd_engine* e, const uint8_t* src, uint64_t n, uint32_t li
 int  fqd_bgzf_inflate(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* comp_len,
                       const uint64_t* out_off, const uint32_t* out_len, const uint32_t* crc, uint64_t n_members,
                       uint8_t* text, uint64_t* n_bad);
+/* The same for one BATCH of members of a file that is still being read: queued on the engine's stream, nothing waited
+ * for; bad members are ADDED to the two uint64 at bad_counters (device; zeroed by the caller, read when it likes), so
+ * the inflate of what has arrived runs under the read of what has not. */
+int  fqd_bgzf_inflate_async(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* comp_len,
+                            const uint64_t* out_off, const uint32_t* out_len, const uint32_t* crc, uint64_t n_members,
+                            uint8_t* text, uint64_t* bad_counters);
 
 /* The n bytes of text (device) cut into records the way the reference's views do it (fastqview.cpp:92-138,
  * fastaview.cpp:78-100): a record is lines_per_record lines (4: FASTQ, 2: FASTA), starts with '@' / '>', and a FASTQ

@@ -63,6 +63,7 @@ struct Round {                           // buffers and events of one round in f
     uint64_t* slot = nullptr;            // where this round's keys are received (tail of the key store)
     hipEvent_t ev_part = nullptr, ev_xchg = nullptr, ev_spill = nullptr, ev_ins = nullptr, ev_done = nullptr, t0 = nullptr, t1 = nullptr;
     uint64_t n = 0, n_inserted = 0;
+    fqd_reads seg[2] = {};               // the round's input (it must stay where it is until the round's flags are final)
     uint8_t* keep_dst = nullptr;
     bool used = false;
     bool compact = false;                // owner side: a spill arrived and the round was laid out again, exactly
@@ -218,7 +219,16 @@ int finish_receive(fqd_shard* s, uint64_t k)
         std::vector<hipEvent_t> ready;
         for (Local& l : s->lr) {
             Round& r = l.rb[k & 1];
-            ready.push_back(r.ev_part);                        // the sources' send buffers have long been complete
+            bool over_out = false;
+            for (int p = 0; p < W; ++p) over_out = over_out || r.h_counts[p] > cap;
+            if (over_out && !s->padded) {
+                // the one-pass encoder leaves out what a full slab cannot take: this source groups the round again, the
+                // three-step way, which writes the spill region (same slabs, same origin: nothing already sent changes)
+                SH_HIP(s, hipSetDevice(l.device));
+                SH_ENG(s, l, fqd_encode_slabs(l.e, r.seg, r.n, uint32_t(W), cap, r.grouped, r.d_counts, r.origin, FQD_SLABS_EXACT));
+                SH_HIP(s, hipEventRecord(r.ev_part, l.es));
+            }
+            ready.push_back(r.ev_part);                        // the sources' send buffers are complete behind this
             if (!r.compact) continue;
             SH_HIP(s, hipSetDevice(l.device));
             // owner side: [all slabs as received][spill of source 0][of source 1]... in a buffer of its own
@@ -412,7 +422,7 @@ int fqd_shard_create(fqd_engine* const* engines, const fqd_shard_config* cfg, fq
         hipError_t err;
         if ((err = hipSetDevice(l.device)) != hipSuccess) return bail(std::string("hipSetDevice: ") + hipGetErrorString(err));
         if ((err = hipStreamCreateWithFlags(&l.cs, hipStreamNonBlocking)) != hipSuccess) return bail(std::string("hipStreamCreate: ") + hipGetErrorString(err));
-        if ((err = hipMalloc(reinterpret_cast<void**>(&l.records), cfg->round_reads * uint64_t(s->K + 1) * 8)) != hipSuccess)
+        if (s->padded && (err = hipMalloc(reinterpret_cast<void**>(&l.records), cfg->round_reads * uint64_t(s->K + 1) * 8)) != hipSuccess)
             return bail(std::string("hipMalloc(records): ") + hipGetErrorString(err));
         for (Round& r : l.rb) {
             if ((err = hipMalloc(reinterpret_cast<void**>(&r.grouped), slots * s->K * 8)) != hipSuccess ||
@@ -489,9 +499,14 @@ int fqd_shard_round(fqd_shard* s, const fqd_reads* seg, const uint64_t* n, uint8
         SH_HIP(s, hipSetDevice(l.device));
         if (r.used) SH_HIP(s, hipStreamWaitEvent(l.es, r.ev_done, 0));     // round k-2 has left these buffers
         r.used = true; r.n = n[a]; r.keep_dst = keep[a]; r.compact = false;
-        if (s->padded) SH_ENG(s, l, fqd_encode_padded(l.e, seg + a * s->S, n[a], s->cfg.len0, s->cfg.len1, l.records));
-        else           SH_ENG(s, l, fqd_encode_uniform(l.e, seg + a * s->S, n[a], l.records));
-        SH_ENG(s, l, fqd_partition_slabs(l.e, l.records, n[a], s->K, uint32_t(W), s->cap, r.grouped, r.d_counts, r.origin));
+        for (uint32_t m = 0; m < s->S; ++m) r.seg[m] = seg[a * s->S + m];
+        if (s->padded) {
+            SH_ENG(s, l, fqd_encode_padded(l.e, seg + a * s->S, n[a], s->cfg.len0, s->cfg.len1, l.records));
+            SH_ENG(s, l, fqd_partition_slabs(l.e, l.records, n[a], s->K, uint32_t(W), s->cap, r.grouped, r.d_counts, r.origin));
+        } else {
+            // one pass where it applies; a slab that overflows is noticed from the counts and the round grouped again (finish_receive)
+            SH_ENG(s, l, fqd_encode_slabs(l.e, seg + a * s->S, n[a], uint32_t(W), s->cap, r.grouped, r.d_counts, r.origin, 0u));
+        }
         SH_HIP(s, hipMemcpyAsync(r.h_counts, r.d_counts, size_t(W) * 8, hipMemcpyDeviceToHost, l.es));
         SH_HIP(s, hipMemcpyAsync(r.h_bad, fqd_internal_state(l.e), 8, hipMemcpyDeviceToHost, l.es));     // first bad byte so far, this round's encoder included
         SH_HIP(s, hipEventRecord(r.ev_part, l.es));

@@ -181,6 +181,14 @@ int  fqd_insert_keys(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t l
  * keep has n_slabs * slab_cap entries; those of unused slots mean nothing. */
 int  fqd_partition_slabs(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words, uint32_t n_parts,
                          uint64_t slab_cap, uint64_t* out_keys, uint64_t* counts, uint32_t* origin);
+/* fqd_encode_uniform + fqd_partition_slabs in one call — and, where it applies (single-end reads of one fixed length,
+ * at most 16 parts), in ONE pass over the input: every key is written once, straight into its slab, its place found by
+ * chaining the counts of the encoder's tiles (a decoupled look-back).  Same slabs, same origin[], same counts[] as the
+ * two calls; the one-pass form does not write the spill region (a key whose slab is full is not written at all — the
+ * counts say so): call again with FQD_SLABS_EXACT to have it. */
+#define FQD_SLABS_EXACT 1u
+int  fqd_encode_slabs(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t n_parts, uint64_t slab_cap,
+                      uint64_t* out_keys, uint64_t* counts, uint32_t* origin, uint32_t flags);
 int  fqd_insert_slabs(fqd_engine* e, const uint64_t* keys, uint32_t n_slabs, uint64_t slab_cap, const uint64_t* slab_count,
                       uint32_t len0, uint32_t len1, uint8_t* keep);
 

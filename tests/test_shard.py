@@ -351,3 +351,39 @@ def test_shard_group_refuses_a_read_longer_than_its_maximum():
         with pytest.raises(FqdError) as ei:
             g.flush()
         assert ei.value.code == 1 and "longer" in str(ei.value)
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("parts,cap", [(1, 70_000), (3, 30_000), (8, 9_000), (16, 5_000), (8, 2_000), (5, 16)])
+def test_one_pass_grouping_equals_the_three_step_path(paired, parts, cap):
+    """fqd_encode_slabs: the one-pass encoder (keys straight into their slabs, places from a look-back over the tiles)
+    must give the slabs, origin[] and counts[] of fqd_encode_uniform + fqd_partition_slabs — for slabs with room, for
+    slabs that overflow (what does not fit is left out, the counts stay true), for tiles that end short."""
+    from fastq_dupaway_amd import Engine, Reads
+    n = 61_003
+    S = 2 if paired else 1
+    lens = (150, 101)
+    dev = torch.device("cuda", 0)
+    with Engine(segments=S) as e:
+        W = e.key_words(lens[0], lens[1] if paired else 0)
+        bases = [torch.empty(n * lens[m] + 16, dtype=torch.uint8, device=dev) for m in range(S)]
+        for m in range(S):
+            e.synth_reads(21, 0, n, lens[m], 250, m, bases[m], None)
+        segs = [Reads(bases[m], uniform_len=lens[m], uniform_stride=lens[m]) for m in range(S)]
+        slots = parts * cap + n
+        out = {}
+        for exact in (True, False):
+            keys = torch.full((slots * W,), -7, dtype=torch.int64, device=dev)
+            origin = torch.full((slots,), -7, dtype=torch.int32, device=dev)
+            counts = torch.zeros(parts, dtype=torch.int64, device=dev)
+            e.encode_slabs(segs, n, parts, cap, keys, counts, origin, exact=exact)
+            e.sync()
+            out[exact] = (keys.cpu().numpy().reshape(slots, W), origin.cpu().numpy(), counts.cpu().numpy())
+    (k3, o3, c3), (k1, o1, c1) = out[True], out[False]
+    assert np.array_equal(c1, c3) and int(c3.sum()) == n
+    head = parts * cap
+    assert np.array_equal(o1[:head], o3[:head])
+    used = o3[:head] != -1
+    assert np.array_equal(k1[:head][used], k3[:head][used])
+    assert (c3 > cap).any() == (cap < 9_000) or parts == 1
+    assert np.all(o1[head:] == -7) and np.all(k1[head:] == -7)            # the one-pass form never touches the spill region

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--mem-limit", default="", help="-m value in MB (default: the CLI's 2048)")
     ap.add_argument("--keep-inputs", action="store_true", help="leave r1.fq.gz / r2.fq.gz in --dir (for a profiler run of the CLI on them)")
     ap.add_argument("--no-check", action="store_true", help="skip reading the outputs back")
+    ap.add_argument("--settle", type=float, default=0.0, help="seconds to wait before the first timed run (the kernel clears the device memory a process that "
+                                                              "has just exited gave back; an allocation waits for that clearing)")
     ap.add_argument("--also", default="", help="further timed runs on the same inputs, each under extra environment settings: "
                                                "'FQD_HOST_THREADS=8;FQD_HOST_THREADS=32,FQD_GZ_LEVEL=6' (only their -v lines are checked)")
     a = ap.parse_args()
@@ -95,6 +97,10 @@ def main():
     cmd = [str(_lib.CLI_PATH), "-i", str(gz[0]), "-u", str(gz[1]), "-o", str(outs[0]), "-p", str(outs[1]), "--fast", "--unordered", "-v"]
     if a.mem_limit:
         cmd += ["-m", a.mem_limit]
+    if a.settle > 0:
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        time.sleep(a.settle)
     t0 = time.perf_counter()
     base_env = dict(os.environ, FQD_HOST_TIMING="1")
     base_env.pop("FQD_GZ_LEVEL", None)
@@ -114,6 +120,8 @@ def main():
     for extra in filter(None, a.also.split(";")):
         env = dict(base_env)
         env.update(kv.split("=", 1) for kv in extra.split(","))
+        if "SLEEP" in env:                                    # "SLEEP=8,...": let the memory the run before gave back be cleared first
+            time.sleep(float(env.pop("SLEEP")))
         t1 = time.perf_counter()
         r2 = subprocess.run(cmd, capture_output=True, text=True, cwd=str(d), env=env)
         dt2 = time.perf_counter() - t1

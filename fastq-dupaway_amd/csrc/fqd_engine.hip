@@ -356,11 +356,7 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
             auto launch = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream, sv[0], n, first_idx, ks, hash_out, err, magic, h1);
             };
-            // FQD_ENCODE_PIPE=0: the encoder that stages, packs and only then asks for the next tile (round 2)
-            static const bool pipe = [] { const char* v = std::getenv("FQD_ENCODE_PIPE"); return v && std::atoi(v) != 0; }();
-            const uint64_t tile_chunks = (uint64_t(c.R) * seg[0].uniform_stride + 15 + 15) / 16;
-            if (c.lds_out && pipe && tile_chunks <= 10ull * c.R) launch(encode_staged_pipe_kernel<10>);
-            else if (c.lds_out) launch(encode_staged_kernel<true>); else launch(encode_staged_kernel<false>);
+            if (c.lds_out) launch(encode_staged_kernel<true>); else launch(encode_staged_kernel<false>);
         } else {
             auto launch = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream,
@@ -499,25 +495,11 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
         hipLaunchKernelGGL(bulk_hist1_kernel, dim3(part_grid), dim3(kPartThreads), 0, e->stream, hashes, hash_stride, n, g, hist1);
     hipLaunchKernelGGL(bulk_scan256_kernel, dim3(1), dim3(320), 0, e->stream,
                        static_cast<const uint32_t*>(hist1), nd1, start1, cursor1, tile_start1);
-    // scatter passes: 0 = one tile at a time, 1024 threads (round 2); 1/2 = software-pipelined with 1024 / 512 threads;
-    // 3/4 = 512 / 1024 threads, not pipelined (the A/B legs of tools/ab_bench.py)
-    static const int scatter_mode = [] { const char* v = std::getenv("FQD_SCATTER_MODE"); return v ? std::atoi(v) : 0; }();
-    auto scatter = [&](auto level, const uint64_t* h, uint32_t hs, uint32_t fi, const uint64_t* in, uint32_t* cursor, uint64_t* out, uint8_t* d2, uint32_t grid) {
-        constexpr int LV = decltype(level)::value;
-        auto go = [&](auto kernel, uint32_t threads) {
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), 0, e->stream, h, hs, fi, in, n, g,
-                               static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor, out, d2);
-        };
-        switch (scatter_mode) {
-            case 1:  go(bulk_scatter_v2_kernel<LV, 1024, true>, 1024u); break;
-            case 2:  go(bulk_scatter_v2_kernel<LV, 512, true>, 512u); break;
-            case 3:  go(bulk_scatter_v2_kernel<LV, 512, false>, 512u); break;
-            case 4:  go(bulk_scatter_v2_kernel<LV, 1024, false>, 1024u); break;
-            default: go(bulk_scatter_kernel<LV>, uint32_t(kPartThreads)); break;
-        }
-    };
-    scatter(std::integral_constant<int, 1>{}, hashes, hash_stride, uint32_t(first_idx), static_cast<const uint64_t*>(nullptr), cursor1, recA,
-            g.bits2 > 8 ? static_cast<uint8_t*>(nullptr) : p.digit2, part_grid);
+    // (round 3 measured, and dropped, software-pipelined and 512-thread forms of these passes and an encoder that keeps its next
+    //  tile's loads in flight: profiles/r03_ab_pipelining.jsonl — no gain; the phase stamps of `make STAMPS=1` show why)
+    hipLaunchKernelGGL(bulk_scatter_kernel<1>, dim3(part_grid), dim3(kPartThreads), 0, e->stream,
+                       hashes, hash_stride, uint32_t(first_idx), static_cast<const uint64_t*>(nullptr), n, g,
+                       static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor1, recA, g.bits2 > 8 ? static_cast<uint8_t*>(nullptr) : p.digit2);
     if (g.bits2) {
         const uint32_t grid2 = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile + nd1, uint64_t(e->n_cu) * part_per_cu));
         const uint32_t hgrid = uint32_t(std::min<uint64_t>((n + kPartTile - 1) / kPartTile + nd1, uint64_t(e->n_cu) * 2u));   // 2 KB of LDS: two 1024-thread blocks fill a CU's wave slots
@@ -525,18 +507,16 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
             hipLaunchKernelGGL(bulk_hist2_kernel<true>, dim3(hgrid), dim3(kPartThreads), 0, e->stream,
                                static_cast<const uint8_t*>(nullptr), static_cast<const uint64_t*>(recA), g, static_cast<const uint32_t*>(start1),
                                static_cast<const uint32_t*>(tile_start1), hist2);
-        else if (scatter_mode != 0)
-            hipLaunchKernelGGL(bulk_hist2_bytes_kernel, dim3(hgrid), dim3(kPartThreads), 0, e->stream,
-                               static_cast<const uint8_t*>(p.digit2), g, static_cast<const uint32_t*>(start1),
-                               static_cast<const uint32_t*>(tile_start1), hist2);
         else
             hipLaunchKernelGGL(bulk_hist2_kernel<false>, dim3(hgrid), dim3(kPartThreads), 0, e->stream,
                                static_cast<const uint8_t*>(p.digit2), static_cast<const uint64_t*>(nullptr), g, static_cast<const uint32_t*>(start1),
                                static_cast<const uint32_t*>(tile_start1), hist2);
         hipLaunchKernelGGL(bulk_scan_buckets_kernel, dim3(nd1), dim3(512), 0, e->stream,
                            static_cast<const uint32_t*>(hist2), g.bits2, static_cast<const uint32_t*>(start1), nd1, start2, cursor2);
-        scatter(std::integral_constant<int, 2>{}, static_cast<const uint64_t*>(nullptr), 0u, 0u, static_cast<const uint64_t*>(recA), cursor2, recB,
-                static_cast<uint8_t*>(nullptr), grid2);
+        hipLaunchKernelGGL(bulk_scatter_kernel<2>, dim3(grid2), dim3(kPartThreads), 0, e->stream,
+                           static_cast<const uint64_t*>(nullptr), 0u, 0u, static_cast<const uint64_t*>(recA), n, g,
+                           static_cast<const uint32_t*>(start1), static_cast<const uint32_t*>(tile_start1), cursor2, recB,
+                           static_cast<uint8_t*>(nullptr));
         final_recs = recB; bstart = start2;
     }
     }
@@ -1014,7 +994,10 @@ int fqd_encode_slabs(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t n
         if (!seg_is_uniform(seg[s])) return e->fail(FQD_ERR_ARG, "fqd_encode_slabs: uniform batches only (fqd_encode_padded + fqd_partition_slabs take the others)");
     HIP_TRY(e, hipSetDevice(e->device));
     const uint32_t W = seg_words(seg[0].uniform_len) + (e->S == 2 ? seg_words(seg[1].uniform_len) : 0u);
-    static const bool one_pass_on = [] { const char* v = std::getenv("FQD_ENCODE_GROUP"); return !v || std::atoi(v) != 0; }();
+    // off unless asked for: measured on 100 M reads (bench.py --config sharded1, one rank) the look-back makes the encoder take 8.9 ms
+    // against 4.4 + 5.0 ms for encode + grouping in three steps — a tile is only 256 reads, so ~1000 tiles are in flight at once
+    // and each sums its way back through most of them, one global round trip at a time
+    static const bool one_pass_on = [] { const char* v = std::getenv("FQD_ENCODE_GROUP"); return v && std::atoi(v) != 0; }();
     // a tile: 256 reads, or 128 pairs (one lane per mate); every key is parked over its own read's bytes in LDS (encode_staged)
     const uint32_t per_tile = e->S == 2 ? kBlock / 2 : kBlock;
     const uint64_t tile0 = (uint64_t(per_tile) * seg[0].uniform_stride + 32 + 15) & ~15ull;

@@ -368,85 +368,6 @@ void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
     if (h1.hist) hist1_flush(lhist, h1.hist);
 }
 
-// The same encoder (LDS_OUT form) with the NEXT tile's loads in flight while this tile is packed: a lane keeps
-// NCH 16-byte chunks of the next tile in registers (NCH * R * 16 bytes >= one tile; 10 for 150-byte reads at
-// R = 256), requested right after the current tile has been put into LDS and written there once the workgroup is
-// done with it.  Four workgroups per CU (LDS) then hold four tiles of loads in flight all the time instead of
-// only while they are in their staging phase.  Host side picks it when the tile fits NCH chunks per lane.
-template <int NCH>
-__global__ __launch_bounds__(kBlock)
-void encode_staged_pipe_kernel(SegView s0, uint64_t n, uint64_t first_idx,
-                               KeyStore ks, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ err, uint32_t rw_magic, Hist1 h1)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    __shared__ __attribute__((aligned(16))) uint32_t lhist[256];
-    if (h1.hist) hist1_clear(lhist);
-    uint64_t* lds64 = reinterpret_cast<uint64_t*>(lds);
-    u32x4* lds16 = reinterpret_cast<u32x4*>(lds);
-    const uint32_t R = blockDim.x;
-    const uint32_t row_words = ks.W0 + ks.lead;
-    const uint64_t n_tiles = (n + R - 1) / R;
-    uint64_t tile = blockIdx.x;
-    if (tile < n_tiles) {
-        u32x4 v[NCH];
-        uint32_t n16 = 0, in0 = 0, nr = 0;
-        auto request = [&](uint64_t t) {
-            const uint64_t r0 = t * R;
-            nr = uint32_t(n - r0 < R ? n - r0 : R);
-            const uint8_t* g0 = s0.bases + r0 * uint64_t(s0.ustride);
-            const uint32_t bytes = (nr - 1u) * s0.ustride + s0.ulen;
-            in0 = uint32_t(reinterpret_cast<uintptr_t>(g0) & 15u);
-            n16 = (in0 + bytes + 15u) >> 4;
-            const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(g0 - in0);
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) { const uint32_t c = threadIdx.x + uint32_t(k) * R; v[k] = __builtin_nontemporal_load(&src[c < n16 ? c : n16 - 1u]); }
-        };
-        request(tile);
-        for (;;) {
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) { const uint32_t c = threadIdx.x + uint32_t(k) * R; if (c < n16) lds16[c] = v[k]; }
-            __syncthreads();
-            const uint64_t r0 = tile * R;
-            const uint32_t cur_in0 = in0, cur_nr = nr;
-            const uint64_t next = tile + gridDim.x;
-            if (next < n_tiles) request(next);                 // in flight while this tile is packed
-            const uint32_t t = threadIdx.x;
-            const uint64_t i = r0 + t;
-            const uint32_t l0 = s0.ulen;
-            if (t < cur_nr) {
-                uint64_t h = hash_begin(l0, 0);
-                const uint32_t b0 = cur_in0 + t * s0.ustride;
-                uint64_t* row = lds64 + ((b0 + 4u + 7u) >> 3) + ks.lead;
-                uint64_t* out = row;
-                auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
-                const uint32_t diff = pack_mate(lds + (b0 >> 2), b0 & 3u, l0, sink);
-                h = hash_end(h) & h1.hash_and;
-                if (ks.lead) row[-1] = h;
-                if (hash_out) hash_out[i] = h;
-                if (h1.hist) atomicAdd(&lhist[bucket_of(h, h1.g) >> h1.g.bits2], 1u);
-                if (diff) {
-                    const uint64_t e = locate_bad_base(s0.bases + i * uint64_t(s0.ustride), l0, nullptr, 0, first_idx + i);
-                    if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
-                }
-            }
-            {
-                const uint32_t wave = t >> 6, lane = t & 63u;
-                const uint32_t wave_reads = (cur_nr > wave * 64u) ? ((cur_nr - wave * 64u < 64u) ? cur_nr - wave * 64u : 64u) : 0u;
-                uint64_t* __restrict__ gout = ks.keys + (first_idx + r0 + wave * 64u) * uint64_t(ks.stride);
-                const uint32_t total = wave_reads * row_words;
-                for (uint32_t x = lane; x < total; x += 64u) {
-                    const uint32_t rr = __umulhi(x, rw_magic), kk = x - rr * row_words;
-                    __builtin_nontemporal_store(lds64[((cur_in0 + (wave * 64u + rr) * s0.ustride + 4u + 7u) >> 3) + kk], &gout[x]);
-                }
-            }
-            __syncthreads();
-            if (next >= n_tiles) break;
-            tile = next;
-        }
-    }
-    if (h1.hist) hist1_flush(lhist, h1.hist);
-}
-
 // Paired variant: ONE LANE PER MATE (lane 2p = mate 1 of pair p, lane 2p+1 = mate 2), so a
 // 256-lane workgroup stages 128 pairs (2 x 19 KiB) and runs at the same wave occupancy as the
 // single-end encoder.  Each lane hashes and parks its own mate (same in-place rule, per mate:
@@ -732,7 +653,7 @@ __device__ __forceinline__ uint32_t part_q(uint64_t hash, const BulkGeom& g)
 // digit's run reserves its place with ONE atomicAdd on that digit's cursor, and the runs are
 // copied out contiguously.
 template <int LEVEL>
-__global__ __launch_bounds__(kPartThreads)
+__global__ __launch_bounds__(kPartThreads, 8)            // 8 waves per SIMD = two of these workgroups per CU (LDS allows two): at most 64 VGPRs (level 2 took 65)
 void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stride, uint32_t first_idx,
                          const uint64_t* __restrict__ in, uint64_t n, BulkGeom g,
                          const uint32_t* __restrict__ start1, const uint32_t* __restrict__ tile_start1,
@@ -834,137 +755,6 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
     STAMP_FLUSH(LEVEL - 1);
 }
 
-// The same pass, software-pipelined (the scatters issued 6-12 % of their cycles, each tile waiting
-// out its own load round trip behind block-wide barriers).  Differences to bulk_scatter_kernel:
-//   * the records of tile t+1 are requested while tile t is ranked, scanned and written out (PIPE), so a
-//     workgroup always has a tile of loads in flight;
-//   * THREADS x (8192 / THREADS) records per lane: at 512 threads a lane holds two tiles' worth of registers
-//     inside the 128-VGPR budget of two workgroups per CU (the 1024-thread level-2 kernel needs 65 VGPRs,
-//     one over what lets two of them share a CU);
-//   * level 2 finds its tile's level-1 digit in an LDS copy of the tile table instead of eight dependent
-//     global loads per tile.
-template <int LEVEL, int THREADS, bool PIPE>
-__global__ __launch_bounds__(THREADS)
-void bulk_scatter_v2_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stride, uint32_t first_idx,
-                            const uint64_t* __restrict__ in, uint64_t n, BulkGeom g,
-                            const uint32_t* __restrict__ start1, const uint32_t* __restrict__ tile_start1,
-                            uint32_t* __restrict__ cursor, uint64_t* __restrict__ out,
-                            uint8_t* __restrict__ digit2_out)
-{
-    constexpr int PER = kPartTile / THREADS;
-    __shared__ uint64_t stage[kPartTile];
-    __shared__ uint8_t sdig[LEVEL == 1 ? kPartTile : 16];
-    constexpr int kBins = (LEVEL == 1) ? 256 : 512;
-    __shared__ uint32_t cnt[kBins], lstart[kBins], gbase[kBins];
-    __shared__ uint32_t ts1[LEVEL == 1 ? 4 : 260], st1[LEVEL == 1 ? 4 : 260];
-    __shared__ uint32_t n_valid;
-    const uint32_t nd1 = 1u << g.bits1, mask2 = (1u << g.bits2) - 1u;
-    if (LEVEL == 2) {
-        for (uint32_t k = threadIdx.x; k <= nd1; k += THREADS) { ts1[k] = tile_start1[k]; st1[k] = start1[k]; }
-        __syncthreads();
-    }
-    const uint64_t n_tiles = (LEVEL == 1) ? (n + kPartTile - 1) / kPartTile : ts1[nd1];
-    auto range_of = [&](uint64_t tile, uint64_t& lo, uint32_t& count, uint32_t& d1) {
-        if (LEVEL == 1) { lo = tile * kPartTile; count = uint32_t(n - lo < kPartTile ? n - lo : kPartTile); d1 = 0; }
-        else {
-            uint32_t a = 0, b = nd1;
-            while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (ts1[m] <= tile) a = m; else b = m; }
-            d1 = a;
-            lo = st1[a] + (tile - ts1[a]) * uint64_t(kPartTile);
-            const uint64_t end = st1[a + 1];
-            count = uint32_t(end - lo < kPartTile ? end - lo : kPartTile);
-        }
-    };
-    auto request = [&](uint64_t lo, uint32_t count, uint64_t (&r)[PER]) {
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const uint32_t x = threadIdx.x + k * THREADS;
-            const uint64_t at = lo + (x < count ? x : count - 1u);
-            r[k] = (LEVEL == 1) ? hashes[at * uint64_t(hash_stride)] : in[at];
-        }
-    };
-    uint64_t tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-    uint64_t lo; uint32_t count, d1;
-    range_of(tile, lo, count, d1);
-    uint64_t rec[PER];
-    request(lo, count, rec);
-    for (;;) {
-        const uint64_t next = tile + gridDim.x;
-        const bool more = next < n_tiles;
-        for (int k = threadIdx.x; k < kBins; k += THREADS) cnt[k] = 0;
-        __syncthreads();
-        uint32_t dr[PER];                                       // digit (9 bits) | rank in the tile's digit << 9
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const uint32_t x = threadIdx.x + k * THREADS;
-            dr[k] = 0xFFFFFFFFu;                                // no record: past the tile's end, or a skipped position
-            if (x < count && (LEVEL != 1 || rec[k] != kSkipHash)) {
-                uint32_t dig;
-                if (LEVEL == 1) {
-                    const uint64_t h = rec[k];
-                    rec[k] = (uint64_t(part_q(h, g)) << 32) | (first_idx + uint32_t(lo + x));
-                    dig = bucket_of(h, g) >> g.bits2;
-                } else {
-                    dig = (uint32_t(rec[k] >> 32) >> g.seg_bits) & mask2;
-                }
-                dr[k] = dig | (atomicAdd(&cnt[dig], 1u) << 9);
-            }
-        }
-        uint64_t nlo = 0; uint32_t ncount = 0, nd = 0;
-        uint64_t nxt[PER];
-        if (PIPE && more) { range_of(next, nlo, ncount, nd); request(nlo, ncount, nxt); }
-        __syncthreads();
-        if (threadIdx.x < 64) {                               // exclusive scan of the counts by one wave
-            constexpr int kPer = kBins / 64;
-            uint32_t c[kPer], s = 0;
-#pragma unroll
-            for (int k = 0; k < kPer; ++k) { c[k] = cnt[threadIdx.x * kPer + k]; s += c[k]; }
-            uint32_t inc = s;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(inc, d, 64); if (int(threadIdx.x) >= d) inc += up; }
-            uint32_t ex = inc - s;
-#pragma unroll
-            for (int k = 0; k < kPer; ++k) { lstart[threadIdx.x * kPer + k] = ex; ex += c[k]; }
-            if (threadIdx.x == 63) n_valid = inc;
-        }
-        __syncthreads();
-        for (int k = threadIdx.x; k < kBins; k += THREADS)
-            gbase[k] = cnt[k] ? atomicAdd(&cursor[(LEVEL == 1 ? 0u : (d1 << g.bits2)) + k], cnt[k]) : 0u;
-#pragma unroll
-        for (int k = 0; k < PER; ++k)
-            if (dr[k] != 0xFFFFFFFFu) {
-                const uint32_t dig = dr[k] & 511u, at = lstart[dig] + (dr[k] >> 9);
-                stage[at] = rec[k];
-                if (LEVEL == 1) sdig[at] = uint8_t(dig);
-            }
-        __syncthreads();
-        const uint32_t valid = n_valid;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const uint32_t x = threadIdx.x + k * THREADS;
-            if (x < valid) {
-                const uint64_t v = stage[x];
-                const uint32_t d = (LEVEL == 1) ? uint32_t(sdig[x]) : ((uint32_t(v >> 32) >> g.seg_bits) & mask2);
-                const uint32_t to = gbase[d] + (x - lstart[d]);
-                out[to] = v;
-                if (LEVEL == 1 && digit2_out) digit2_out[to] = uint8_t((uint32_t(v >> 32) >> g.seg_bits) & mask2);
-            }
-        }
-        __syncthreads();
-        if (!more) break;
-        if (PIPE) {
-            lo = nlo; count = ncount; d1 = nd;
-#pragma unroll
-            for (int k = 0; k < PER; ++k) rec[k] = nxt[k];
-        } else {
-            range_of(next, lo, count, d1);
-            request(lo, count, rec);
-        }
-        tile = next;
-    }
-}
-
 // Level-2 histogram over the level-1 output (read through the 1-byte level-2 digits the
 // level-1 scatter leaves beside the records: an eighth of the bytes).  A tile lies inside one
 // level-1 digit, so its counts go to consecutive buckets; LDS-aggregated, one global add per bin.
@@ -997,65 +787,6 @@ void bulk_hist2_kernel(const uint8_t* __restrict__ digit2_in, const uint64_t* __
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) if (h[k]) atomicAdd(&hist2[(d1 << g.bits2) + k], h[k]);
         __syncthreads();
-    }
-}
-
-// The byte-digit form of the level-2 histogram with the tile table in LDS, eight digits per load and the next
-// tile's load issued before this tile is counted.
-__global__ __launch_bounds__(kPartThreads)
-void bulk_hist2_bytes_kernel(const uint8_t* __restrict__ digit2_in, BulkGeom g, const uint32_t* __restrict__ start1,
-                             const uint32_t* __restrict__ tile_start1, uint32_t* __restrict__ hist2)
-{
-    __shared__ uint32_t h[256];
-    __shared__ uint32_t ts1[260], st1[260];
-    const uint32_t nd1 = 1u << g.bits1, nd2 = 1u << g.bits2;
-    for (uint32_t k = threadIdx.x; k <= nd1; k += kPartThreads) { ts1[k] = tile_start1[k]; st1[k] = start1[k]; }
-    __syncthreads();
-    const uint64_t n_tiles = ts1[nd1];
-    auto range_of = [&](uint64_t tile, uint64_t& lo, uint64_t& hi, uint32_t& d1) {
-        uint32_t a = 0, b = nd1;
-        while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (ts1[m] <= tile) a = m; else b = m; }
-        d1 = a;
-        lo = st1[a] + (tile - ts1[a]) * uint64_t(kPartTile);
-        hi = lo + kPartTile < st1[a + 1] ? lo + kPartTile : st1[a + 1];
-    };
-    // a tile of <= 8192 bytes starting anywhere covers <= 1025 aligned 8-byte words: word t for lane t, the last by lane 0
-    auto request = [&](uint64_t lo, uint64_t hi, uint64_t (&w)[2]) {
-        const uint64_t a0 = lo & ~7ull;
-        const uint64_t at = a0 + 8ull * threadIdx.x;
-        w[0] = at < hi ? *reinterpret_cast<const uint64_t*>(digit2_in + at) : 0ull;
-        const uint64_t at2 = a0 + 8ull * kPartThreads;
-        w[1] = (threadIdx.x == 0 && at2 < hi) ? *reinterpret_cast<const uint64_t*>(digit2_in + at2) : 0ull;
-    };
-    uint64_t tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-    uint64_t lo, hi; uint32_t d1;
-    range_of(tile, lo, hi, d1);
-    uint64_t w[2];
-    request(lo, hi, w);
-    for (;;) {
-        const uint64_t next = tile + gridDim.x;
-        const bool more = next < n_tiles;
-        for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) h[k] = 0;
-        __syncthreads();
-        uint64_t nlo = 0, nhi = 0; uint32_t nd = 0; uint64_t nw[2] = {0, 0};
-        if (more) { range_of(next, nlo, nhi, nd); request(nlo, nhi, nw); }
-        const uint64_t a0 = lo & ~7ull;
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            const uint64_t at = a0 + 8ull * (part ? uint64_t(kPartThreads) : uint64_t(threadIdx.x));
-            if (part == 1 && threadIdx.x != 0) break;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const uint64_t idx = at + b;
-                if (idx >= lo && idx < hi) atomicAdd(&h[uint32_t(w[part] >> (8 * b)) & (nd2 - 1u) & 255u], 1u);
-            }
-        }
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < nd2; k += kPartThreads) if (h[k]) atomicAdd(&hist2[(d1 << g.bits2) + k], h[k]);
-        __syncthreads();
-        if (!more) break;
-        tile = next; lo = nlo; hi = nhi; d1 = nd; w[0] = nw[0]; w[1] = nw[1];
     }
 }
 

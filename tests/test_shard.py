@@ -355,11 +355,12 @@ def test_shard_group_refuses_a_read_longer_than_its_maximum():
 
 @pytest.mark.parametrize("paired", [False, True])
 @pytest.mark.parametrize("parts,cap", [(1, 70_000), (3, 30_000), (8, 9_000), (16, 5_000), (8, 2_000), (5, 16)])
-def test_one_pass_grouping_equals_the_three_step_path(paired, parts, cap):
+def test_one_pass_grouping_equals_the_three_step_path(monkeypatch, paired, parts, cap):
     """fqd_encode_slabs: the one-pass encoder (keys straight into their slabs, places from a look-back over the tiles)
     must give the slabs, origin[] and counts[] of fqd_encode_uniform + fqd_partition_slabs — for slabs with room, for
     slabs that overflow (what does not fit is left out, the counts stay true), for tiles that end short."""
     from fastq_dupaway_amd import Engine, Reads
+    monkeypatch.setenv("FQD_ENCODE_GROUP", "1")
     n = 61_003
     S = 2 if paired else 1
     lens = (150, 101)
@@ -385,5 +386,5 @@ def test_one_pass_grouping_equals_the_three_step_path(paired, parts, cap):
     assert np.array_equal(o1[:head], o3[:head])
     used = o3[:head] != -1
     assert np.array_equal(k1[:head][used], k3[:head][used])
-    assert (c3 > cap).any() == (cap < 9_000) or parts == 1
+    assert (c3 > cap).any() == (cap in (2_000, 16))
     assert np.all(o1[head:] == -7) and np.all(k1[head:] == -7)            # the one-pass form never touches the spill region

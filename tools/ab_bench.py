@@ -10,13 +10,9 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 DEFAULT = [
-    ("r2 (scatter 0, no encoder prefetch)", {"FQD_SCATTER_MODE": "0", "FQD_ENCODE_PIPE": "0"}),
-    ("scatter 4: 1024 thr, LDS tile table", {"FQD_SCATTER_MODE": "4", "FQD_ENCODE_PIPE": "0"}),
-    ("scatter 3: 512 thr", {"FQD_SCATTER_MODE": "3", "FQD_ENCODE_PIPE": "0"}),
-    ("scatter 1: 1024 thr, pipelined", {"FQD_SCATTER_MODE": "1", "FQD_ENCODE_PIPE": "0"}),
-    ("scatter 2: 512 thr, pipelined", {"FQD_SCATTER_MODE": "2", "FQD_ENCODE_PIPE": "0"}),
-    ("encoder prefetch, scatter 0", {"FQD_SCATTER_MODE": "0", "FQD_ENCODE_PIPE": "1"}),
-    ("encoder prefetch + scatter 2", {"FQD_SCATTER_MODE": "2", "FQD_ENCODE_PIPE": "1"}),
+    ("as built", {}),
+    ("dedup: eight lanes x 8 bytes per candidate", {"FQD_DEDUP_VL": "0"}),
+    ("encoder: 14 KB of LDS more per workgroup (3 per CU)", {"FQD_ENC_EXTRA_LDS": "14336"}),
 ]
 
 

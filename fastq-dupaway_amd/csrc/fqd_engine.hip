@@ -997,7 +997,8 @@ int fqd_encode_slabs(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t n
     // off unless asked for: measured on 100 M reads (bench.py --config sharded1, one rank) the look-back makes the encoder take 8.9 ms
     // against 4.4 + 5.0 ms for encode + grouping in three steps — a tile is only 256 reads, so ~1000 tiles are in flight at once
     // and each sums its way back through most of them, one global round trip at a time
-    static const bool one_pass_on = [] { const char* v = std::getenv("FQD_ENCODE_GROUP"); return v && std::atoi(v) != 0; }();
+    const char* group_env = std::getenv("FQD_ENCODE_GROUP");                 // (read per call: tests switch it inside one process)
+    const bool one_pass_on = group_env && std::atoi(group_env) != 0;
     // a tile: 256 reads, or 128 pairs (one lane per mate); every key is parked over its own read's bytes in LDS (encode_staged)
     const uint32_t per_tile = e->S == 2 ? kBlock / 2 : kBlock;
     const uint64_t tile0 = (uint64_t(per_tile) * seg[0].uniform_stride + 32 + 15) & ~15ull;

@@ -24,7 +24,9 @@ __device__ unsigned long long g_stamps[8][16];
     if (threadIdx.x == 0) { for (int q_ = 0; q_ < 16; ++q_) st_acc_[q_] = 0; st_last_ = wall_clock64(); }
 #define STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); st_acc_[i] += now_ - st_last_; st_last_ = now_; } } while (0)
 #define STAMP_FLUSH(kid) do { if (threadIdx.x == 0) for (int q_ = 0; q_ < 16; ++q_) if (st_acc_[q_]) atomicAdd(&g_stamps[kid][q_], st_acc_[q_]); } while (0)
+#define STAMP_LOADS_IN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")      /* so that a stamp behind it separates waiting for loads from working on them */
 #else
+#define STAMP_LOADS_IN() do { } while (0)
 #define STAMP_DECL
 #define STAMP(i) do { } while (0)
 #define STAMP_FLUSH(kid) do { } while (0)
@@ -691,6 +693,7 @@ void bulk_scatter_kernel(const uint64_t* __restrict__ hashes, uint32_t hash_stri
             const uint64_t at = lo + (r < count ? r : count - 1u);
             rec[k] = (LEVEL == 1) ? hashes[at * uint64_t(hash_stride)] : in[at];
         }
+        STAMP_LOADS_IN(); STAMP(10);                          // (diagnostic build) the tile's round trip, apart from the ranking
 #pragma unroll
         for (int k = 0; k < kPartPer; ++k) {
             const uint32_t r = threadIdx.x + k * kPartThreads;
@@ -942,6 +945,7 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
 #pragma unroll
                     for (uint32_t u = 0; u < kDedupLoads; ++u) { const uint32_t c = c0 + u * blockDim.x; v[u] = recs[chunk_lo + (c < chunk_n ? c : chunk_n - 1u)]; }
                 }
+                STAMP_LOADS_IN(); STAMP(9);                   // (diagnostic build) the records' round trip, apart from the walks
 #pragma unroll
                 for (uint32_t u = 0; u < kDedupLoads; ++u) {
                     if (c0 + u * blockDim.x < chunk_n) {

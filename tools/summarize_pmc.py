@@ -23,7 +23,7 @@ ROOT = Path(__file__).resolve().parents[1]
 
 def counter_avgs(directory, name):
     out = collections.defaultdict(list)
-    for f in glob.glob(f"{directory}/*/*counter_collection.csv"):
+    for f in glob.glob(f"{directory}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == name and "fqd::" in r["Kernel_Name"]:
                 out[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
@@ -35,7 +35,7 @@ def main():
     prof = ROOT / "profiles"
     prof.mkdir(exist_ok=True)
     rows = []
-    for f in glob.glob(f"{stats_dir}/*/*kernel_stats.csv"):
+    for f in glob.glob(f"{stats_dir}/**/*kernel_stats.csv", recursive=True):
         rows = list(csv.DictReader(open(f)))
         (prof / f"{tag}_kernel_stats.csv").write_text(open(f).read())
     fetch = counter_avgs(fetch_dir, "FETCH_SIZE")

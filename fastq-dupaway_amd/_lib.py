@@ -146,7 +146,7 @@ def load_library():
     L.fqd_range_keep.argtypes = [vp, vp, u64, u32, vp, C.POINTER(u64)]
     L.fqd_max_u32.argtypes = [vp, vp, u64, C.POINTER(u32)]
     L.fqd_partition_slabs.argtypes = [vp, vp, u64, u32, u32, u64, vp, vp, vp]
-    L.fqd_encode_slabs.argtypes = [vp, C.POINTER(ReadsDesc), u64, u32, u64, vp, vp, vp, u32]
+    L.fqd_encode_slabs.argtypes = [vp, C.POINTER(ReadsDesc), u64, u32, u64, u32, u64, vp, vp, vp, vp, u32]
     L.fqd_insert_slabs.argtypes = [vp, vp, u32, u64, vp, u32, u32, vp]
     L.fqd_shard_unique_id.argtypes = [vp]
     L.fqd_shard_slab_capacity.argtypes = [u64, C.c_int32, u32]

@@ -979,68 +979,76 @@ int fqd_partition_slabs(fqd_engine* e, const uint64_t* records, uint64_t n, uint
     return partition_impl(e, records, n, key_words, n_parts, out_keys, counts, origin, 1u, slab_cap);
 }
 
-// Encode + group by owner into slabs.  One pass (encode_group_kernel) where it applies — single-end reads of one fixed
-// length, equally spaced, a tile of which fits LDS with room for its keys, at most kGroupParts owners — and no slab can
-// overflow unnoticed: counts[] are always the true counts, a key whose slab is full is just not written.  flags &
-// FQD_SLABS_EXACT (or anything the one-pass kernel does not take): the three-step path through an internal record
-// buffer, which also writes the spill region.  Both give the same slabs, the same origin[] and the same counts.
-int fqd_encode_slabs(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t n_parts, uint64_t slab_cap,
-                     uint64_t* out_keys, uint64_t* counts, uint32_t* origin, uint32_t flags)
+// Encode + group by owner into slabs cut into one sub-slab per chunk of the input (fqd_kernels.hpp, encode_chunks).
+// One pass where it applies — reads of one fixed length per mate, equally spaced, a tile of which fits LDS with room
+// for its keys, at most kGroupParts owners, chunks of whole tiles — otherwise, or with FQD_SLABS_EXACT, the three-step
+// path through an internal record buffer: slabs filled from their first slot on (the same thing seen as full, partial
+// and empty sub-slabs), spill region written.  chunk_counts[p * n_chunks + c] and totals[p] are the TRUE counts either
+// way; the one-pass form does not write a key whose sub-slab is full.
+int fqd_encode_slabs(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t n_parts, uint64_t chunk_reads, uint32_t n_chunks, uint64_t sub_cap,
+                     uint64_t* out_keys, uint64_t* chunk_counts, uint64_t* totals, uint32_t* origin, uint32_t flags)
 {
     if (!e) return FQD_ERR_ARG;
-    if (!seg || !n_parts || !slab_cap || !counts || (n && (!out_keys || !origin)) || n > 0xFFFFFFFFull || slab_cap * n_parts + n > 0xFFFFFFFFull)
+    const uint64_t slab_cap = uint64_t(n_chunks) * sub_cap;
+    if (!seg || !n_parts || !n_chunks || !sub_cap || !chunk_reads || !chunk_counts || !totals || (n && (!out_keys || !origin)) || n > 0xFFFFFFFFull ||
+        slab_cap * n_parts + n > 0xFFFFFFFFull || n > chunk_reads * n_chunks)
         return e->fail(FQD_ERR_ARG, "fqd_encode_slabs: bad arguments");
     for (int s = 0; s < e->S; ++s)
         if (!seg_is_uniform(seg[s])) return e->fail(FQD_ERR_ARG, "fqd_encode_slabs: uniform batches only (fqd_encode_padded + fqd_partition_slabs take the others)");
     HIP_TRY(e, hipSetDevice(e->device));
     const uint32_t W = seg_words(seg[0].uniform_len) + (e->S == 2 ? seg_words(seg[1].uniform_len) : 0u);
-    // off unless asked for: measured on 100 M reads (bench.py --config sharded1, one rank) the look-back makes the encoder take 8.9 ms
-    // against 4.4 + 5.0 ms for encode + grouping in three steps — a tile is only 256 reads, so ~1000 tiles are in flight at once
-    // and each sums its way back through most of them, one global round trip at a time
-    const char* group_env = std::getenv("FQD_ENCODE_GROUP");                 // (read per call: tests switch it inside one process)
-    const bool one_pass_on = group_env && std::atoi(group_env) != 0;
+    const char* group_env = std::getenv("FQD_ENCODE_GROUP");                 // FQD_ENCODE_GROUP=0: always the three steps (read per call: tests switch it inside one process)
+    const bool one_pass_on = !group_env || std::atoi(group_env) != 0;
     // a tile: 256 reads, or 128 pairs (one lane per mate); every key is parked over its own read's bytes in LDS (encode_staged)
     const uint32_t per_tile = e->S == 2 ? kBlock / 2 : kBlock;
     const uint64_t tile0 = (uint64_t(per_tile) * seg[0].uniform_stride + 32 + 15) & ~15ull;
     const uint64_t tile1 = e->S == 2 ? ((uint64_t(per_tile) * seg[1].uniform_stride + 32 + 15) & ~15ull) : 0;
     const uint64_t tile_bytes = tile0 + tile1;
     const uint32_t W_0 = seg_words(seg[0].uniform_len), W_1 = e->S == 2 ? seg_words(seg[1].uniform_len) : 0u;
-    bool one_pass = one_pass_on && !(flags & FQD_SLABS_EXACT) && n_parts <= kGroupParts && !(e->flags & FQD_FLAG_NO_STAGE) &&
+    bool one_pass = one_pass_on && !(flags & FQD_SLABS_EXACT) && n_parts <= kGroupParts && !(e->flags & FQD_FLAG_NO_STAGE) && chunk_reads % per_tile == 0 &&
                     W > 1 && tile_bytes <= 64 * 1024 && seg[0].uniform_stride >= 8u * W_0 + 15u && seg[0].uniform_len > 0;
     if (e->S == 2) one_pass = one_pass && seg[1].uniform_stride >= 8u * W_1 + 15u && seg[1].uniform_len > 0;
     if (!one_pass) {
         int rc = reserve(e, e->slab_records, std::max<uint64_t>(n, 1) * uint64_t(W + 1) * sizeof(uint64_t));
         if (rc) return rc;
         if ((rc = fqd_encode_uniform(e, seg, n, e->slab_records.as<uint64_t>()))) return rc;
-        return fqd_partition_slabs(e, e->slab_records.as<uint64_t>(), n, W, n_parts, slab_cap, out_keys, counts, origin);
+        if ((rc = fqd_partition_slabs(e, e->slab_records.as<uint64_t>(), n, W, n_parts, slab_cap, out_keys, totals, origin))) return rc;
+        HIP_TRY(e, hipMemsetAsync(totals + n_parts, 0, sizeof(uint64_t), e->stream));
+        HIP_TRY(e, hipMemsetAsync(totals + n_parts, 1, 1, e->stream));        // layout word: 1 = slabs filled from their first slot on
+        const uint64_t cells = uint64_t(n_parts) * n_chunks;
+        hipLaunchKernelGGL(classic_chunk_counts_kernel, dim3(uint32_t((cells + 255) / 256)), dim3(256), 0, e->stream,
+                           static_cast<const uint64_t*>(totals), n_parts, n_chunks, sub_cap, chunk_counts);
+        HIP_TRY(e, hipGetLastError());
+        return FQD_OK;
     }
     {
         Bracket br(e, K_OTHER, 0);
         HIP_TRY(e, hipMemsetAsync(origin, 0xFF, slab_cap * n_parts * sizeof(uint32_t), e->stream));
-        if (n == 0) { HIP_TRY(e, hipMemsetAsync(counts, 0, n_parts * sizeof(uint64_t), e->stream)); return FQD_OK; }
+        HIP_TRY(e, hipMemsetAsync(chunk_counts, 0, uint64_t(n_parts) * n_chunks * sizeof(uint64_t), e->stream));
+        HIP_TRY(e, hipMemsetAsync(totals, 0, (n_parts + 1) * sizeof(uint64_t), e->stream));       // (and the layout word: 0 = sub-slab by sub-slab)
+        if (n == 0) return FQD_OK;
     }
-    const uint64_t n_tiles = (n + per_tile - 1) / per_tile;
-    const size_t state_bytes = (n_tiles * n_parts + 2) * sizeof(uint64_t);
-    int rc = reserve(e, e->part_scratch, state_bytes);
+    int rc = reserve(e, e->part_scratch, 256);
     if (rc) return rc;
-    unsigned long long* tstate = e->part_scratch.as<unsigned long long>() + 2;
-    uint32_t* next_tile = e->part_scratch.as<uint32_t>();
+    uint32_t* next_chunk = e->part_scratch.as<uint32_t>();
     {
         Bracket br(e, K_OTHER, 0);
-        HIP_TRY(e, hipMemsetAsync(e->part_scratch.p, 0, state_bytes, e->stream));
+        HIP_TRY(e, hipMemsetAsync(next_chunk, 0, 256, e->stream));
     }
     SegView sv{seg[0].bases, nullptr, nullptr, seg[0].uniform_len, seg[0].uniform_stride};
     const uint64_t hash_and = (e->flags & FQD_FLAG_WEAK_HASH) ? 0x00000000FFFFFFC0ull : ~0ull;
     const uint32_t magic = uint32_t(((1ull << 32) + W - 1) / W);
-    const uint32_t grid = uint32_t(std::min<uint64_t>(n_tiles, uint64_t(e->n_cu) * 4u));     // what is resident at once: a waiting tile must never keep an earlier one from starting
+    const uint32_t chunk_tiles = uint32_t(chunk_reads / per_tile);
+    const uint32_t used_chunks = uint32_t((n + chunk_reads - 1) / chunk_reads);
+    const uint32_t grid = uint32_t(std::min<uint64_t>(used_chunks, uint64_t(e->n_cu) * 4u));
     Bracket br(e, K_ENCODE, n);
     if (e->S == 1)
-        hipLaunchKernelGGL(encode_group_kernel, dim3(grid), dim3(kBlock), size_t(tile_bytes), e->stream, sv, n, W, n_parts, slab_cap,
-                           out_keys, origin, counts, tstate, next_tile, e->d_state, magic, hash_and);
+        hipLaunchKernelGGL(encode_chunks_kernel, dim3(grid), dim3(kBlock), size_t(tile_bytes), e->stream, sv, n, W, n_parts, chunk_tiles, n_chunks, used_chunks, sub_cap,
+                           out_keys, origin, chunk_counts, reinterpret_cast<unsigned long long*>(totals), next_chunk, e->d_state, magic, hash_and);
     else {
         SegView sv1{seg[1].bases, nullptr, nullptr, seg[1].uniform_len, seg[1].uniform_stride};
-        hipLaunchKernelGGL(encode_group_pe_kernel, dim3(grid), dim3(kBlock), size_t(tile_bytes), e->stream, sv, sv1, n, W_0, W_1, n_parts, slab_cap,
-                           out_keys, origin, counts, tstate, next_tile, e->d_state, uint32_t(tile0), magic, hash_and);
+        hipLaunchKernelGGL(encode_chunks_pe_kernel, dim3(grid), dim3(kBlock), size_t(tile_bytes), e->stream, sv, sv1, n, W_0, W_1, n_parts, chunk_tiles, n_chunks, used_chunks, sub_cap,
+                           out_keys, origin, chunk_counts, reinterpret_cast<unsigned long long*>(totals), next_chunk, e->d_state, uint32_t(tile0), magic, hash_and);
     }
     HIP_TRY(e, hipGetLastError());
     return FQD_OK;

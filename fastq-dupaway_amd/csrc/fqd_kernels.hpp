@@ -1353,113 +1353,97 @@ __global__ void part_slab_offsets_kernel(const uint64_t* __restrict__ starts2d, 
 }
 
 // ---------------------------------------------------------------------------
-// encode_group: the source side of the sharded exchange in ONE pass (round 3: the three-step form — encode 72-byte
-// records, count owners, scan, copy the keys to their slabs — wrote every key twice and read it once more: 378 bytes
-// of traffic per 150-base read against 218 here).  The staged encoder of above, plus: the owner of every read of the
-// tile is known once its key is packed; lanes rank themselves among the tile's reads of the same owner (wave ballots,
-// input order); the tile's count per owner is chained to the counts of all EARLIER tiles by a decoupled look-back
-// (tiles are handed out by an atomic counter, so every earlier tile belongs to a workgroup that is already running and
-// publishes its own count before it waits for anybody: the chain always ends at tile 0); that gives every key its place
-// in its owner's slab — stable, i.e. in input order, which is what makes first-occurrence-wins global — and the wave
-// streams its rows there straight out of LDS.  A key that finds its slab full is NOT written (counts stay exact): the
-// round is then grouped again by the three-step path, which knows how to spill (csrc/fqd_shard.hip).
-// tstate[tile * n_parts + p]: top two bits 0 = nothing yet, 1 = this tile's own count, 2 = count of all tiles up to
-// and including this one; zeroed by the host together with *next_tile before every launch.  n_parts <= kGroupParts.
+// encode_chunks: the source side of the sharded exchange in ONE pass (the three-step form — encode 72-byte records,
+// count owners, scan, copy the keys to their slabs — writes every key twice and reads it once more: 378 bytes of
+// traffic per 150-base read against 218 here).  Input order has to survive the grouping (it is what makes
+// first-occurrence-wins global), so a key's place in its owner's slab would depend on every read before it — unless
+// the slab is CUT the way the input is: the batch is cut into chunks of chunk_reads consecutive reads, every owner's
+// slab into one sub-slab of sub_cap slots per chunk (a fair share of a chunk plus 5.5 standard deviations), and chunk
+// c's keys for owner p go, in input order, to sub-slab (p, c).  A workgroup takes a whole chunk (an atomic counter
+// hands them out), walks its tiles in order with one running count per owner in LDS, and needs nobody else's
+// counts: lanes rank themselves among the tile's reads of the same owner with wave ballots, the wave streams its
+// rows to their slots straight out of LDS.  (A first version chained the counts of ALL tiles by a decoupled
+// look-back instead: with tiles of 256 reads ~1000 of them are in flight and each summed its way back through
+// most of them — the encoder took twice its time; git 4299492..) .  counts[p * n_chunks + c] = keys of chunk c for
+// owner p — the TRUE count: a key that finds its sub-slab full is not written, and the caller groups that batch
+// again the three-step way (fqd_encode_slabs, FQD_SLABS_EXACT) — totals[p] += the same.  n_parts <= kGroupParts.
 constexpr uint32_t kGroupParts = 16;
-constexpr unsigned long long kTileOwn = 1ull << 62, kTileAll = 2ull << 62, kTileValue = (1ull << 62) - 1ull;
 
 __global__ __launch_bounds__(kBlock)
-void encode_group_kernel(SegView s0, uint64_t n, uint32_t W0, uint32_t n_parts, uint64_t slab_cap,
-                         uint64_t* __restrict__ out_keys, uint32_t* __restrict__ origin, uint64_t* __restrict__ counts,
-                         unsigned long long* __restrict__ tstate, uint32_t* __restrict__ next_tile,
-                         uint64_t* __restrict__ err, uint32_t rw_magic, uint64_t hash_and)
+void encode_chunks_kernel(SegView s0, uint64_t n, uint32_t W0, uint32_t n_parts, uint32_t chunk_tiles, uint32_t n_chunks, uint32_t used_chunks, uint64_t sub_cap,
+                          uint64_t* __restrict__ out_keys, uint32_t* __restrict__ origin, uint64_t* __restrict__ counts,
+                          unsigned long long* __restrict__ totals, uint32_t* __restrict__ next_chunk,
+                          uint64_t* __restrict__ err, uint32_t rw_magic, uint64_t hash_and)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t wave_cnt[kGroupParts][kBlock / 64];
-    __shared__ unsigned long long part_before[kGroupParts];
+    __shared__ uint32_t running[kGroupParts];                     // keys of this chunk so far, per owner
     __shared__ uint32_t dst_of[kBlock];
-    __shared__ uint32_t my_tile;
+    __shared__ uint32_t my_chunk;
     uint64_t* lds64 = reinterpret_cast<uint64_t*>(lds);
     const uint32_t R = blockDim.x;
     const uint64_t n_tiles = (n + R - 1) / R;
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
     for (;;) {
-        if (t == 0) my_tile = atomicAdd(next_tile, 1u);
+        if (t == 0) my_chunk = atomicAdd(next_chunk, 1u);
+        if (t < n_parts) running[t] = 0;
         __syncthreads();
-        const uint64_t tile = my_tile;
-        if (tile >= n_tiles) break;                               // the same for every lane of the workgroup
-        const uint64_t r0 = tile * R;
-        const uint32_t nr = uint32_t(n - r0 < R ? n - r0 : R);
-        const uint8_t* g0 = s0.bases + r0 * uint64_t(s0.ustride);
-        const uint32_t bytes = (nr - 1u) * s0.ustride + s0.ulen;
-        const uint32_t in0 = uint32_t(reinterpret_cast<uintptr_t>(g0) & 15u);
-        stage_chunks(g0 - in0, lds, (in0 + bytes + 15u) >> 4, R);
-        __syncthreads();
-        const uint64_t i = r0 + t;
-        const uint32_t l0 = s0.ulen;
-        uint32_t owner = 0xFFFFFFFFu;
-        if (t < nr) {
-            uint64_t h = hash_begin(l0, 0);
-            const uint32_t b0 = in0 + t * s0.ustride;
-            uint64_t* out = lds64 + ((b0 + 4u + 7u) >> 3);         // the key is parked over the read's own consumed bytes (encode_staged, LDS_OUT)
-            auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
-            const uint32_t diff = pack_mate(lds + (b0 >> 2), b0 & 3u, l0, sink);
-            h = hash_end(h) & hash_and;
-            owner = owner_of(h, n_parts);
-            if (diff) {
-                const uint64_t e = locate_bad_base(s0.bases + i * uint64_t(s0.ustride), l0, nullptr, 0, i);
-                if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
-            }
-        }
-        // rank among the tile's reads of the same owner, in input order
-        uint32_t rank_in_wave = 0;
-        for (uint32_t p = 0; p < n_parts; ++p) {
-            const unsigned long long m = __ballot(owner == p);
-            if (owner == p) rank_in_wave = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
-            if (lane == 0) wave_cnt[p][wave] = uint32_t(__popcll(m));
-        }
-        __syncthreads();
-        if (t < n_parts) {                                          // one lane per owner: publish this tile's count, look back
-            unsigned long long c = 0;
-            for (uint32_t w = 0; w < R / 64u; ++w) c += wave_cnt[t][w];
-            unsigned long long* mine = tstate + tile * n_parts + t;
-            unsigned long long before = 0;
-            if (tile == 0) {
-                __hip_atomic_store(mine, kTileAll | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                __hip_atomic_store(mine, kTileOwn | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (uint64_t back = tile; back-- > 0;) {
-                    const unsigned long long* theirs = tstate + back * n_parts + t;
-                    unsigned long long v;
-                    while (((v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0ull) __builtin_amdgcn_s_sleep(1);
-                    before += v & kTileValue;
-                    if ((v >> 62) == 2ull) break;
+        const uint32_t chunk = my_chunk;
+        if (chunk >= used_chunks) break;                          // the same for every lane of the workgroup
+        const uint64_t tile_lo = uint64_t(chunk) * chunk_tiles, tile_hi = tile_lo + chunk_tiles < n_tiles ? tile_lo + chunk_tiles : n_tiles;
+        for (uint64_t tile = tile_lo; tile < tile_hi; ++tile) {
+            const uint64_t r0 = tile * R;
+            const uint32_t nr = uint32_t(n - r0 < R ? n - r0 : R);
+            const uint8_t* g0 = s0.bases + r0 * uint64_t(s0.ustride);
+            const uint32_t bytes = (nr - 1u) * s0.ustride + s0.ulen;
+            const uint32_t in0 = uint32_t(reinterpret_cast<uintptr_t>(g0) & 15u);
+            stage_chunks(g0 - in0, lds, (in0 + bytes + 15u) >> 4, R);
+            __syncthreads();
+            const uint64_t i = r0 + t;
+            const uint32_t l0 = s0.ulen;
+            uint32_t owner = 0xFFFFFFFFu;
+            if (t < nr) {
+                uint64_t h = hash_begin(l0, 0);
+                const uint32_t b0 = in0 + t * s0.ustride;
+                uint64_t* out = lds64 + ((b0 + 4u + 7u) >> 3);     // the key is parked over the read's own consumed bytes (encode_staged, LDS_OUT)
+                auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
+                const uint32_t diff = pack_mate(lds + (b0 >> 2), b0 & 3u, l0, sink);
+                h = hash_end(h) & hash_and;
+                owner = owner_of(h, n_parts);
+                if (diff) {
+                    const uint64_t e = locate_bad_base(s0.bases + i * uint64_t(s0.ustride), l0, nullptr, 0, i);
+                    if (e != kNoError) atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(e));
                 }
-                __hip_atomic_store(mine, kTileAll | (before + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            part_before[t] = before;
-            if (tile + 1 == n_tiles) counts[t] = before + c;
-        }
-        __syncthreads();
-        if (t < nr) {
-            uint32_t in_tile = rank_in_wave;
-            for (uint32_t w = 0; w < wave; ++w) in_tile += wave_cnt[owner][w];
-            const uint64_t local = part_before[owner] + in_tile;
-            const uint32_t slot = local < slab_cap ? uint32_t(uint64_t(owner) * slab_cap + local) : 0xFFFFFFFFu;
-            dst_of[t] = slot;
-            if (slot != 0xFFFFFFFFu) origin[slot] = uint32_t(i);
-        }
-        __syncthreads();
-        {   // every wave streams its rows to their slots: eight lanes per 64-byte key
-            const uint32_t wave_reads = (nr > wave * 64u) ? ((nr - wave * 64u < 64u) ? nr - wave * 64u : 64u) : 0u;
-            const uint32_t total = wave_reads * W0;
-            for (uint32_t x = lane; x < total; x += 64u) {
-                const uint32_t rr = __umulhi(x, rw_magic), kk = x - rr * W0;
-                const uint32_t slot = dst_of[wave * 64u + rr];
-                if (slot != 0xFFFFFFFFu)
-                    __builtin_nontemporal_store(lds64[((in0 + (wave * 64u + rr) * s0.ustride + 4u + 7u) >> 3) + kk], &out_keys[uint64_t(slot) * W0 + kk]);
+            uint32_t rank_in_wave = 0;                            // among the tile's reads of the same owner, in input order
+            for (uint32_t p = 0; p < n_parts; ++p) {
+                const unsigned long long m = __ballot(owner == p);
+                if (owner == p) rank_in_wave = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+                if (lane == 0) wave_cnt[p][wave] = uint32_t(__popcll(m));
             }
+            __syncthreads();
+            if (t < nr) {
+                uint32_t local = running[owner] + rank_in_wave;
+                for (uint32_t w = 0; w < wave; ++w) local += wave_cnt[owner][w];
+                const uint32_t slot = local < sub_cap ? uint32_t((uint64_t(owner) * n_chunks + chunk) * sub_cap + local) : 0xFFFFFFFFu;
+                dst_of[t] = slot;
+                if (slot != 0xFFFFFFFFu) origin[slot] = uint32_t(i);
+            }
+            __syncthreads();
+            if (t < n_parts) { uint32_t c = 0; for (uint32_t w = 0; w < R / 64u; ++w) c += wave_cnt[t][w]; running[t] += c; }
+            {   // every wave streams its rows to their slots: eight lanes per 64-byte key
+                const uint32_t wave_reads = (nr > wave * 64u) ? ((nr - wave * 64u < 64u) ? nr - wave * 64u : 64u) : 0u;
+                const uint32_t total = wave_reads * W0;
+                for (uint32_t x = lane; x < total; x += 64u) {
+                    const uint32_t rr = __umulhi(x, rw_magic), kk = x - rr * W0;
+                    const uint32_t slot = dst_of[wave * 64u + rr];
+                    if (slot != 0xFFFFFFFFu)
+                        __builtin_nontemporal_store(lds64[((in0 + (wave * 64u + rr) * s0.ustride + 4u + 7u) >> 3) + kk], &out_keys[uint64_t(slot) * W0 + kk]);
+                }
+            }
+            __syncthreads();
         }
+        if (t < n_parts) { counts[uint64_t(t) * n_chunks + chunk] = running[t]; if (running[t]) atomicAdd(&totals[t], static_cast<unsigned long long>(running[t])); }
         __syncthreads();
     }
 }
@@ -1467,114 +1451,113 @@ void encode_group_kernel(SegView s0, uint64_t n, uint32_t W0, uint32_t n_parts, 
 // The paired form: one lane per MATE as in encode_staged_pe_kernel (lane 2q = mate 1 of pair q, lane 2q+1 = mate 2), 128
 // pairs per 256-lane tile; the pair's owner comes from the pair's hash (even lane), ranks count pairs.
 __global__ __launch_bounds__(kBlock)
-void encode_group_pe_kernel(SegView s0, SegView s1, uint64_t n, uint32_t W_0, uint32_t W_1, uint32_t n_parts, uint64_t slab_cap,
-                            uint64_t* __restrict__ out_keys, uint32_t* __restrict__ origin, uint64_t* __restrict__ counts,
-                            unsigned long long* __restrict__ tstate, uint32_t* __restrict__ next_tile,
-                            uint64_t* __restrict__ err, uint32_t tile_bytes0, uint32_t rw_magic, uint64_t hash_and)
+void encode_chunks_pe_kernel(SegView s0, SegView s1, uint64_t n, uint32_t W_0, uint32_t W_1, uint32_t n_parts, uint32_t chunk_tiles, uint32_t n_chunks,
+                             uint32_t used_chunks, uint64_t sub_cap, uint64_t* __restrict__ out_keys, uint32_t* __restrict__ origin, uint64_t* __restrict__ counts,
+                             unsigned long long* __restrict__ totals, uint32_t* __restrict__ next_chunk,
+                             uint64_t* __restrict__ err, uint32_t tile_bytes0, uint32_t rw_magic, uint64_t hash_and)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t wave_cnt[kGroupParts][kBlock / 64];
-    __shared__ unsigned long long part_before[kGroupParts];
+    __shared__ uint32_t running[kGroupParts];
     __shared__ uint32_t dst_of[kBlock / 2];
-    __shared__ uint32_t my_tile;
+    __shared__ uint32_t my_chunk;
     uint64_t* lds64 = reinterpret_cast<uint64_t*>(lds);
     const uint32_t R = blockDim.x, P = R >> 1, row_words = W_0 + W_1;
     const uint64_t n_tiles = (n + P - 1) / P;
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u, pair = t >> 1, mate = t & 1u;
     for (;;) {
-        if (t == 0) my_tile = atomicAdd(next_tile, 1u);
+        if (t == 0) my_chunk = atomicAdd(next_chunk, 1u);
+        if (t < n_parts) running[t] = 0;
         __syncthreads();
-        const uint64_t tile = my_tile;
-        if (tile >= n_tiles) break;
-        const uint64_t r0 = tile * P;
-        const uint32_t np = uint32_t(n - r0 < P ? n - r0 : P);
-        uint32_t in_base[2];
+        const uint32_t chunk = my_chunk;
+        if (chunk >= used_chunks) break;
+        const uint64_t tile_lo = uint64_t(chunk) * chunk_tiles, tile_hi = tile_lo + chunk_tiles < n_tiles ? tile_lo + chunk_tiles : n_tiles;
+        for (uint64_t tile = tile_lo; tile < tile_hi; ++tile) {
+            const uint64_t r0 = tile * P;
+            const uint32_t np = uint32_t(n - r0 < P ? n - r0 : P);
+            uint32_t in_base[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const SegView& sv = s ? s1 : s0;
-            const uint8_t* g0 = sv.bases + r0 * uint64_t(sv.ustride);
-            const uint32_t bytes = (np - 1u) * sv.ustride + sv.ulen;
-            const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(g0) & 15u);
-            const uint32_t off = s ? tile_bytes0 : 0u;
-            in_base[s] = off + head;
-            stage_chunks(g0 - head, lds + (off >> 2), (head + bytes + 15u) >> 4, R);
-        }
-        __syncthreads();
-        const bool live = pair < np;
-        const uint64_t i = r0 + pair;
-        const uint32_t len = mate ? s1.ulen : s0.ulen;
-        const uint32_t stride = mate ? s1.ustride : s0.ustride;
-        const uint32_t b = in_base[mate] + pair * stride;
-        uint64_t h = hash_begin(len, 0);
-        uint32_t diff = 0;
-        if (live) {
-            uint64_t* out = lds64 + ((b + 4u + 7u) >> 3);
-            auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
-            diff = pack_mate(lds + (b >> 2), b & 3u, len, sink);
-        }
-        const uint64_t other = __shfl_xor(h, 1, 64);
-        uint32_t owner = 0xFFFFFFFFu;
-        if (live && !mate) owner = owner_of(hash_pair(h, other) & hash_and, n_parts);
-        owner = __shfl(owner, int(lane & ~1u), 64);                  // both mates know their pair's owner
-        if (live && diff) {
-            uint32_t byte = 0;
-            const uint8_t* gp = (mate ? s1.bases : s0.bases) + i * uint64_t(stride);
-            const uint32_t pos = first_bad_base(gp, len, &byte);
-            if (pos != 0xFFFFFFFFu)
-                atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(make_error(i, mate, pos, byte)));
-        }
-        uint32_t rank_in_wave = 0;
-        for (uint32_t p = 0; p < n_parts; ++p) {
-            const unsigned long long m = __ballot(owner == p && mate == 0u);
-            if (owner == p) rank_in_wave = uint32_t(__popcll(m & ((1ull << (lane & ~1u)) - 1ull)));
-            if (lane == 0) wave_cnt[p][wave] = uint32_t(__popcll(m));
-        }
-        __syncthreads();
-        if (t < n_parts) {
-            unsigned long long c = 0;
-            for (uint32_t w = 0; w < R / 64u; ++w) c += wave_cnt[t][w];
-            unsigned long long* mine = tstate + tile * n_parts + t;
-            unsigned long long before = 0;
-            if (tile == 0) {
-                __hip_atomic_store(mine, kTileAll | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                __hip_atomic_store(mine, kTileOwn | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (uint64_t back = tile; back-- > 0;) {
-                    const unsigned long long* theirs = tstate + back * n_parts + t;
-                    unsigned long long v;
-                    while (((v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0ull) __builtin_amdgcn_s_sleep(1);
-                    before += v & kTileValue;
-                    if ((v >> 62) == 2ull) break;
+            for (int s = 0; s < 2; ++s) {
+                const SegView& sv = s ? s1 : s0;
+                const uint8_t* g0 = sv.bases + r0 * uint64_t(sv.ustride);
+                const uint32_t bytes = (np - 1u) * sv.ustride + sv.ulen;
+                const uint32_t head = uint32_t(reinterpret_cast<uintptr_t>(g0) & 15u);
+                const uint32_t off = s ? tile_bytes0 : 0u;
+                in_base[s] = off + head;
+                stage_chunks(g0 - head, lds + (off >> 2), (head + bytes + 15u) >> 4, R);
+            }
+            __syncthreads();
+            const bool live = pair < np;
+            const uint64_t i = r0 + pair;
+            const uint32_t len = mate ? s1.ulen : s0.ulen;
+            const uint32_t stride = mate ? s1.ustride : s0.ustride;
+            const uint32_t b = in_base[mate] + pair * stride;
+            uint64_t h = hash_begin(len, 0);
+            uint32_t diff = 0;
+            if (live) {
+                uint64_t* out = lds64 + ((b + 4u + 7u) >> 3);
+                auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
+                diff = pack_mate(lds + (b >> 2), b & 3u, len, sink);
+            }
+            const uint64_t other = __shfl_xor(h, 1, 64);
+            uint32_t owner = 0xFFFFFFFFu;
+            if (live && !mate) owner = owner_of(hash_pair(h, other) & hash_and, n_parts);
+            owner = __shfl(owner, int(lane & ~1u), 64);              // both mates know their pair's owner
+            if (live && diff) {
+                uint32_t byte = 0;
+                const uint8_t* gp = (mate ? s1.bases : s0.bases) + i * uint64_t(stride);
+                const uint32_t pos = first_bad_base(gp, len, &byte);
+                if (pos != 0xFFFFFFFFu)
+                    atomicMin(reinterpret_cast<unsigned long long*>(err), static_cast<unsigned long long>(make_error(i, mate, pos, byte)));
+            }
+            uint32_t rank_in_wave = 0;
+            for (uint32_t p = 0; p < n_parts; ++p) {
+                const unsigned long long m = __ballot(owner == p && mate == 0u);
+                if (owner == p) rank_in_wave = uint32_t(__popcll(m & ((1ull << (lane & ~1u)) - 1ull)));
+                if (lane == 0) wave_cnt[p][wave] = uint32_t(__popcll(m));
+            }
+            __syncthreads();
+            if (live && !mate) {
+                uint32_t local = running[owner] + rank_in_wave;
+                for (uint32_t w = 0; w < wave; ++w) local += wave_cnt[owner][w];
+                const uint32_t slot = local < sub_cap ? uint32_t((uint64_t(owner) * n_chunks + chunk) * sub_cap + local) : 0xFFFFFFFFu;
+                dst_of[pair] = slot;
+                if (slot != 0xFFFFFFFFu) origin[slot] = uint32_t(i);
+            }
+            __syncthreads();
+            if (t < n_parts) { uint32_t c = 0; for (uint32_t w = 0; w < R / 64u; ++w) c += wave_cnt[t][w]; running[t] += c; }
+            {
+                const uint32_t wave_pairs = (np > wave * 32u) ? ((np - wave * 32u < 32u) ? np - wave * 32u : 32u) : 0u;
+                const uint32_t total = wave_pairs * row_words;
+                for (uint32_t x = lane; x < total; x += 64u) {
+                    const uint32_t rr = __umulhi(x, rw_magic), kk = x - rr * row_words;
+                    const uint32_t m = kk >= W_0 ? 1u : 0u, kw = m ? kk - W_0 : kk;
+                    const uint32_t slot = dst_of[wave * 32u + rr];
+                    const uint32_t pb = in_base[m] + (wave * 32u + rr) * (m ? s1.ustride : s0.ustride);
+                    if (slot != 0xFFFFFFFFu)
+                        __builtin_nontemporal_store(lds64[((pb + 4u + 7u) >> 3) + kw], &out_keys[uint64_t(slot) * row_words + kk]);
                 }
-                __hip_atomic_store(mine, kTileAll | (before + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            part_before[t] = before;
-            if (tile + 1 == n_tiles) counts[t] = before + c;
+            __syncthreads();
         }
-        __syncthreads();
-        if (live && !mate) {
-            uint32_t in_tile = rank_in_wave;
-            for (uint32_t w = 0; w < wave; ++w) in_tile += wave_cnt[owner][w];
-            const uint64_t local = part_before[owner] + in_tile;
-            const uint32_t slot = local < slab_cap ? uint32_t(uint64_t(owner) * slab_cap + local) : 0xFFFFFFFFu;
-            dst_of[pair] = slot;
-            if (slot != 0xFFFFFFFFu) origin[slot] = uint32_t(i);
-        }
-        __syncthreads();
-        {
-            const uint32_t wave_pairs = (np > wave * 32u) ? ((np - wave * 32u < 32u) ? np - wave * 32u : 32u) : 0u;
-            const uint32_t total = wave_pairs * row_words;
-            for (uint32_t x = lane; x < total; x += 64u) {
-                const uint32_t rr = __umulhi(x, rw_magic), kk = x - rr * row_words;
-                const uint32_t m = kk >= W_0 ? 1u : 0u, kw = m ? kk - W_0 : kk;
-                const uint32_t slot = dst_of[wave * 32u + rr];
-                const uint32_t pb = in_base[m] + (wave * 32u + rr) * (m ? s1.ustride : s0.ustride);
-                if (slot != 0xFFFFFFFFu)
-                    __builtin_nontemporal_store(lds64[((pb + 4u + 7u) >> 3) + kw], &out_keys[uint64_t(slot) * row_words + kk]);
-            }
-        }
+        if (t < n_parts) { counts[uint64_t(t) * n_chunks + chunk] = running[t]; if (running[t]) atomicAdd(&totals[t], static_cast<unsigned long long>(running[t])); }
         __syncthreads();
     }
+}
+
+// The three-step grouping fills an owner's slab from its first slot on (fqd_partition_slabs): seen as sub-slabs that is
+// full ones, a partial one, empty ones — and what a slab of n_chunks * sub_cap slots has no room for shows as a count
+// above sub_cap in the LAST sub-slab.  counts[p * n_chunks + c] from totals[p].
+__global__ void classic_chunk_counts_kernel(const uint64_t* __restrict__ totals, uint32_t n_parts, uint32_t n_chunks, uint64_t sub_cap,
+                                            uint64_t* __restrict__ counts)
+{
+    const uint64_t k = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+    if (k >= uint64_t(n_parts) * n_chunks) return;
+    const uint32_t p = uint32_t(k / n_chunks), c = uint32_t(k - uint64_t(p) * n_chunks);
+    const uint64_t tot = totals[p], before = uint64_t(c) * sub_cap;
+    uint64_t v = tot > before ? tot - before : 0;
+    if (c + 1 < n_chunks && v > sub_cap) v = sub_cap;
+    counts[k] = v;
 }
 
 // counts[p] = number of records of part p, read off the scanned 2-D starts.

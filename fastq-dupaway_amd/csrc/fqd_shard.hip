@@ -8,22 +8,27 @@
 //
 // One round, per rank:
 //   encode + group by owner   every read becomes a fixed-size key; owner = (hash >> 40) % world; the keys bound
-//                             for owner d are written to SLAB d of the send buffer: `cap` key slots, a few per
-//                             cent more than a fair share (fqd_partition_slabs)
+//                             for owner d are written to SLAB d of the send buffer.  The batch is cut into chunks
+//                             of consecutive reads and every slab into one SUB-SLAB per chunk (a fair share of a
+//                             chunk + 5.5 sigma): that is what lets the encoder write every key ONCE, straight
+//                             to its place, in input order, no workgroup waiting for another (fqd_encode_slabs)
 //   all-to-all                slab d travels to rank d and lands at slot s*cap of the room rank d reserved at the
 //                             tail of its key store — messages of FIXED size, so the exchange is queued before any
 //                             count has reached a host; the true counts travel beside the slabs (8 bytes a pair)
-//   insert                    the owner inserts its `world` slabs where they lie, in (source rank, position) order,
-//                             passing over the unused slots (fqd_insert_slabs): first occurrence wins, globally
+//   insert                    the owner inserts its `world` slabs (world * chunks sub-slabs) where they lie, in
+//                             (source rank, position) order, passing over the unused slots (fqd_insert_slabs):
+//                             first occurrence wins, globally
 //   flags back, scatter       the reverse all-to-all (cap bytes a pair) and keep[origin[slot]] = flag
 // Rounds are software-pipelined over two streams per rank: the exchange of round k travels while round k+1 is
 // encoded, the insert of round k runs under the exchange of round k+1.  The host looks at a round's counts only to
 // decide whether a slab overflowed, and only after the next round's encoder has been queued — it never waits
 // with an idle GPU behind it.
 //
-// A slab that overflows (one owner draws far more than its share: millions of copies of one read) is settled
-// before the owner inserts anything of that round: the spilled keys follow in a second, exactly sized exchange —
-// both ends of a pair know its true count — and the owner lays the round out again in (source, position) order.
+// What does not fit is settled before the owner inserts anything of that round, by a second exchange whose sizes both
+// ends of a pair know from the counts of the first: a source one of whose sub-slabs overflowed (the one-pass encoder
+// leaves such keys out) groups the round again the three-step way and sends the slab again, filled from its first slot
+// on; what a whole slab cannot take (one owner drawing far more than its share: millions of copies of one read) follows
+// exactly sized, and the owner lays the round out again with the spills as further sub-slabs behind their slabs.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -53,20 +58,40 @@ void shard_scatter_flags_kernel(const uint8_t* __restrict__ flags, const uint32_
     }
 }
 
+using fqd_plan::Geometry;
+
+// A round's counts, device and pinned mirror alike, as uint64 words:
+//   [out chunk counts: W*G][out totals: W][out layout: 1 = 1 when the slabs are filled from their first slot on]
+//   [in chunk counts: W*G][in totals: W][in layout: W]
+struct CountLayout {
+    uint64_t W, G;
+    uint64_t oc() const { return 0; }
+    uint64_t ot() const { return W * G; }
+    uint64_t of() const { return W * G + W; }
+    uint64_t ic() const { return W * G + W + 1; }
+    uint64_t it() const { return ic() + W * G; }
+    uint64_t il() const { return it() + W; }
+    uint64_t words() const { return il() + W; }
+};
+
 struct Round {                           // buffers and events of one round in flight (two per rank)
-    uint64_t* grouped = nullptr;         // world slabs of cap keys, then the overflow region (round_reads keys)
+    uint64_t* grouped = nullptr;         // world slabs of cap keys, then the spill region (round_reads keys)
     uint32_t* origin = nullptr;          // input position per slot of `grouped`
     uint8_t*  keep_recv = nullptr;       // owner side: flags of what was inserted
     uint8_t*  keep_back = nullptr;       // source side: flags per slot of `grouped`
-    uint64_t* d_counts = nullptr;        // device: [world] out (true counts per owner) then [world] in (per source)
+    uint64_t* d_counts = nullptr;        // CountLayout
     uint64_t* h_counts = nullptr;        // pinned mirror
+    uint64_t* d_ins_counts = nullptr;    // owner side, round laid out again: valid keys per sub-slab
+    uint64_t* h_ins_counts = nullptr;    // pinned
     uint64_t* slot = nullptr;            // where this round's keys are received (tail of the key store)
     hipEvent_t ev_part = nullptr, ev_xchg = nullptr, ev_spill = nullptr, ev_ins = nullptr, ev_done = nullptr, t0 = nullptr, t1 = nullptr;
-    uint64_t n = 0, n_inserted = 0;
+    uint64_t n = 0;
     fqd_reads seg[2] = {};               // the round's input (it must stay where it is until the round's flags are final)
     uint8_t* keep_dst = nullptr;
     bool used = false;
-    bool compact = false;                // owner side: a spill arrived and the round was laid out again, exactly
+    bool relaid = false;                 // owner side: a spill arrived and the round was laid out again
+    bool regrouped = false;              // source side: the round was grouped again (Local::re_grouped holds it)
+    std::vector<uint64_t> off;           // owner side: first slot of every source's keys once inserted
     uint64_t* h_bad = nullptr;           // pinned: the engine's first-bad-byte word once this round was encoded
 };
 
@@ -74,8 +99,9 @@ struct Local {
     fqd_engine* e = nullptr; int device = 0; int rank = 0;
     hipStream_t es = nullptr, cs = nullptr;
     ncclComm_t comm = nullptr;
-    uint64_t* records = nullptr;
-    uint64_t* spill = nullptr; size_t spill_cap = 0;     // rare path: a round laid out again
+    uint64_t* records = nullptr;                          // padded groups: the batch's [hash | key] records
+    uint64_t* spill = nullptr; size_t spill_cap = 0;      // rare path, owner: the slabs as received + the spills
+    uint64_t* re_grouped = nullptr; uint32_t* re_origin = nullptr; uint64_t* re_counts = nullptr;    // rare path, source: the round grouped again
     Round rb[2];
     fqd_shard_stats st{};
 };
@@ -87,7 +113,9 @@ struct fqd_shard {
     std::vector<Local> lr;
     uint32_t S = 1, K = 0;
     bool padded = false; uint32_t own_len0 = 0, own_len1 = 0;
-    uint64_t cap = 0;
+    Geometry g;
+    uint64_t cap = 0;                    // g.cap()
+    CountLayout cl{1, 1};
     uint64_t rounds = 0;                 // rounds started
     int64_t  pending = -1;               // round whose receive side has not been finished yet
     bool use_rccl = false;
@@ -155,6 +183,7 @@ int move(fqd_shard* s, const std::vector<Xfer>& xs, const std::vector<hipEvent_t
 // In a multi-process group a rank only knows its own buffers: a transfer's far end is then described by what
 // both ends can compute (slab geometry), and `from`/`to` of the far side stay null — move() never touches them.
 const void* at_words(const uint64_t* p, uint64_t words) { return p ? p + words : nullptr; }
+void* at_words_rw(uint64_t* p, uint64_t words) { return p ? p + words : nullptr; }
 
 Round* round_of(fqd_shard* s, int rank, uint64_t k) { const int l = local_of(s, rank); return l >= 0 ? &s->lr[size_t(l)].rb[k & 1] : nullptr; }
 
@@ -162,6 +191,7 @@ Round* round_of(fqd_shard* s, int rank, uint64_t k) { const int l = local_of(s, 
 int exchange_forward(fqd_shard* s, uint64_t k)
 {
     const int W = s->cfg.world;
+    const CountLayout& cl = s->cl;
     const uint64_t slab_words = s->cap * s->K;
     for (Local& l : s->lr) {
         Round& r = l.rb[k & 1];
@@ -177,9 +207,13 @@ int exchange_forward(fqd_shard* s, uint64_t k)
             Round* a = round_of(s, src, k); Round* b = round_of(s, dst, k);
             if (!a && !b) continue;
             xs.push_back({src, dst, a ? at_words(a->grouped, fqd_plan::slab_slot(uint32_t(dst), s->cap) * s->K) : nullptr,
-                          b ? const_cast<void*>(at_words(b->slot, fqd_plan::slab_slot(uint32_t(src), s->cap) * s->K)) : nullptr, slab_words * 8});
-            xs.push_back({src, dst, a ? at_words(a->d_counts, uint64_t(dst)) : nullptr,
-                          b ? const_cast<void*>(at_words(b->d_counts, uint64_t(W) + uint64_t(src))) : nullptr, 8});
+                          b ? at_words_rw(b->slot, fqd_plan::slab_slot(uint32_t(src), s->cap) * s->K) : nullptr, slab_words * 8});
+            xs.push_back({src, dst, a ? at_words(a->d_counts, cl.oc() + uint64_t(dst) * cl.G) : nullptr,
+                          b ? at_words_rw(b->d_counts, cl.ic() + uint64_t(src) * cl.G) : nullptr, cl.G * 8});
+            xs.push_back({src, dst, a ? at_words(a->d_counts, cl.ot() + uint64_t(dst)) : nullptr,
+                          b ? at_words_rw(b->d_counts, cl.it() + uint64_t(src)) : nullptr, 8});
+            xs.push_back({src, dst, a ? at_words(a->d_counts, cl.of()) : nullptr,
+                          b ? at_words_rw(b->d_counts, cl.il() + uint64_t(src)) : nullptr, 8});
         }
     int rc = move(s, xs, ready);
     if (rc) return rc;
@@ -187,52 +221,78 @@ int exchange_forward(fqd_shard* s, uint64_t k)
         Round& r = l.rb[k & 1];
         SH_HIP(s, hipSetDevice(l.device));
         SH_HIP(s, hipEventRecord(r.t1, l.cs));
-        SH_HIP(s, hipMemcpyAsync(r.h_counts + W, r.d_counts + W, size_t(W) * 8, hipMemcpyDeviceToHost, l.cs));
+        SH_HIP(s, hipMemcpyAsync(r.h_counts + cl.ic(), r.d_counts + cl.ic(), size_t(cl.words() - cl.ic()) * 8, hipMemcpyDeviceToHost, l.cs));
         SH_HIP(s, hipEventRecord(r.ev_xchg, l.cs));
         l.st.slab_records = s->cap;
     }
     return FQD_OK;
 }
 
-// The owner side of round k once its keys have arrived: insert (after settling any overflow).
+// Did a sub-slab of this pair overflow in a one-pass grouping (so that the source sends the slab again)?
+bool pair_resends(const uint64_t* chunk_counts, uint64_t layout_classic, const Geometry& g)
+{
+    if (layout_classic) return false;
+    for (uint32_t c = 0; c < g.chunks; ++c) if (chunk_counts[c] > g.sub_cap) return true;
+    return false;
+}
+
+// The owner side of round k once its keys have arrived: insert (after settling whatever did not fit).
 int finish_receive(fqd_shard* s, uint64_t k)
 {
     const int W = s->cfg.world;
-    const uint64_t cap = s->cap, K = s->K;
+    const Geometry& g = s->g;
+    const CountLayout& cl = s->cl;
+    const uint64_t cap = s->cap, K = s->K, G = g.chunks;
     // the host reads the counts here — long after the exchange was queued, with the next encoder already behind it
-    bool any_over = false;
+    bool any = false;
     for (Local& l : s->lr) {
         Round& r = l.rb[k & 1];
         SH_HIP(s, hipSetDevice(l.device));
         SH_HIP(s, hipEventSynchronize(r.ev_xchg));
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.t0, r.t1) == hipSuccess) l.st.exchange_ms += ms;
-        r.compact = fqd_plan::owner_is_compact(r.h_counts + W, uint32_t(W), cap);
-        bool over = r.compact;
-        for (int p = 0; p < W; ++p) if (r.h_counts[p] > cap) over = true;
-        if (over) l.st.overflow_rounds++;
-        any_over = any_over || over;
+        r.relaid = false; r.regrouped = false;
+        bool mine = false;
+        for (int p = 0; p < W; ++p) {
+            if (r.h_counts[cl.it() + p] > cap) r.relaid = true;
+            if (pair_resends(r.h_counts + cl.oc() + uint64_t(p) * G, r.h_counts[cl.of()], g)) r.regrouped = true;
+            mine = mine || r.h_counts[cl.ot() + p] > cap || r.h_counts[cl.it() + p] > cap ||
+                   pair_resends(r.h_counts + cl.ic() + uint64_t(p) * G, r.h_counts[cl.il() + p], g);
+        }
+        mine = mine || r.regrouped;
+        if (mine) l.st.overflow_rounds++;
+        any = any || mine;
     }
-    if (any_over) {
-        // ---- a slab overflowed: the spilled keys follow, exactly sized; both ends of a pair know its count ----
+    if (any) {
         std::vector<Xfer> xs;
         std::vector<hipEvent_t> ready;
         for (Local& l : s->lr) {
             Round& r = l.rb[k & 1];
-            bool over_out = false;
-            for (int p = 0; p < W; ++p) over_out = over_out || r.h_counts[p] > cap;
-            if (over_out && !s->padded) {
-                // the one-pass encoder leaves out what a full slab cannot take: this source groups the round again, the
-                // three-step way, which writes the spill region (same slabs, same origin: nothing already sent changes)
-                SH_HIP(s, hipSetDevice(l.device));
-                SH_ENG(s, l, fqd_encode_slabs(l.e, r.seg, r.n, uint32_t(W), cap, r.grouped, r.d_counts, r.origin, FQD_SLABS_EXACT));
+            SH_HIP(s, hipSetDevice(l.device));
+            if (r.regrouped) {
+                // ---- source: a sub-slab overflowed in the one-pass grouping, which leaves such keys out.  The round is
+                // grouped again the three-step way — slabs filled from their first slot on, spill region written — into
+                // buffers of its own: what other owners already hold in the first layout stays as they hold it
+                const uint64_t slots = uint64_t(W) * cap + s->cfg.round_reads;
+                if (!l.re_grouped) {
+                    SH_HIP(s, hipMalloc(reinterpret_cast<void**>(&l.re_grouped), slots * K * 8));
+                    SH_HIP(s, hipMalloc(reinterpret_cast<void**>(&l.re_origin), slots * 4));
+                    SH_HIP(s, hipMalloc(reinterpret_cast<void**>(&l.re_counts), (uint64_t(W) * G + W + 1) * 8));
+                }
+                SH_ENG(s, l, fqd_encode_slabs(l.e, r.seg, r.n, uint32_t(W), g.chunk_reads, g.chunks, g.sub_cap, l.re_grouped,
+                                              l.re_counts, l.re_counts + uint64_t(W) * G, l.re_origin, FQD_SLABS_EXACT));
+                // the flags of the owners that get the slab again come back in ITS slot order: their part of origin[] follows
+                for (int p = 0; p < W; ++p)
+                    if (pair_resends(r.h_counts + cl.oc() + uint64_t(p) * G, 0, g))
+                        SH_HIP(s, hipMemcpyAsync(r.origin + uint64_t(p) * cap, l.re_origin + uint64_t(p) * cap, cap * 4, hipMemcpyDeviceToDevice, l.es));
+                const uint64_t spilled = fqd_plan::spill_slot(r.h_counts + cl.ot(), uint32_t(W), uint32_t(W), cap) - uint64_t(W) * cap;
+                if (spilled) SH_HIP(s, hipMemcpyAsync(r.origin + uint64_t(W) * cap, l.re_origin + uint64_t(W) * cap, spilled * 4, hipMemcpyDeviceToDevice, l.es));
                 SH_HIP(s, hipEventRecord(r.ev_part, l.es));
             }
             ready.push_back(r.ev_part);                        // the sources' send buffers are complete behind this
-            if (!r.compact) continue;
-            SH_HIP(s, hipSetDevice(l.device));
-            // owner side: [all slabs as received][spill of source 0][of source 1]... in a buffer of its own
-            const size_t need = fqd_plan::spill_slot(r.h_counts + W, uint32_t(W), uint32_t(W), cap) * K * 8;
+            if (!r.relaid) continue;
+            // ---- owner: a source's slab had no room for everything: [all slabs as received][spill of source 0][of source 1]... in a buffer of its own
+            const size_t need = fqd_plan::spill_slot(r.h_counts + cl.it(), uint32_t(W), uint32_t(W), cap) * K * 8;
             if (need > l.spill_cap) {
                 SH_HIP(s, hipStreamSynchronize(l.cs)); SH_HIP(s, hipStreamSynchronize(l.es));
                 if (l.spill) SH_HIP(s, hipFree(l.spill));
@@ -246,12 +306,18 @@ int finish_receive(fqd_shard* s, uint64_t k)
             for (int dst = 0; dst < W; ++dst) {
                 Round* a = round_of(s, src, k); Round* b = round_of(s, dst, k);
                 if (!a && !b) continue;
-                const uint64_t c = a ? a->h_counts[dst] : b->h_counts[W + src];
-                if (c <= cap) continue;
-                const void* from = nullptr; void* to = nullptr;
-                if (a) from = a->grouped + fqd_plan::spill_slot(a->h_counts, uint32_t(W), uint32_t(dst), cap) * K;
-                if (b) to = s->lr[size_t(local_of(s, dst))].spill + fqd_plan::spill_slot(b->h_counts + W, uint32_t(W), uint32_t(src), cap) * K;
-                xs.push_back({src, dst, from, to, (c - cap) * K * 8});
+                const int la = local_of(s, src), lb = local_of(s, dst);
+                const uint64_t total = a ? a->h_counts[cl.ot() + dst] : b->h_counts[cl.it() + src];
+                const bool again = a ? pair_resends(a->h_counts + cl.oc() + uint64_t(dst) * G, a->h_counts[cl.of()], g)
+                                     : pair_resends(b->h_counts + cl.ic() + uint64_t(src) * G, b->h_counts[cl.il() + src], g);
+                const uint64_t* keys = a ? (a->regrouped ? s->lr[size_t(la)].re_grouped : a->grouped) : nullptr;
+                uint64_t* land = b ? (b->relaid ? s->lr[size_t(lb)].spill : b->slot) : nullptr;
+                if (again)                                     // the whole slab once more, now filled from its first slot on
+                    xs.push_back({src, dst, at_words(keys, fqd_plan::slab_slot(uint32_t(dst), cap) * K), at_words_rw(land, fqd_plan::slab_slot(uint32_t(src), cap) * K), cap * K * 8});
+                if (total > cap)                               // and what the slab has no room for
+                    xs.push_back({src, dst, a ? at_words(keys, fqd_plan::spill_slot(a->h_counts + cl.ot(), uint32_t(W), uint32_t(dst), cap) * K) : nullptr,
+                                  b ? at_words_rw(s->lr[size_t(lb)].spill, fqd_plan::spill_slot(b->h_counts + cl.it(), uint32_t(W), uint32_t(src), cap) * K) : nullptr,
+                                  (total - cap) * K * 8});
             }
         if (!xs.empty()) { const int rc = move(s, xs, ready); if (rc) return rc; }
         for (Local& l : s->lr) { SH_HIP(s, hipSetDevice(l.device)); SH_HIP(s, hipEventRecord(l.rb[k & 1].ev_spill, l.cs)); }
@@ -259,28 +325,50 @@ int finish_receive(fqd_shard* s, uint64_t k)
     for (Local& l : s->lr) {
         Round& r = l.rb[k & 1];
         SH_HIP(s, hipSetDevice(l.device));
-        if (!r.compact) {
-            SH_HIP(s, hipStreamWaitEvent(l.es, r.ev_xchg, 0));
-            SH_ENG(s, l, fqd_insert_slabs(l.e, r.slot, uint32_t(W), cap, r.d_counts + W, s->own_len0, s->own_len1, r.keep_recv));
-            r.n_inserted = uint64_t(W) * cap;
+        r.off.assign(size_t(W) + 1, 0);
+        // valid keys per sub-slab as the owner will insert them; a source that sent its slab again filled it from the first slot on
+        bool fixed = false;
+        uint64_t n_sub = 0;
+        for (int p = 0; p < W; ++p) {
+            const uint64_t total = r.h_counts[cl.it() + p];
+            const bool again = pair_resends(r.h_counts + cl.ic() + uint64_t(p) * G, r.h_counts[cl.il() + p], g);
+            const uint64_t subs = r.relaid ? fqd_plan::owner_sub_slabs(total, g) : G;
+            r.off[size_t(p)] = n_sub * g.sub_cap;
+            for (uint64_t c = 0; c < subs; ++c) {
+                uint64_t v;
+                if (c < G && !again && !r.h_counts[cl.il() + p]) v = r.h_counts[cl.ic() + uint64_t(p) * G + c];       // as the one-pass encoder filled it
+                else if (c < G) v = std::min<uint64_t>(fqd_plan::classic_count(total, uint32_t(c), g.chunks, g.sub_cap), g.sub_cap);
+                else v = std::min<uint64_t>(total - cap - (c - G) * g.sub_cap, g.sub_cap);                               // a sub-slab of the spill
+                r.h_ins_counts[n_sub + c] = v;
+            }
+            fixed = fixed || again || r.h_counts[cl.il() + p] != 0;      // (a slab filled from its first slot on: its sub-slab counts did not travel)
+            n_sub += subs;
+        }
+        r.off[size_t(W)] = n_sub * g.sub_cap;
+        if (!r.relaid) {
+            SH_HIP(s, hipStreamWaitEvent(l.es, any ? r.ev_spill : r.ev_xchg, 0));
+            const uint64_t* counts = r.d_counts + cl.ic();
+            if (fixed) {                                       // a slab came again: its sub-slab counts are not the ones that travelled
+                SH_HIP(s, hipMemcpyAsync(r.d_ins_counts, r.h_ins_counts, n_sub * 8, hipMemcpyHostToDevice, l.es));
+                counts = r.d_ins_counts;
+            }
+            SH_ENG(s, l, fqd_insert_slabs(l.e, r.slot, uint32_t(n_sub), g.sub_cap, counts, s->own_len0, s->own_len1, r.keep_recv));
         } else {
-            // this owner received a spill: the round is laid out again, exactly, in (source, position) order
-            const uint64_t total = fqd_plan::owner_records(r.h_counts + W, uint32_t(W), cap);
+            // this owner received a spill: every source's slab, then its spill as further sub-slabs, in (source, position) order
             SH_HIP(s, hipStreamWaitEvent(l.es, r.ev_spill, 0));
             uint64_t* slot = nullptr;
-            SH_ENG(s, l, fqd_reserve_keys(l.e, total, s->own_len0, s->own_len1, &slot));
-            uint64_t at = 0, spill_at = uint64_t(W) * cap;
+            SH_ENG(s, l, fqd_reserve_keys(l.e, n_sub * g.sub_cap, s->own_len0, s->own_len1, &slot));
+            uint64_t spill_at = uint64_t(W) * cap;
             for (int p = 0; p < W; ++p) {
-                const uint64_t c = r.h_counts[W + p], head = std::min(c, cap);
-                if (head) SH_HIP(s, hipMemcpyAsync(slot + at * K, l.spill + uint64_t(p) * cap * K, head * K * 8, hipMemcpyDeviceToDevice, l.es));
-                at += head;
-                if (c > cap) {
-                    SH_HIP(s, hipMemcpyAsync(slot + at * K, l.spill + spill_at * K, (c - cap) * K * 8, hipMemcpyDeviceToDevice, l.es));
-                    at += c - cap; spill_at += c - cap;
+                const uint64_t total = r.h_counts[cl.it() + p];
+                SH_HIP(s, hipMemcpyAsync(slot + r.off[size_t(p)] * K, l.spill + uint64_t(p) * cap * K, cap * K * 8, hipMemcpyDeviceToDevice, l.es));
+                if (total > cap) {
+                    SH_HIP(s, hipMemcpyAsync(slot + (r.off[size_t(p)] + cap) * K, l.spill + spill_at * K, (total - cap) * K * 8, hipMemcpyDeviceToDevice, l.es));
+                    spill_at += total - cap;
                 }
             }
-            if (total) SH_ENG(s, l, fqd_insert_keys(l.e, slot, total, s->own_len0, s->own_len1, r.keep_recv));
-            r.n_inserted = total;
+            SH_HIP(s, hipMemcpyAsync(r.d_ins_counts, r.h_ins_counts, n_sub * 8, hipMemcpyHostToDevice, l.es));
+            SH_ENG(s, l, fqd_insert_slabs(l.e, slot, uint32_t(n_sub), g.sub_cap, r.d_ins_counts, s->own_len0, s->own_len1, r.keep_recv));
         }
         SH_HIP(s, hipEventRecord(r.ev_ins, l.es));
     }
@@ -291,6 +379,7 @@ int finish_receive(fqd_shard* s, uint64_t k)
 int return_flags(fqd_shard* s, uint64_t k)
 {
     const int W = s->cfg.world;
+    const CountLayout& cl = s->cl;
     const uint64_t cap = s->cap;
     std::vector<Xfer> xs;
     std::vector<hipEvent_t> ready;
@@ -299,21 +388,21 @@ int return_flags(fqd_shard* s, uint64_t k)
         for (int src = 0; src < W; ++src) {
             Round* o = round_of(s, own, k); Round* a = round_of(s, src, k);
             if (!o && !a) continue;
-            // where source `src`'s flags start at the owner: slot src*cap in the slab layout, the running sum of the
-            // true counts in a round laid out again — only the owner needs to know which
-            const uint64_t c = a ? a->h_counts[own] : o->h_counts[W + src];
-            const uint8_t* from = o ? o->keep_recv + fqd_plan::owner_offset(o->h_counts + W, uint32_t(W), uint32_t(src), cap) : nullptr;
-            xs.push_back({own, src, from, a ? a->keep_back + fqd_plan::slab_slot(uint32_t(own), cap) : nullptr, cap});   // fixed size; a short slab's tail means nothing
-            if (c > cap)
+            // a source's flags start where the owner put its slab (slot src*cap, or further on in a round laid out again —
+            // only the owner needs to know); the flags of its spill follow the slab's
+            const uint64_t total = a ? a->h_counts[cl.ot() + own] : o->h_counts[cl.it() + src];
+            const uint8_t* from = o ? o->keep_recv + o->off[size_t(src)] : nullptr;
+            xs.push_back({own, src, from, a ? a->keep_back + fqd_plan::slab_slot(uint32_t(own), cap) : nullptr, cap});   // fixed size; unused slots' flags mean nothing
+            if (total > cap)
                 xs.push_back({own, src, o ? from + cap : nullptr,
-                              a ? a->keep_back + fqd_plan::spill_slot(a->h_counts, uint32_t(W), uint32_t(own), cap) : nullptr, c - cap});
+                              a ? a->keep_back + fqd_plan::spill_slot(a->h_counts + cl.ot(), uint32_t(W), uint32_t(own), cap) : nullptr, total - cap});
         }
     int rc = move(s, xs, ready);
     if (rc) return rc;
     for (Local& l : s->lr) {
         Round& r = l.rb[k & 1];
         SH_HIP(s, hipSetDevice(l.device));
-        const uint64_t slots = fqd_plan::spill_slot(r.h_counts, uint32_t(W), uint32_t(W), cap);
+        const uint64_t slots = fqd_plan::spill_slot(r.h_counts + cl.ot(), uint32_t(W), uint32_t(W), cap);
         const uint32_t grid = uint32_t(std::min<uint64_t>((slots + 255) / 256, 2048));
         hipLaunchKernelGGL(shard_scatter_flags_kernel, dim3(grid), dim3(256), 0, l.cs,
                            static_cast<const uint8_t*>(r.keep_back), static_cast<const uint32_t*>(r.origin), slots, r.keep_dst);
@@ -348,12 +437,17 @@ void free_all(fqd_shard* s)
             if (r.keep_recv) (void)hipFree(r.keep_recv);
             if (r.keep_back) (void)hipFree(r.keep_back);
             if (r.d_counts) (void)hipFree(r.d_counts);
+            if (r.d_ins_counts) (void)hipFree(r.d_ins_counts);
             if (r.h_counts) (void)hipHostFree(r.h_counts);
+            if (r.h_ins_counts) (void)hipHostFree(r.h_ins_counts);
             if (r.h_bad) (void)hipHostFree(r.h_bad);
             for (hipEvent_t ev : {r.ev_part, r.ev_xchg, r.ev_spill, r.ev_ins, r.ev_done, r.t0, r.t1}) if (ev) (void)hipEventDestroy(ev);
         }
         if (l.records) (void)hipFree(l.records);
         if (l.spill) (void)hipFree(l.spill);
+        if (l.re_grouped) (void)hipFree(l.re_grouped);
+        if (l.re_origin) (void)hipFree(l.re_origin);
+        if (l.re_counts) (void)hipFree(l.re_counts);
         if (l.cs) (void)hipStreamDestroy(l.cs);
     }
 }
@@ -376,14 +470,10 @@ int fqd_shard_unique_id(uint8_t* id)
     return FQD_OK;
 }
 
-uint64_t fqd_shard_slab_capacity(uint64_t round_reads, int32_t world, uint32_t slack_permille)
+uint64_t fqd_shard_slab_capacity(uint64_t round_reads, int32_t world, uint32_t)
 {
     if (world <= 0) return 0;
-    const uint64_t fair = (round_reads + uint64_t(world) - 1) / uint64_t(world);
-    const uint64_t slack = slack_permille ? slack_permille : 30u;
-    // a fair share plus slack plus six standard deviations of a binomial share, rounded to whole 16-key units
-    uint64_t sd6 = 0; while ((sd6 + 1) * (sd6 + 1) <= fair) ++sd6; sd6 *= 6;
-    return world == 1 ? std::max<uint64_t>(round_reads, 16) : ((fair + fair * slack / 1000 + sd6 + 64 + 15) & ~15ull);
+    return fqd_plan::geometry(round_reads, uint32_t(world)).cap();
 }
 
 int fqd_shard_create(fqd_engine* const* engines, const fqd_shard_config* cfg, fqd_shard** out)
@@ -400,8 +490,9 @@ int fqd_shard_create(fqd_engine* const* engines, const fqd_shard_config* cfg, fq
     s->S = cfg->len1 ? 2u : 1u;
     s->own_len0 = s->padded ? s->K : cfg->len0;                   // what the owners' engines are told their keys are
     s->own_len1 = s->padded ? FQD_OPAQUE_KEYS : cfg->len1;
-    s->cap = fqd_shard_slab_capacity(cfg->round_reads, cfg->world, cfg->slack_permille);
-    if (cfg->slab_records) s->cap = cfg->slab_records;
+    s->g = fqd_plan::geometry(cfg->round_reads, uint32_t(cfg->world), cfg->slab_records);
+    s->cap = s->g.cap();
+    s->cl = CountLayout{uint64_t(cfg->world), uint64_t(s->g.chunks)};
     bool distinct = true;
     for (int a = 0; a < cfg->n_local; ++a) {
         if (!engines[a]) { g_shard_error = "fqd_shard_create: null engine"; delete s; return FQD_ERR_ARG; }
@@ -415,6 +506,8 @@ int fqd_shard_create(fqd_engine* const* engines, const fqd_shard_config* cfg, fq
     if (s->use_rccl && !cfg->unique_id) { g_shard_error = "fqd_shard_create: RCCL needs the group's unique id"; delete s; return FQD_ERR_ARG; }
     auto bail = [&](const std::string& m) { g_shard_error = m; free_all(s); delete s; return FQD_ERR_HIP; };
     const uint64_t W = uint64_t(cfg->world), slots = W * s->cap + cfg->round_reads;
+    // sub-slabs an owner may have to list when it lays a round out again: every slab, and every spill as further sub-slabs
+    const uint64_t ins_subs = W * s->g.chunks + (W * cfg->round_reads + s->g.sub_cap - 1) / s->g.sub_cap + W;
     s->lr.resize(size_t(cfg->n_local));
     for (int a = 0; a < cfg->n_local; ++a) {
         Local& l = s->lr[size_t(a)];
@@ -427,10 +520,12 @@ int fqd_shard_create(fqd_engine* const* engines, const fqd_shard_config* cfg, fq
         for (Round& r : l.rb) {
             if ((err = hipMalloc(reinterpret_cast<void**>(&r.grouped), slots * s->K * 8)) != hipSuccess ||
                 (err = hipMalloc(reinterpret_cast<void**>(&r.origin), slots * 4)) != hipSuccess ||
-                (err = hipMalloc(reinterpret_cast<void**>(&r.keep_recv), W * s->cap + W * cfg->round_reads + s->cap)) != hipSuccess ||
+                (err = hipMalloc(reinterpret_cast<void**>(&r.keep_recv), ins_subs * s->g.sub_cap + s->cap)) != hipSuccess ||
                 (err = hipMalloc(reinterpret_cast<void**>(&r.keep_back), slots + s->cap)) != hipSuccess ||
-                (err = hipMalloc(reinterpret_cast<void**>(&r.d_counts), 2 * W * 8)) != hipSuccess ||
-                (err = hipHostMalloc(reinterpret_cast<void**>(&r.h_counts), 2 * W * 8, hipHostMallocDefault)) != hipSuccess ||
+                (err = hipMalloc(reinterpret_cast<void**>(&r.d_counts), s->cl.words() * 8)) != hipSuccess ||
+                (err = hipMalloc(reinterpret_cast<void**>(&r.d_ins_counts), ins_subs * 8)) != hipSuccess ||
+                (err = hipHostMalloc(reinterpret_cast<void**>(&r.h_counts), s->cl.words() * 8, hipHostMallocDefault)) != hipSuccess ||
+                (err = hipHostMalloc(reinterpret_cast<void**>(&r.h_ins_counts), ins_subs * 8, hipHostMallocDefault)) != hipSuccess ||
                 (err = hipHostMalloc(reinterpret_cast<void**>(&r.h_bad), 8, hipHostMallocDefault)) != hipSuccess)
                 return bail(std::string("shard buffers: ") + hipGetErrorString(err));
             for (hipEvent_t* ev : {&r.ev_part, &r.ev_xchg, &r.ev_spill, &r.ev_ins, &r.ev_done})
@@ -498,16 +593,21 @@ int fqd_shard_round(fqd_shard* s, const fqd_reads* seg, const uint64_t* n, uint8
         }
         SH_HIP(s, hipSetDevice(l.device));
         if (r.used) SH_HIP(s, hipStreamWaitEvent(l.es, r.ev_done, 0));     // round k-2 has left these buffers
-        r.used = true; r.n = n[a]; r.keep_dst = keep[a]; r.compact = false;
+        r.used = true; r.n = n[a]; r.keep_dst = keep[a]; r.relaid = false; r.regrouped = false;
         for (uint32_t m = 0; m < s->S; ++m) r.seg[m] = seg[a * s->S + m];
+        const CountLayout& cl = s->cl;
         if (s->padded) {
             SH_ENG(s, l, fqd_encode_padded(l.e, seg + a * s->S, n[a], s->cfg.len0, s->cfg.len1, l.records));
-            SH_ENG(s, l, fqd_partition_slabs(l.e, l.records, n[a], s->K, uint32_t(W), s->cap, r.grouped, r.d_counts, r.origin));
+            SH_ENG(s, l, fqd_partition_slabs(l.e, l.records, n[a], s->K, uint32_t(W), s->cap, r.grouped, r.d_counts + cl.ot(), r.origin));
+            SH_HIP(s, hipMemsetAsync(r.d_counts + cl.of(), 0, 8, l.es));
+            SH_HIP(s, hipMemsetAsync(r.d_counts + cl.of(), 1, 1, l.es));       // layout: slabs filled from their first slot on
         } else {
-            // one pass where it applies; a slab that overflows is noticed from the counts and the round grouped again (finish_receive)
-            SH_ENG(s, l, fqd_encode_slabs(l.e, seg + a * s->S, n[a], uint32_t(W), s->cap, r.grouped, r.d_counts, r.origin, 0u));
+            // one pass where it applies (it says which way it went in the word behind the totals); a sub-slab that overflows is
+            // noticed from the counts and the round grouped again (finish_receive)
+            SH_ENG(s, l, fqd_encode_slabs(l.e, seg + a * s->S, n[a], uint32_t(W), s->g.chunk_reads, s->g.chunks, s->g.sub_cap, r.grouped,
+                                          r.d_counts + cl.oc(), r.d_counts + cl.ot(), r.origin, 0u));
         }
-        SH_HIP(s, hipMemcpyAsync(r.h_counts, r.d_counts, size_t(W) * 8, hipMemcpyDeviceToHost, l.es));
+        SH_HIP(s, hipMemcpyAsync(r.h_counts, r.d_counts, size_t(cl.ic()) * 8, hipMemcpyDeviceToHost, l.es));
         SH_HIP(s, hipMemcpyAsync(r.h_bad, fqd_internal_state(l.e), 8, hipMemcpyDeviceToHost, l.es));     // first bad byte so far, this round's encoder included
         SH_HIP(s, hipEventRecord(r.ev_part, l.es));
         l.st.rounds++;

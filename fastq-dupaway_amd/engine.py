@@ -162,8 +162,10 @@ class Engine:
         self._check(self._L.fqd_partition_slabs(self._h, _addr(records), n, key_words, n_parts, slab_cap,
                                                 _addr(out_keys), _addr(counts), _addr(origin)))
 
-    def encode_slabs(self, segs: Sequence[Reads], n: int, n_parts: int, slab_cap: int, out_keys, counts, origin, exact: bool = False):
-        self._check(self._L.fqd_encode_slabs(self._h, _desc_array(segs), n, n_parts, slab_cap, _addr(out_keys), _addr(counts), _addr(origin), 1 if exact else 0))
+    def encode_slabs(self, segs: Sequence[Reads], n: int, n_parts: int, chunk_reads: int, n_chunks: int, sub_cap: int, out_keys,
+                     chunk_counts, totals, origin, exact: bool = False):
+        self._check(self._L.fqd_encode_slabs(self._h, _desc_array(segs), n, n_parts, chunk_reads, n_chunks, sub_cap, _addr(out_keys),
+                                             _addr(chunk_counts), _addr(totals), _addr(origin), 1 if exact else 0))
 
     def insert_slabs(self, keys, n_slabs: int, slab_cap: int, slab_count, len0: int, len1: int, keep):
         self._check(self._L.fqd_insert_slabs(self._h, _addr(keys), n_slabs, slab_cap, _addr(slab_count), len0, len1, _addr(keep)))

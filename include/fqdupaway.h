@@ -181,14 +181,21 @@ int  fqd_insert_keys(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t l
  * keep has n_slabs * slab_cap entries; those of unused slots mean nothing. */
 int  fqd_partition_slabs(fqd_engine* e, const uint64_t* records, uint64_t n, uint32_t key_words, uint32_t n_parts,
                          uint64_t slab_cap, uint64_t* out_keys, uint64_t* counts, uint32_t* origin);
-/* fqd_encode_uniform + fqd_partition_slabs in one call — and, where it applies (single-end reads of one fixed length,
- * at most 16 parts), in ONE pass over the input: every key is written once, straight into its slab, its place found by
- * chaining the counts of the encoder's tiles (a decoupled look-back).  Same slabs, same origin[], same counts[] as the
- * two calls; the one-pass form does not write the spill region (a key whose slab is full is not written at all — the
- * counts say so): call again with FQD_SLABS_EXACT to have it. */
+/* Encode + group in one call, with every owner's slab CUT into n_chunks sub-slabs of sub_cap slots, one per chunk of
+ * chunk_reads consecutive reads of the batch (n <= n_chunks * chunk_reads): chunk c's keys for part p go, in input order,
+ * to the slots from (p * n_chunks + c) * sub_cap on.  Cutting the slab the way the input is cut is what lets the keys be
+ * written ONCE, straight to their place, by an encoder whose workgroups need nothing from each other (csrc/fqd_kernels.hpp,
+ * encode_chunks) — where that applies: reads of one fixed length per mate, at most 16 parts, chunk_reads a multiple of 256.
+ * chunk_counts[p * n_chunks + c] and totals[p] (device; totals has n_parts + 1 words, the last says which way the slabs
+ * were filled: 0 sub-slab by sub-slab, 1 from their first slot on) are the TRUE counts; a key whose sub-slab is full is not written:
+ * call again with FQD_SLABS_EXACT for the three-step path (fqd_encode_uniform + fqd_partition_slabs through an internal
+ * buffer), which fills each slab from its first slot on — the same thing seen as full, partial and empty sub-slabs — and
+ * writes what n_chunks * sub_cap slots cannot take to the spill region (chunk_counts shows it as a count above sub_cap in
+ * the last sub-slab).  origin[] as fqd_partition_slabs has it.  Owner side: fqd_insert_slabs with n_parts_of_the_group *
+ * n_chunks slabs of sub_cap slots. */
 #define FQD_SLABS_EXACT 1u
-int  fqd_encode_slabs(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t n_parts, uint64_t slab_cap,
-                      uint64_t* out_keys, uint64_t* counts, uint32_t* origin, uint32_t flags);
+int  fqd_encode_slabs(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t n_parts, uint64_t chunk_reads, uint32_t n_chunks,
+                      uint64_t sub_cap, uint64_t* out_keys, uint64_t* chunk_counts, uint64_t* totals, uint32_t* origin, uint32_t flags);
 int  fqd_insert_slabs(fqd_engine* e, const uint64_t* keys, uint32_t n_slabs, uint64_t slab_cap, const uint64_t* slab_count,
                       uint32_t len0, uint32_t len1, uint8_t* keep);
 

@@ -354,17 +354,19 @@ def test_shard_group_refuses_a_read_longer_than_its_maximum():
 
 
 @pytest.mark.parametrize("paired", [False, True])
-@pytest.mark.parametrize("parts,cap", [(1, 70_000), (3, 30_000), (8, 9_000), (16, 5_000), (8, 2_000), (5, 16)])
-def test_one_pass_grouping_equals_the_three_step_path(monkeypatch, paired, parts, cap):
-    """fqd_encode_slabs: the one-pass encoder (keys straight into their slabs, places from a look-back over the tiles)
-    must give the slabs, origin[] and counts[] of fqd_encode_uniform + fqd_partition_slabs — for slabs with room, for
-    slabs that overflow (what does not fit is left out, the counts stay true), for tiles that end short."""
+@pytest.mark.parametrize("parts,chunk,sub_cap", [(1, 4096, 4096), (3, 4096, 1600), (8, 8192, 1300), (16, 4096, 420), (8, 4096, 500), (5, 65536, 64)])
+def test_one_pass_grouping_equals_the_three_step_path(monkeypatch, paired, parts, chunk, sub_cap):
+    """fqd_encode_slabs: the one-pass encoder writes every key straight into the sub-slab of its chunk; the three-step path
+    fills each slab from its first slot on.  Read sub-slab by sub-slab / from the first slot on, both must give every owner
+    the same keys in the same (input) order with the same origin[], and the same true counts — also when sub-slabs overflow
+    (what does not fit is left out by the one-pass form, the counts say so) and for tiles and chunks that end short."""
     from fastq_dupaway_amd import Engine, Reads
-    monkeypatch.setenv("FQD_ENCODE_GROUP", "1")
     n = 61_003
     S = 2 if paired else 1
     lens = (150, 101)
     dev = torch.device("cuda", 0)
+    G = -(-n // chunk)
+    cap = G * sub_cap
     with Engine(segments=S) as e:
         W = e.key_words(lens[0], lens[1] if paired else 0)
         bases = [torch.empty(n * lens[m] + 16, dtype=torch.uint8, device=dev) for m in range(S)]
@@ -376,15 +378,30 @@ def test_one_pass_grouping_equals_the_three_step_path(monkeypatch, paired, parts
         for exact in (True, False):
             keys = torch.full((slots * W,), -7, dtype=torch.int64, device=dev)
             origin = torch.full((slots,), -7, dtype=torch.int32, device=dev)
-            counts = torch.zeros(parts, dtype=torch.int64, device=dev)
-            e.encode_slabs(segs, n, parts, cap, keys, counts, origin, exact=exact)
+            counts = torch.full((parts * G,), -7, dtype=torch.int64, device=dev)
+            totals = torch.full((parts + 1,), -7, dtype=torch.int64, device=dev)
+            e.encode_slabs(segs, n, parts, chunk, G, sub_cap, keys, counts, totals, origin, exact=exact)
             e.sync()
-            out[exact] = (keys.cpu().numpy().reshape(slots, W), origin.cpu().numpy(), counts.cpu().numpy())
-    (k3, o3, c3), (k1, o1, c1) = out[True], out[False]
-    assert np.array_equal(c1, c3) and int(c3.sum()) == n
-    head = parts * cap
-    assert np.array_equal(o1[:head], o3[:head])
-    used = o3[:head] != -1
-    assert np.array_equal(k1[:head][used], k3[:head][used])
-    assert (c3 > cap).any() == (cap in (2_000, 16))
-    assert np.all(o1[head:] == -7) and np.all(k1[head:] == -7)            # the one-pass form never touches the spill region
+            out[exact] = (keys.cpu().numpy().reshape(slots, W), origin.cpu().numpy(), counts.cpu().numpy().reshape(parts, G), totals.cpu().numpy())
+    (k3, o3, c3, t3), (k1, o1, c1, t1) = out[True], out[False]
+    assert t3[parts] == 1 and t1[parts] == 0                               # the layout word
+    assert np.array_equal(t1[:parts], t3[:parts]) and int(t3[:parts].sum()) == n
+    assert np.array_equal(c1.sum(axis=1), t1[:parts])
+    overflowed = bool((c1 > sub_cap).any())
+    assert overflowed == (sub_cap in (500, 64) and parts > 1)
+    for p in range(parts):
+        # the owner's keys in order: sub-slab by sub-slab (one pass) / from the first slot on (three steps)
+        seq1_o = np.concatenate([o1[p * cap + c * sub_cap: p * cap + c * sub_cap + min(int(c1[p, c]), sub_cap)] for c in range(G)])
+        seq1_k = np.concatenate([k1[p * cap + c * sub_cap: p * cap + c * sub_cap + min(int(c1[p, c]), sub_cap)] for c in range(G)])
+        head = min(int(t3[p]), cap)
+        seq3_o, seq3_k = o3[p * cap: p * cap + head], k3[p * cap: p * cap + head]
+        assert np.all(np.diff(seq1_o) > 0) and np.all(np.diff(seq3_o) > 0)       # input order
+        if not overflowed:
+            assert np.array_equal(seq1_o, seq3_o) and np.array_equal(seq1_k, seq3_k)
+        else:                                                                     # what the one-pass form wrote is a subset, keys equal where both have the read
+            where = np.searchsorted(seq3_o, seq1_o)
+            both = (where < len(seq3_o)) & (seq3_o[np.minimum(where, len(seq3_o) - 1)] == seq1_o)
+            assert np.array_equal(seq1_k[both], seq3_k[where[both]])
+        # classic counts: full sub-slabs, a partial one, empty ones
+        assert list(c3[p]) == [max(0, min(int(t3[p]) - c * sub_cap, sub_cap if c + 1 < G else 1 << 62)) for c in range(G)]
+    assert np.all(o1[parts * cap:] == -7) and np.all(k1[parts * cap:] == -7)      # the one-pass form never touches the spill region

@@ -561,7 +561,7 @@ def main():
         sys.exit(f"bench.py --gpus {a.gpus} was started with WORLD_SIZE={world}: the two must agree")
     torch.cuda.set_device(local)
     dist = None
-    config = "pe" if a.paired else a.config
+    config = a.config if a.config in ("sharded1", "virtual") else ("pe" if a.paired else a.config)
     sharded_mode = False
     if world > 1:
         sharded_mode = "ranks"
@@ -578,7 +578,7 @@ def main():
     dev = torch.device("cuda", local)
     L = a.read_len
 
-    headline_paired = config == "pe"
+    headline_paired = config == "pe" or a.paired
     res, eng, bases, expect, keep = device_phase(a, torch, dist, dev, local, rank, world, headline_paired, sharded_mode, a.cpu_sample)
     out = None
     if rank == 0:

@@ -130,4 +130,9 @@ uint64_t plan_spill_slot(const uint64_t* counts, uint32_t world, uint32_t part, 
 int      plan_owner_is_compact(const uint64_t* in_counts, uint32_t world, uint64_t cap) { return owner_is_compact(in_counts, world, cap) ? 1 : 0; }
 uint64_t plan_owner_offset(const uint64_t* in_counts, uint32_t world, uint32_t src, uint64_t cap) { return owner_offset(in_counts, world, src, cap); }
 uint64_t plan_owner_records(const uint64_t* in_counts, uint32_t world, uint64_t cap) { return owner_records(in_counts, world, cap); }
+void     plan_geometry(uint64_t round_reads, uint32_t world, uint64_t forced_cap, uint64_t* chunk_reads, uint32_t* chunks, uint64_t* sub_cap)
+{ const Geometry g = geometry(round_reads, world, forced_cap); *chunk_reads = g.chunk_reads; *chunks = g.chunks; *sub_cap = g.sub_cap; }
+uint64_t plan_classic_count(uint64_t total, uint32_t c, uint32_t chunks, uint64_t sub_cap) { return classic_count(total, c, chunks, sub_cap); }
+uint64_t plan_owner_sub_slabs(uint64_t total, uint64_t chunk_reads, uint32_t chunks, uint64_t sub_cap)
+{ Geometry g; g.chunk_reads = chunk_reads; g.chunks = chunks; g.sub_cap = sub_cap; return owner_sub_slabs(total, g); }
 }

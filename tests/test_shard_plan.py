@@ -56,6 +56,40 @@ def _plan():
     return lib
 
 
+def test_sub_slab_geometry():
+    """Slabs cut into one sub-slab per chunk of the input (fqd_plan::geometry): chunks of whole tiles covering the round, room
+    for a fair share plus 5.5 sigma, no slack for a group of one; classic_count reads a slab filled from its first slot on as
+    full / partial / empty sub-slabs and shows a spill in the last one; a spill takes further sub-slabs at an owner."""
+    _build()
+    P = _plan()
+    P.plan_geometry.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    P.plan_classic_count.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]; P.plan_classic_count.restype = C.c_uint64
+    P.plan_owner_sub_slabs.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64]; P.plan_owner_sub_slabs.restype = C.c_uint64
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 3, 8, 16):
+        for reads in (1, 300, 4096, 50_000, 8 << 20, 50 << 20, 100_000_000):
+            cr, ch, sc = C.c_uint64(), C.c_uint32(), C.c_uint64()
+            P.plan_geometry(reads, world, 0, C.byref(cr), C.byref(ch), C.byref(sc))
+            chunk, chunks, sub = cr.value, ch.value, sc.value
+            assert chunk % 256 == 0 and chunk >= 4096 and chunks * chunk >= reads and (chunks - 1) * chunk < reads and chunks <= 1024
+            if world == 1:
+                assert sub == chunk
+            else:
+                fair = -(-chunk // world)
+                assert fair + 5 * fair ** 0.5 < sub < fair + 6 * fair ** 0.5 + 32
+                # a binomial share of a chunk stays inside a sub-slab
+                assert (rng.binomial(chunk, 1.0 / world, 20000) <= sub).all()
+            for total in (0, 1, sub, sub + 1, chunks * sub, chunks * sub + 5, 3 * chunks * sub + 1):
+                got = [P.plan_classic_count(total, c, chunks, sub) for c in range(chunks)]
+                assert sum(got) == total and all(v == sub for v in got[:-1] if total >= chunks * sub)
+                assert all(got[c] <= sub for c in range(chunks - 1)) and (got[-1] > sub) == (total > chunks * sub)
+                over = max(0, total - chunks * sub)
+                assert P.plan_owner_sub_slabs(total, chunk, chunks, sub) == chunks + -(-over // sub)
+    cr, ch, sc = C.c_uint64(), C.c_uint32(), C.c_uint64()
+    P.plan_geometry(20_000, 4, 16, C.byref(cr), C.byref(ch), C.byref(sc))       # tests force tiny slabs: one chunk, one sub-slab
+    assert (ch.value, sc.value) == (1, 16) and cr.value >= 20_000
+
+
 def _gloo_rank(rank, world, port, reads, cap, result_dir):
     """One rank of the exchange, round after round, with the product's geometry and a set for a table."""
     import hashlib

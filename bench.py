@@ -176,10 +176,13 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
     shard_before = sharded.stats(0) if sharded else None
     fence()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(a.steps):
         step()
+        marks.append(time.perf_counter())                          # (a step ends with the engine's sync: its own time is known, nothing is added to the region)
     fence()
     dt = time.perf_counter() - t0
+    each = sorted((b - a_) * 1e3 for a_, b in zip([t0] + marks[:-1], marks))
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -254,7 +257,8 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
                           "sharding": "none" if not sharded_mode else
                                       (f"hash-prefix sharding over {job_world} rank(s)" + (f" sharing this GPU ({n_rank} reads each)" if sharded_mode == "virtual" else f" = {world} GPU(s), one process each")
                                        + f", fixed-size all-to-all slabs, {rounds} round(s) of {m} reads per rank and step")},
-               "parity": parity, "roofline": roofline}
+               "parity": parity, "roofline": roofline,
+               "step_ms_spread": {"min": round(each[0], 3), "median": round(each[len(each) // 2], 3), "max": round(each[-1], 3)}}
         if sharded_mode:
             res["per_gpu"] = per_gpu
         if world == 1 and cpu_sample > 0 and sharded_mode != "virtual":
@@ -585,7 +589,8 @@ def main():
         out = {"metric": "Mreads/s dedup, 150 bp %s FASTQ (device phase: sequences resident in HBM)" % ("PE" if headline_paired else "SE"),
                "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "u8", "data": "synthetic", "config": res["config"], "parity": res["parity"], "roofline": res["roofline"]}
+               "dtype": "u8", "data": "synthetic", "config": res["config"], "parity": res["parity"], "roofline": res["roofline"],
+               "step_ms_spread": res["step_ms_spread"]}
         if "cpu_baseline" in res:
             out["cpu_baseline"] = res["cpu_baseline"]
         if "per_gpu" in res:

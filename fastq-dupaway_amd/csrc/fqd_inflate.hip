@@ -57,18 +57,43 @@ void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __res
     if (bad) atomicAdd(n_bad, static_cast<unsigned long long>(bad));
 }
 
+// Byte table and "advance by 128 * 2^k zero bytes" matrices of CRC-32, worked out by the compiler: they live in the
+// code object, so that queueing a batch (fqd_bgzf_inflate_async) never copies from pageable host memory — such a
+// copy makes the caller wait for everything queued on the stream before it, i.e. for the batch before.
 struct CrcTables { uint32_t table[256]; uint32_t shift[fqd::bgzf::kLevels][32]; };
+constexpr CrcTables make_crc_tables()
+{
+    CrcTables c{};
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t r = i;
+        for (int k = 0; k < 8; ++k) r = (r >> 1) ^ (r & 1u ? 0xEDB88320u : 0u);
+        c.table[i] = r;
+    }
+    for (uint32_t b = 0; b < 32; ++b) {
+        uint32_t reg = 1u << b;
+        for (uint32_t k = 0; k < fqd::bgzf::kChunk; ++k) reg = c.table[reg & 0xFFu] ^ (reg >> 8);
+        c.shift[0][b] = reg;
+    }
+    for (uint32_t k = 1; k < fqd::bgzf::kLevels; ++k)
+        for (uint32_t b = 0; b < 32; ++b) {
+            uint32_t out = 0;                                 // the matrix applied to its own column: twice as far
+            for (uint32_t j = 0; j < 32u; ++j) out ^= (c.shift[k - 1][b] >> j) & 1u ? c.shift[k - 1][j] : 0u;
+            c.shift[k][b] = out;
+        }
+    return c;
+}
+__device__ const CrcTables g_crc_tables = make_crc_tables();
 
 __global__ __launch_bounds__(fqd::bgzf::kThreads)
 void bgzf_check_crc_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ out_len,
-                           const uint32_t* __restrict__ want, uint64_t members, const CrcTables* __restrict__ tabs,
-                           unsigned long long* __restrict__ n_bad)
+                           const uint32_t* __restrict__ want, uint64_t members, unsigned long long* __restrict__ n_bad)
 {
     using namespace fqd::bgzf;
     __shared__ alignas(16) uint8_t data[kThreads * kChunk + 16];
     __shared__ uint32_t table[256];
     __shared__ uint32_t crc[kThreads];
     const uint32_t t = threadIdx.x;
+    const CrcTables* __restrict__ tabs = &g_crc_tables;
     for (uint32_t i = t; i < 256u; i += kThreads) table[i] = tabs->table[i];
     __syncthreads();
     for (uint64_t m = blockIdx.x; m < members; m += gridDim.x) {
@@ -213,22 +238,6 @@ void records_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict
 
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-void fill_crc_tables(CrcTables& c)
-{
-    for (uint32_t i = 0; i < 256; ++i) {
-        uint32_t r = i;
-        for (int k = 0; k < 8; ++k) r = (r >> 1) ^ (r & 1u ? 0xEDB88320u : 0u);
-        c.table[i] = r;
-    }
-    for (uint32_t b = 0; b < 32; ++b) {
-        uint32_t reg = 1u << b;
-        for (uint32_t k = 0; k < fqd::bgzf::kChunk; ++k) reg = c.table[reg & 0xFFu] ^ (reg >> 8);
-        c.shift[0][b] = reg;
-    }
-    for (uint32_t k = 1; k < fqd::bgzf::kLevels; ++k)
-        for (uint32_t b = 0; b < 32; ++b) c.shift[k][b] = fqd::bgzf::crc_advance(c.shift[k - 1], c.shift[k - 1][b]);
-}
-
 } // namespace
 
 extern "C" {
@@ -247,20 +256,16 @@ int fqd_bgzf_inflate_async(fqd_engine* e, const uint8_t* comp, const uint64_t* c
     hipStream_t stream = fqd_internal_stream(e);
     const uint32_t grid = uint32_t(std::min<uint64_t>((n_members + kWave - 1) / kWave, 256u * 6u * 2u));
     const size_t lens_bytes = round_up(size_t(fqd::inflate::kLitSymbols + fqd::inflate::kDistSymbols + 2) * grid * kWave, 256);
-    const size_t tabs_bytes = round_up(sizeof(CrcTables), 256);
     void* base = nullptr;
-    const int rc = fqd_internal_scratch(e, 1, 256 + tabs_bytes + lens_bytes, &base);     // batches of one stream share it: they run one after the other
+    const int rc = fqd_internal_scratch(e, 1, 256 + lens_bytes, &base);     // batches of one stream share it: they run one after the other
     if (rc != FQD_OK) return rc;
-    CrcTables* d_tabs = reinterpret_cast<CrcTables*>(static_cast<uint8_t*>(base) + 256);
-    uint8_t* d_lens = static_cast<uint8_t*>(base) + 256 + tabs_bytes;
-    static const CrcTables tabs = [] { CrcTables c; fill_crc_tables(c); return c; }();
-    INF_TRY(e, hipMemcpyAsync(d_tabs, &tabs, sizeof tabs, hipMemcpyHostToDevice, stream));
+    uint8_t* d_lens = static_cast<uint8_t*>(base) + 256;
     unsigned long long* d_bad = reinterpret_cast<unsigned long long*>(bad_counters);
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(grid), dim3(kWave), 0, stream, comp, comp_off, comp_len, out_off, out_len, n_members,
                        text, d_lens, d_bad);
     INF_TRY(e, hipGetLastError());
     hipLaunchKernelGGL(bgzf_check_crc_kernel, dim3(uint32_t(std::min<uint64_t>(n_members, 2048))), dim3(fqd::bgzf::kThreads), 0, stream,
-                       static_cast<const uint8_t*>(text), out_off, out_len, crc, n_members, static_cast<const CrcTables*>(d_tabs), d_bad + 1);
+                       static_cast<const uint8_t*>(text), out_off, out_len, crc, n_members, d_bad + 1);
     INF_TRY(e, hipGetLastError());
     return FQD_OK;
 }
@@ -278,21 +283,17 @@ int fqd_bgzf_inflate(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_of
     hipStream_t stream = fqd_internal_stream(e);
     const uint32_t grid = uint32_t(std::min<uint64_t>((n_members + kWave - 1) / kWave, 256u * 6u * 2u));
     const size_t lens_bytes = round_up(size_t(fqd::inflate::kLitSymbols + fqd::inflate::kDistSymbols + 2) * grid * kWave, 256);
-    const size_t tabs_bytes = round_up(sizeof(CrcTables), 256);
     void* base = nullptr;
-    const int rc = fqd_internal_scratch(e, 1, 256 + tabs_bytes + lens_bytes, &base);
+    const int rc = fqd_internal_scratch(e, 1, 256 + lens_bytes, &base);
     if (rc != FQD_OK) return rc;
     unsigned long long* d_bad = static_cast<unsigned long long*>(base);
-    CrcTables* d_tabs = reinterpret_cast<CrcTables*>(static_cast<uint8_t*>(base) + 256);
-    uint8_t* d_lens = static_cast<uint8_t*>(base) + 256 + tabs_bytes;
-    static const CrcTables tabs = [] { CrcTables c; fill_crc_tables(c); return c; }();
+    uint8_t* d_lens = static_cast<uint8_t*>(base) + 256;
     INF_TRY(e, hipMemsetAsync(d_bad, 0, 256, stream));
-    INF_TRY(e, hipMemcpyAsync(d_tabs, &tabs, sizeof tabs, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(grid), dim3(kWave), 0, stream, comp, comp_off, comp_len, out_off, out_len, n_members,
                        text, d_lens, d_bad);
     INF_TRY(e, hipGetLastError());
     hipLaunchKernelGGL(bgzf_check_crc_kernel, dim3(uint32_t(std::min<uint64_t>(n_members, 2048))), dim3(fqd::bgzf::kThreads), 0, stream,
-                       static_cast<const uint8_t*>(text), out_off, out_len, crc, n_members, static_cast<const CrcTables*>(d_tabs), d_bad + 1);
+                       static_cast<const uint8_t*>(text), out_off, out_len, crc, n_members, d_bad + 1);
     INF_TRY(e, hipGetLastError());
     unsigned long long bad[2] = {0, 0};
     INF_TRY(e, hipMemcpyAsync(bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, stream));

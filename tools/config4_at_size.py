@@ -13,6 +13,7 @@ Prints a progress line per stage (append-friendly for gpurun_out logs).
   python tools/config4_at_size.py [--pairs 100000000] [--dir /dev/shm/fqd_c4] [--gz-level 1]
 """
 import argparse
+import shlex
 import os
 import subprocess
 import sys
@@ -40,6 +41,7 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip reading the outputs back")
     ap.add_argument("--settle", type=float, default=0.0, help="seconds to wait before the first timed run (the kernel clears the device memory a process that "
                                                               "has just exited gave back; an allocation waits for that clearing)")
+    ap.add_argument("--wrap", default="", help="command prefix for the --also runs that carry WRAP=1, ({i} = the run's index) e.g. 'rocprofv3 --kernel-trace --output-format csv -d DIR/{i} -o c4 --'")
     ap.add_argument("--also", default="", help="further timed runs on the same inputs, each under extra environment settings: "
                                                "'FQD_HOST_THREADS=8;FQD_HOST_THREADS=32,FQD_GZ_LEVEL=6' (only their -v lines are checked)")
     a = ap.parse_args()
@@ -117,13 +119,14 @@ def main():
     ok = r.returncode == 0 and r.stdout == (f"{n} valid read pairs processed, out of which {dups} duplicates were removed.\n"
                                              f"0 Non-matching entries from both files were skipped.\n")
     log("-v lines == closed form:", ok)
-    for extra in filter(None, a.also.split(";")):
+    for run, extra in enumerate(filter(None, a.also.split(";"))):
         env = dict(base_env)
         env.update(kv.split("=", 1) for kv in extra.split(","))
+        wrap = shlex.split(a.wrap.replace("{i}", str(run))) if env.pop("WRAP", "") else []   # "WRAP=1,...": this run under --wrap's prefix (a profiler)
         if "SLEEP" in env:                                    # "SLEEP=8,...": let the memory the run before gave back be cleared first
             time.sleep(float(env.pop("SLEEP")))
         t1 = time.perf_counter()
-        r2 = subprocess.run(cmd, capture_output=True, text=True, cwd=str(d), env=env)
+        r2 = subprocess.run(wrap + cmd, capture_output=True, text=True, cwd=str(d), env=env)
         dt2 = time.perf_counter() - t1
         stages = "; ".join(" ".join(l.split("] ", 1)[1].split("  (")[0].split()) for l in r2.stderr.splitlines() if "unordered" in l or "on the GPU" in l)
         log(f"also [{extra}]: rc={r2.returncode} {dt2:.1f} s = {n / dt2 / 1e6:.3f} M pairs/s, same -v lines: {r2.stdout == r.stdout} | {stages}")

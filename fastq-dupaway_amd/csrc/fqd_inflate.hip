@@ -1,7 +1,7 @@
 // fqd_inflate.hip — BGZF inputs inflated and cut into records on the GPU (same library as fqd_engine.hip).
 //
-//   bgzf_inflate_kernel   one thread per member (fqd_inflate_core.hpp), 64 members per wave, the two
-//                         canonical-code tables of every thread in LDS (420 B, interleaved by lane: six waves per CU)
+//   bgzf_inflate_kernel   one WAVE per member (fqd_inflate_wave.hpp): the lanes decode a block's bits side by side from
+//                         guessed code boundaries, fall into step, count, decode again to write; tables in LDS (10 KB)
 //   bgzf_check_crc_kernel one workgroup per member: CRC-32 of what came out against the member's trailer
 //                         (chunk registers + pairwise combine, as the writer: fqd_bgzf_core.hpp)
 //   count_newlines / newline_positions / records kernels: the inflated text cut into FASTQ/FASTA records
@@ -13,11 +13,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 
 #include "../../include/fqdupaway.h"
 #include "fqd_bgzf_core.hpp"
-#include "fqd_inflate_core.hpp"
+#include "fqd_inflate_wave.hpp"
 
 #define FQD_HIDDEN __attribute__((visibility("hidden")))
 FQD_HIDDEN hipStream_t fqd_internal_stream(fqd_engine* e);
@@ -33,28 +34,52 @@ namespace {
 
 constexpr uint32_t kWave = 64;
 
-struct GlobalLens {                                     // byte i of thread g at [i * stride + g]
-    uint8_t* base; uint64_t stride;
-    __device__ uint32_t get(uint32_t i) const { return base[i * stride]; }
-    __device__ void set(uint32_t i, uint8_t v) { base[i * stride] = v; }
+// The wave as fqd_inflate_wave.hpp sees it: a workgroup IS one wave, so the workgroup barrier costs nothing and makes
+// the LDS and global writes of a phase visible to the next.
+struct WaveCtx {
+    static constexpr uint32_t kLanes = kWave;
+    uint32_t lane;
+    template <class F> __device__ __forceinline__ void lanes(F f) { f(lane); __syncthreads(); }
+    template <class F> __device__ __forceinline__ void lanes_open(F f) { f(lane); }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    template <class F> __device__ __forceinline__ uint64_t ballot(F f) { return __ballot(f(lane) ? 1 : 0); }
+    __device__ __forceinline__ uint32_t same(uint32_t v) const { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+    __device__ __forceinline__ void add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
+#ifdef FQD_STAMPS
+    unsigned long long last = 0, spent[8] = {};
+    __device__ __forceinline__ void mark(int k) { const unsigned long long now = __builtin_readcyclecounter(); spent[k] += now - last; last = now; }
+#else
+    __device__ __forceinline__ void mark(int) {}
+#endif
 };
+#ifdef FQD_STAMPS
+__device__ unsigned long long g_inflate_cycles[8];
+#endif
 
-__global__ __launch_bounds__(kWave)
+constexpr uint32_t kInflateWavesPerCu = 16;            // 10 KB of LDS each; four per SIMD need <= 128 VGPRs
+
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_len,
                          const uint64_t* __restrict__ out_off, const uint32_t* __restrict__ out_len, uint64_t members,
-                         uint8_t* __restrict__ text, uint8_t* __restrict__ lens_scratch, unsigned long long* __restrict__ n_bad)
+                         uint8_t* __restrict__ text, fqd::winf::Token* __restrict__ tokens, unsigned long long* __restrict__ n_bad)
 {
-    __shared__ alignas(4) uint8_t tables[fqd::inflate::kPackedBytes * kWave];      // 26880 B: six waves per CU
-    const uint64_t threads = uint64_t(gridDim.x) * kWave, gid = uint64_t(blockIdx.x) * kWave + threadIdx.x;
-    fqd::inflate::PackedTables<kWave> t(tables, threadIdx.x);
-    GlobalLens lens{lens_scratch + gid, threads};
+    __shared__ fqd::winf::Shared<kWave> sh;
+    WaveCtx ctx{threadIdx.x};
+#ifdef FQD_STAMPS
+    ctx.last = __builtin_readcyclecounter();
+#endif
+    fqd::winf::Token* tok = tokens + size_t(blockIdx.x) * fqd::winf::kTokenRoom;
     uint32_t bad = 0;
-    for (uint64_t m = gid; m < members; m += threads) {
-        if (out_len[m] > 65536u) { ++bad; continue; }         // no BGZF member holds more (the CLI's header walk says so too; an ABI caller may not)
-        const uint32_t st = fqd::inflate::inflate_member(comp + comp_off[m], comp_len[m], text + out_off[m], out_len[m], t, lens);
-        bad += st != fqd::inflate::kOk ? 1u : 0u;
+    for (uint64_t m = blockIdx.x; m < members; m += gridDim.x) {
+        const uint32_t len = out_len[m];
+        if (len > 65536u) { ++bad; continue; }                // no BGZF member holds more (the CLI's header walk says so too; an ABI caller may not)
+        const uint32_t st = fqd::winf::inflate_member(ctx, sh, comp + comp_off[m], comp_len[m], text + out_off[m], len, tok);
+        bad += st != fqd::winf::kOk ? 1u : 0u;
     }
-    if (bad) atomicAdd(n_bad, static_cast<unsigned long long>(bad));
+    if (threadIdx.x == 0 && bad) atomicAdd(n_bad, static_cast<unsigned long long>(bad));
+#ifdef FQD_STAMPS
+    if (threadIdx.x == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_inflate_cycles[k], ctx.spent[k]);
+#endif
 }
 
 // Byte table and "advance by 128 * 2^k zero bytes" matrices of CRC-32, worked out by the compiler: they live in the
@@ -254,15 +279,15 @@ int fqd_bgzf_inflate_async(fqd_engine* e, const uint8_t* comp, const uint64_t* c
     if (n_members == 0) return FQD_OK;
     INF_TRY(e, hipSetDevice(fqd_internal_device(e)));
     hipStream_t stream = fqd_internal_stream(e);
-    const uint32_t grid = uint32_t(std::min<uint64_t>((n_members + kWave - 1) / kWave, 256u * 6u * 2u));
-    const size_t lens_bytes = round_up(size_t(fqd::inflate::kLitSymbols + fqd::inflate::kDistSymbols + 2) * grid * kWave, 256);
+    const uint32_t grid = uint32_t(std::min<uint64_t>(n_members, 256u * kInflateWavesPerCu));
+    const size_t lens_bytes = round_up(sizeof(fqd::winf::Token) * fqd::winf::kTokenRoom * grid, 256);
     void* base = nullptr;
     const int rc = fqd_internal_scratch(e, 1, 256 + lens_bytes, &base);     // batches of one stream share it: they run one after the other
     if (rc != FQD_OK) return rc;
-    uint8_t* d_lens = static_cast<uint8_t*>(base) + 256;
+    fqd::winf::Token* d_tokens = reinterpret_cast<fqd::winf::Token*>(static_cast<uint8_t*>(base) + 256);
     unsigned long long* d_bad = reinterpret_cast<unsigned long long*>(bad_counters);
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(grid), dim3(kWave), 0, stream, comp, comp_off, comp_len, out_off, out_len, n_members,
-                       text, d_lens, d_bad);
+                       text, d_tokens, d_bad);
     INF_TRY(e, hipGetLastError());
     hipLaunchKernelGGL(bgzf_check_crc_kernel, dim3(uint32_t(std::min<uint64_t>(n_members, 2048))), dim3(fqd::bgzf::kThreads), 0, stream,
                        static_cast<const uint8_t*>(text), out_off, out_len, crc, n_members, d_bad + 1);
@@ -281,16 +306,16 @@ int fqd_bgzf_inflate(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_of
     if (n_members == 0) return FQD_OK;
     INF_TRY(e, hipSetDevice(fqd_internal_device(e)));
     hipStream_t stream = fqd_internal_stream(e);
-    const uint32_t grid = uint32_t(std::min<uint64_t>((n_members + kWave - 1) / kWave, 256u * 6u * 2u));
-    const size_t lens_bytes = round_up(size_t(fqd::inflate::kLitSymbols + fqd::inflate::kDistSymbols + 2) * grid * kWave, 256);
+    const uint32_t grid = uint32_t(std::min<uint64_t>(n_members, 256u * kInflateWavesPerCu));
+    const size_t lens_bytes = round_up(sizeof(fqd::winf::Token) * fqd::winf::kTokenRoom * grid, 256);
     void* base = nullptr;
     const int rc = fqd_internal_scratch(e, 1, 256 + lens_bytes, &base);
     if (rc != FQD_OK) return rc;
     unsigned long long* d_bad = static_cast<unsigned long long*>(base);
-    uint8_t* d_lens = static_cast<uint8_t*>(base) + 256;
+    fqd::winf::Token* d_tokens = reinterpret_cast<fqd::winf::Token*>(static_cast<uint8_t*>(base) + 256);
     INF_TRY(e, hipMemsetAsync(d_bad, 0, 256, stream));
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(grid), dim3(kWave), 0, stream, comp, comp_off, comp_len, out_off, out_len, n_members,
-                       text, d_lens, d_bad);
+                       text, d_tokens, d_bad);
     INF_TRY(e, hipGetLastError());
     hipLaunchKernelGGL(bgzf_check_crc_kernel, dim3(uint32_t(std::min<uint64_t>(n_members, 2048))), dim3(fqd::bgzf::kThreads), 0, stream,
                        static_cast<const uint8_t*>(text), out_off, out_len, crc, n_members, d_bad + 1);
@@ -298,6 +323,18 @@ int fqd_bgzf_inflate(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_of
     unsigned long long bad[2] = {0, 0};
     INF_TRY(e, hipMemcpyAsync(bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, stream));
     INF_TRY(e, hipStreamSynchronize(stream));
+#ifdef FQD_STAMPS
+    {
+        unsigned long long c[8] = {}, zero[8] = {};
+        INF_TRY(e, hipMemcpyFromSymbol(c, HIP_SYMBOL(g_inflate_cycles), sizeof c));
+        INF_TRY(e, hipMemcpyToSymbol(HIP_SYMBOL(g_inflate_cycles), zero, sizeof zero));
+        unsigned long long all = 0; for (int k = 0; k < 8; ++k) all += c[k];
+        const char* name[8] = {"headers", "tables", "count rounds", "prefix", "write pass", "match order", "stored", "match copies"};
+        std::fprintf(stderr, "[inflate cycles, summed over waves] total %.3e:", double(all));
+        for (int k = 0; k < 8; ++k) std::fprintf(stderr, "  %s %.1f%%", name[k], all ? 100.0 * double(c[k]) / double(all) : 0.0);
+        std::fprintf(stderr, "\n");
+    }
+#endif
     *n_bad = bad[0] + bad[1];
     return FQD_OK;
 }

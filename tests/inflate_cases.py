@@ -43,5 +43,8 @@ def cases():
     rnd = rng.integers(0, 256, size=150_000, dtype=np.uint8).tobytes()
     yield "random_bytes", rnd, bgzf(rnd, size=60000)
     yield "long_runs", b"A" * 100_000 + b"CG" * 50_000, bgzf(b"A" * 100_000 + b"CG" * 50_000)
+    periods = b"".join(bytes(range(65, 65 + k)) * (n // k) + b"\n" for k in (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 31, 32, 33) for n in (3, 7, 8, 9, 15, 16, 17, 40, 64, 150, 258, 259, 1000))
+    yield "short_periods", periods, bgzf(periods)
+    yield "short_periods_level1", periods, bgzf(periods, level=1)
     yield "one_byte", b"x", bgzf(b"x")
     yield "empty_members_between", fq[:70_000], member(fq[:30_000]) + member(b"") + member(fq[30_000:70_000]) + EOF_MARK

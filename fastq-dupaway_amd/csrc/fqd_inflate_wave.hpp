@@ -109,16 +109,19 @@ FQD_HD uint32_t reverse_bits32(uint32_t v)
 FQD_HD uint32_t popcount64(uint64_t v) { return uint32_t(__builtin_popcountll(v)); }
 FQD_HD uint32_t lowest_bit64(uint64_t v) { return uint32_t(__builtin_ctzll(v)); }
 
-// Bits of the member, least significant first, read as aligned 32-bit words from any bit position on, one word
-// AHEAD of the one being consumed: its load is in flight while the bits before it are decoded (a refill that had to
-// wait for its own load would cost a trip to memory every few codes).  Words beyond the member read as zero: a lane
-// that runs off the end decodes zeros until its position says so.
+// Bits of the member, least significant first, read as aligned 32-bit words from any bit position on.  The words
+// come four at a time and AHEAD of their use: a memory instruction costs the CU's one address unit some 25 to 60
+// clocks however few lanes ask (tools/vmem_probe.hip), and with 64 lanes each wanting a word every few codes that is
+// one instruction per turn of the decode loop unless a lane asks seldom; and the load is in flight while the bits
+// before it are decoded.  Words beyond the member read as zero: a lane that runs off the end decodes zeros until
+// its position says so.
 struct Bits {
     const uint32_t* words = nullptr;
     uint32_t end_word = 0, lead = 0;      // words that hold the member; bits of words[0] before its first byte
     uint64_t buf = 0;
-    uint32_t cnt = 0, next = 0;           // valid bits of buf; index of the word held in `ahead`
-    uint32_t ahead = 0;
+    uint32_t cnt = 0, next = 0;           // valid bits of buf; index of the first word not yet in buf
+    uint64_t q_lo = 0, q_hi = 0;          // words[next ...], `have` of them
+    uint32_t have = 0;
     uint32_t at = 0;                      // bit position of the head of buf, from the member's first bit
 
     FQD_HD void open(const uint8_t* p, uint32_t nbytes)
@@ -129,13 +132,25 @@ struct Bits {
         lead = 8u * skip;
     }
     FQD_HD uint32_t word(uint32_t i) const { return i < end_word ? words[i] : 0u; }
+    FQD_HD void fetch(uint32_t i)                         // q = words[i .. i + 4)
+    {
+        if (i + 4u <= end_word) {
+            uint64_t v[2];
+            __builtin_memcpy(v, words + i, 16);
+            q_lo = v[0]; q_hi = v[1];
+        } else {
+            q_lo = uint64_t(word(i)) | (uint64_t(word(i + 1u)) << 32);
+            q_hi = uint64_t(word(i + 2u)) | (uint64_t(word(i + 3u)) << 32);
+        }
+        have = 4u;
+    }
     FQD_HD void seek(uint32_t bit)
     {
         const uint32_t a = bit + lead;
         next = a >> 5;
         const uint64_t lo = word(next), hi = word(next + 1u);
-        ahead = word(next + 2u);
         next += 2u;
+        fetch(next);
         buf = (lo | (hi << 32)) >> (a & 31u);
         cnt = 64u - (a & 31u);
         at = bit;
@@ -143,7 +158,12 @@ struct Bits {
     FQD_HD uint32_t pos() const { return at; }
     FQD_HD void ensure()                                  // at least 33 bits afterwards
     {
-        if (cnt <= 32u) { buf |= uint64_t(ahead) << cnt; cnt += 32u; ++next; ahead = word(next); }
+        if (cnt <= 32u) {
+            buf |= (q_lo & 0xFFFFFFFFull) << cnt;
+            cnt += 32u; ++next;
+            q_lo = (q_lo >> 32) | (q_hi << 32); q_hi >>= 32;
+            if (--have == 0u) fetch(next);
+        }
     }
     FQD_HD uint32_t peek(uint32_t n) const { return uint32_t(buf) & ((1u << n) - 1u); }     // n <= 31
     FQD_HD void skip(uint32_t n) { buf >>= n; cnt -= n; at += n; }
@@ -258,6 +278,16 @@ FQD_HD void pack_literals(Ctx& ctx, S& sh)
 // One lane over its subsequence: from the bit `from` (a code boundary, or a guess at one) to the first code boundary
 // at or beyond `stop`, or to the end-of-block code, or to something that is no code.  kWrite: the literals go to
 // out[] from `pos` on and the matches to tok[] from `tk` on (the counts of the run before said where).
+FQD_HD uint64_t load8(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }      // (any alignment)
+FQD_HD void store8(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+
+FQD_HD void store_low(uint8_t* d, uint64_t v, uint32_t n)                       // the low n < 8 bytes of v
+{
+    if (n & 4u) { const uint32_t w = uint32_t(v); __builtin_memcpy(d, &w, 4); d += 4; v >>= 32; }
+    if (n & 2u) { const uint16_t w = uint16_t(v); __builtin_memcpy(d, &w, 2); d += 2; v >>= 16; }
+    if (n & 1u) *d = uint8_t(v);
+}
+
 // Do most of the lanes that are still decoding say yes?  (On the CPU a lane is asked alone.)  The answer only decides
 // in which order the lanes of a wave get their turns, never what they decode.
 FQD_HD bool most_lanes(bool mine)
@@ -279,6 +309,22 @@ FQD_HD void decode_range(const S& sh, Bits& in, uint32_t from, uint32_t stop, ui
     in.seek(from);
     uint32_t bytes = 0, matches = 0, fl = 0, burst = 0;
     const uint32_t limit = stop < total_bits ? stop : total_bits;
+    // kWrite: literals wait in a register until there are eight of them — one store instead of eight
+    uint64_t acc = 0;
+    uint32_t waiting = 0;                                             // bytes in acc: out[pos - waiting, pos)
+    auto put = [&](uint32_t lits, uint32_t n) {                       // n <= 3 literals, the first one lowest
+        acc |= uint64_t(lits) << (8u * waiting);
+        waiting += n; pos += n;
+        if (waiting >= 8u) {
+            if (pos - waiting + 8u <= out_len) store8(out + (pos - waiting), acc);
+            waiting -= 8u;
+            acc = waiting ? uint64_t(lits) >> (8u * (n - waiting)) : 0ull;
+        }
+    };
+    auto flush = [&]() {
+        if (waiting && pos <= out_len) store_low(out + (pos - waiting), acc, waiting);
+        waiting = 0; acc = 0;
+    };
     // A turn of this loop costs every lane of the wave every branch some lane takes, and literals are most of what
     // a FASTQ stream holds: while most lanes have a literal next, a turn is the literal's few instructions only and
     // the lanes that have a length code next wait (kBurst turns at most).
@@ -292,16 +338,7 @@ FQD_HD void decode_range(const S& sh, Bits& in, uint32_t from, uint32_t stop, ui
         const bool literal = n != 0u;
         if (literal) {
             in.skip(len);
-            if (kWrite) {
-                if (pos + 3u <= out_len) {
-                    out[pos] = uint8_t(sym);
-                    if (n > 1u) out[pos + 1u] = uint8_t(sym >> 8);
-                    if (n > 2u) out[pos + 2u] = uint8_t(sym >> 16);
-                } else {
-                    for (uint32_t k = 0; k < n; ++k) if (pos + k < out_len) out[pos + k] = uint8_t(sym >> (8u * k));
-                }
-                pos += n;
-            }
+            if (kWrite) put(sym, n);
             bytes += n;
         }
         if (most_lanes(literal) && ++burst < kBurst) continue;
@@ -313,7 +350,7 @@ FQD_HD void decode_range(const S& sh, Bits& in, uint32_t from, uint32_t stop, ui
         }
         in.skip(len);
         if (sym < 256u) {                                             // (a literal with a code longer than the table's index)
-            if (kWrite) { if (pos < out_len) out[pos] = uint8_t(sym); ++pos; }
+            if (kWrite) put(sym, 1u);
             ++bytes;
             continue;
         }
@@ -334,24 +371,16 @@ FQD_HD void decode_range(const S& sh, Bits& in, uint32_t from, uint32_t stop, ui
         uint32_t dist = dist_base(dsym, eb);
         dist += in.take(eb);
         if (kWrite) {
+            flush();
             if (tk < kTokenRoom) { tok[tk].dst = pos; tok[tk].len_dist = (length << 16) | dist; }
             ++tk;
             pos += length;
         }
         bytes += length; ++matches;
     }
+    if (kWrite) flush();
     if (!(fl & kEndOfBlock) && in.at < stop) fl |= kBroken | kOffTheEnd;       // the member ends inside a block
     end = in.at; nbytes = bytes; ntok = matches; flags = fl;
-}
-
-FQD_HD uint64_t load8(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }      // (any alignment)
-FQD_HD void store8(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
-
-FQD_HD void store_low(uint8_t* d, uint64_t v, uint32_t n)                       // the low n < 8 bytes of v
-{
-    if (n & 4u) { const uint32_t w = uint32_t(v); __builtin_memcpy(d, &w, 4); d += 4; v >>= 32; }
-    if (n & 2u) { const uint16_t w = uint16_t(v); __builtin_memcpy(d, &w, 2); d += 2; v >>= 16; }
-    if (n & 1u) *d = uint8_t(v);
 }
 
 // The first `dist` < 8 bytes at s, repeated to fill a register.

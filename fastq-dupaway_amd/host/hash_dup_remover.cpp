@@ -1005,7 +1005,7 @@ static bool inflate_on_device()
 
 // false: not such a file (nothing is reported; the caller reads it the host way).
 // `into` given: the members are inflated into into->text batch by batch WHILE the file is still being read (a batch =
-// enough members to fill the chip, one thread each: fqd_bgzf_inflate_async on a small engine of this thread's own), and
+// a few rounds of the chip's waves, one member each: fqd_bgzf_inflate_async on a small engine of this thread's own), and
 // the room for the text — sized from the file's size before anything is known about its members, regrown if that was
 // too little — is allocated by a helper thread under the first reads: on a device whose free memory another process
 // has just given back, hipMalloc clears tens of gigabytes of pages and takes seconds (0.36 - 3.07 s of
@@ -1025,7 +1025,7 @@ static bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, 
     // ---- inflate under the read ---------------------------------------------------------------------------------
     static const bool overlap = [] { const char* v = std::getenv("FQD_INFLATE_OVERLAP"); return !v || std::atoi(v) != 0; }();
     const bool inflating = into != nullptr && overlap;
-    constexpr uint64_t kBatchMembers = 256u * 6u * 64u;       // what the chip holds at one thread per member
+    constexpr uint64_t kBatchMembers = 32768;                 // eight rounds of the chip's 4096 waves, one member each: 2 GB of text, ~10 ms
     std::unique_ptr<EngineHandle> codec;                      // this thread's engine: scratch and stream of the inflate launches
     hipStream_t codec_stream = nullptr;
     struct CodecGuard { hipStream_t& s; std::unique_ptr<EngineHandle>& e; ~CodecGuard() { e.reset(); if (s) (void)hipStreamDestroy(s); } } cg{codec_stream, codec};

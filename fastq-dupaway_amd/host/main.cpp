@@ -7,6 +7,7 @@
 // full inner join for --unordered instead of the reference's end-of-file rule),
 // FQD_BLOCK_MB=<input block size>, FQD_DEVICES=<ordinal,ordinal,...> (one engine per listed GPU, reads
 // sharded by hash prefix with an RCCL all-to-all; FQD_EXCHANGE=copy: peer copies instead).
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -214,6 +215,17 @@ bool parse_args(int argc, char** argv, Options& opts)          // main.cpp:40-17
 
 int main(int argc, char** argv)                                // main.cpp:181-262
 {
+    // FQD_HOST_TIMING: where the wall time of the process goes that no stage of the run accounts for — before main
+    // (the loader, the HIP runtime's own start) is what the caller's clock saw and these two lines did not
+    const auto t_main = std::chrono::steady_clock::now();
+    struct AtEnd {
+        std::chrono::steady_clock::time_point t0;
+        ~AtEnd() {
+            if (std::getenv("FQD_HOST_TIMING"))
+                std::cerr << "[host timing] process: main() took " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()
+                          << " s (what follows it: the runtime and the driver giving the device memory back)\n";
+        }
+    } at_end{t_main};
     Options opts;
     if (!parse_args(argc, argv, opts)) return 1;
     try {

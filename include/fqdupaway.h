@@ -371,7 +371,7 @@ int  fqd_bgzf_deflate(fqd_engine* e, const uint8_t* src, uint64_t n, uint32_t li
 
 /* BGZF input inflated in HBM: member m (m < n_members; all arrays device) is the raw deflate stream of comp_len[m]
  * bytes at comp + comp_off[m] and inflates to exactly out_len[m] (<= 65536) bytes at text + out_off[m] whose CRC-32
- * is crc[m] — what the host read off the member's header and trailer.  One GPU thread per member.  *n_bad (host) =
+ * is crc[m] — what the host read off the member's header and trailer.  One wave per member.  *n_bad (host) =
  * members whose stream is damaged, ends early or late, or whose CRC differs; text is then to be discarded.
  * Replaces the gzip decompressor the reference pushes onto its input stream (file_utils.hpp:58-69). */
 int  fqd_bgzf_inflate(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* comp_len,

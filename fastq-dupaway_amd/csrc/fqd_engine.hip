@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -112,7 +113,15 @@ int reserve(fqd_engine* e, DevBuf& b, size_t bytes, size_t used = 0)
     size_t want = std::max(bytes, b.cap + b.cap / 2);
     want = (want + 255) & ~size_t(255);
     void* np = nullptr;
+    // FQD_ENGINE_TIMING: allocations that took long, to stderr (a hipMalloc waits while the driver clears pages another
+    // process has just given back — seconds for tens of gigabytes)
+    static const bool timing = std::getenv("FQD_ENGINE_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(e, hipMalloc(&np, want));
+    if (timing) {
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (dt > 0.005) std::fprintf(stderr, "[engine timing] hipMalloc of %.1f MB took %.3f s\n", double(want) / 1e6, dt);
+    }
     if (used && b.p) {
         hipError_t err = hipMemcpyAsync(np, b.p, used, hipMemcpyDeviceToDevice, e->stream);
         if (err != hipSuccess) { (void)hipFree(np); return e->fail_hip("hipMemcpyAsync(grow)", err); }

@@ -59,6 +59,22 @@ inline uint32_t grid_for(uint64_t n, uint32_t per_block = kBlock, uint32_t cap =
 // starts after the first '.' of the ID line (searched over the whole line, newline included), or
 // after the leading '@' / '>' when there is none, and ends before the first ' ' at or after its
 // start, or else runs through the end of the line INCLUDING the newline.
+// First k in [from, L) with p[k] == c, else L: eight bytes per load while eight are left (one thread reads one ID line;
+// byte by byte that is one scattered load instruction per byte of the line for the wave).
+__device__ __forceinline__ uint32_t first_byte(const uint8_t* __restrict__ p, uint32_t from, uint32_t L, uint8_t c)
+{
+    const uint64_t ones = 0x0101010101010101ull, pattern = ones * c;
+    uint32_t k = from;
+    for (; k + 8u <= L; k += 8u) {
+        uint64_t v;
+        __builtin_memcpy(&v, p + k, 8);
+        const uint64_t x = v ^ pattern, hit = (x - ones) & ~x & (ones << 7);       // the lowest set bit marks the first equal byte
+        if (hit) return k + uint32_t(__builtin_ctzll(hit)) / 8u;
+    }
+    for (; k < L; ++k) if (p[k] == c) return k;
+    return L;
+}
+
 __global__ __launch_bounds__(kBlock)
 void extract_tags_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ id_start,
                          const uint32_t* __restrict__ id_len, uint64_t n,
@@ -68,11 +84,9 @@ void extract_tags_kernel(const uint8_t* __restrict__ text, const uint64_t* __res
         const uint64_t s = id_start[i];
         const uint32_t L = id_len[i];
         const uint8_t* __restrict__ p = text + s;
-        uint32_t dot = L;
-        for (uint32_t k = 0; k < L; ++k) if (p[k] == uint8_t('.')) { dot = k; break; }
+        const uint32_t dot = first_byte(p, 0, L, uint8_t('.'));
         const uint32_t from = dot < L ? dot + 1u : (L ? 1u : 0u);
-        uint32_t to = L;
-        for (uint32_t k = from; k < L; ++k) if (p[k] == uint8_t(' ')) { to = k; break; }
+        const uint32_t to = first_byte(p, from, L, uint8_t(' '));
         tag_off[i] = s + from;
         tag_len[i] = to > from ? to - from : 0u;
     }
@@ -613,18 +627,32 @@ void gather_seq_kernel(const uint32_t* __restrict__ idx, uint64_t n, const uint6
 // and the dedup need of every record — its tag and its sequence — is copied out of the uploaded block
 // into stores that stay in HBM, and where every surviving record goes in the output is computed here.
 
-// dst[dst_off[i] .. +len[i]) = src[src_off[i] .. +len[i]): 8 bytes at a time where both sides allow.
+// dst[dst_off[i] .. +len[i]) = src[src_off[i] .. +len[i]).  EIGHT LANES per span, sixteen bytes each, side by side: a
+// record is a few hundred bytes, and a lane that copies one alone asks for a line of its own with every load and store
+// (64 requests per instruction to the CU's one address unit; tools/vmem_probe.hip) — 277 GB/s; eight lanes per record
+// ask for two or three lines between them.  The last sixteen bytes are copied again if the length is no multiple of
+// sixteen (same bytes, same place); a span shorter than sixteen goes byte by byte.
+constexpr uint32_t kSpanLanes = 8;
 __global__ __launch_bounds__(kBlock)
 void copy_spans_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ len,
                        uint64_t n, uint8_t* __restrict__ dst, const uint64_t* __restrict__ dst_off)
 {
-    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
+    const uint32_t l = threadIdx.x % kSpanLanes;
+    for (uint64_t i = (blockIdx.x * uint64_t(kBlock) + threadIdx.x) / kSpanLanes; i < n; i += uint64_t(gridDim.x) * (kBlock / kSpanLanes)) {
         const uint8_t* __restrict__ a = src + src_off[i];
         uint8_t* __restrict__ b = dst + dst_off[i];
         const uint32_t L = len[i];
-        uint32_t k = 0;
-        for (; k + 8u <= L; k += 8u) { uint64_t w; __builtin_memcpy(&w, a + k, 8); __builtin_memcpy(b + k, &w, 8); }
-        for (; k < L; ++k) b[k] = a[k];
+        if (L < 16u) { for (uint32_t k = l; k < L; k += kSpanLanes) b[k] = a[k]; continue; }
+        for (uint32_t k = 16u * l; k + 16u <= L; k += 16u * kSpanLanes) {
+            uint64_t w[2];
+            __builtin_memcpy(w, a + k, 16);
+            __builtin_memcpy(b + k, w, 16);
+        }
+        if ((L & 15u) && l == ((L / 16u) % kSpanLanes)) {              // (the lane whose turn the next chunk would have been)
+            uint64_t w[2];
+            __builtin_memcpy(w, a + L - 16u, 16);
+            __builtin_memcpy(b + L - 16u, w, 16);
+        }
     }
 }
 
@@ -1035,7 +1063,7 @@ int fqd_copy_spans(fqd_engine* e, const uint8_t* src, const uint64_t* src_off, c
     if (n && (!src || !src_off || !len || !dst || !dst_off)) return fqd_internal_fail(e, FQD_ERR_ARG, "fqd_copy_spans: bad arguments");
     if (n == 0) return FQD_OK;
     JOIN_TRY(e, hipSetDevice(fqd_internal_device(e)));
-    hipLaunchKernelGGL(copy_spans_kernel, dim3(grid_for(n, kBlock, 4096)), dim3(kBlock), 0, fqd_internal_stream(e), src, src_off, len, n, dst, dst_off);
+    hipLaunchKernelGGL(copy_spans_kernel, dim3(grid_for(n * kSpanLanes, kBlock, 8192)), dim3(kBlock), 0, fqd_internal_stream(e), src, src_off, len, n, dst, dst_off);
     JOIN_TRY(e, hipGetLastError());
     return FQD_OK;
 }

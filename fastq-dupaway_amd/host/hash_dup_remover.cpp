@@ -1212,7 +1212,7 @@ static bool deflate_on_device()
 struct SurvivorBuffers {
     struct PerFile {
         Device<uint64_t> src_off, dst_off; Device<uint32_t> len; uint64_t total = 0;
-        Pinned<char> buf[2]; Device<char> d_win, d_members;
+        Pinned<char> buf[2]; Device<char> d_win[2], d_members[2];      // a slot = pinned buffer k + the device buffers k
         bool on_device = false;                       // .gz: windows leave the device as finished BGZF members
     } f[2];
     uint64_t window = 0, roomy = 0;
@@ -1234,9 +1234,11 @@ static void plan_survivors(fqd_engine* e, int S, FileOnDevice* const* file, cons
         // every buffer is sized once, for the largest window the writer lets through (a single record larger than that is the
         // one case that grows them later): a window a little larger than all before it must not cost a new pinned allocation
         const uint64_t room = std::min<uint64_t>(b.roomy, std::max<uint64_t>(o.total, 1));
-        o.d_win.reserve(room + 64);
-        for (int k = 0; k < 2; ++k) o.buf[k].reserve((o.on_device ? std::max<uint64_t>(room / 2, 1u << 20) : room) + 64);
-        if (o.on_device) o.d_members.reserve(fqd_bgzf_bound(room));
+        for (int k = 0; k < 2; ++k) {
+            o.d_win[k].reserve(room + 64);
+            o.buf[k].reserve((o.on_device ? std::max<uint64_t>(room / 2, 1u << 20) : room) + 64);
+            if (o.on_device) o.d_members[k].reserve(fqd_bgzf_bound(room));
+        }
     }
     b.planned = true;
 }
@@ -1257,14 +1259,28 @@ static void write_survivors(fqd_engine* e, hipStream_t stream, int S, FileOnDevi
     const uint32_t lines_per_record = format == Format::Fastq ? 4u : 2u;
     struct Out {
         Device<uint64_t>& src_off; Device<uint64_t>& dst_off; Device<uint32_t>& len; uint64_t total;
-        Pinned<char>* buf; Device<char>& d_win; Device<char>& d_members;
+        Pinned<char>* buf; Device<char>* d_win; Device<char>* d_members;
         Channel<int> free_bufs, full_bufs; int slot_id[2] = {0, 1}; size_t bytes[2] = {0, 0};
+        hipEvent_t copied[2] = {nullptr, nullptr};        // the slot's window has reached its pinned buffer
         bool on_device = false;
         std::thread writer; std::exception_ptr error;
         explicit Out(SurvivorBuffers::PerFile& p) : src_off(p.src_off), dst_off(p.dst_off), len(p.len), total(p.total), buf(p.buf), d_win(p.d_win), d_members(p.d_members), on_device(p.on_device) {}
     };
     Out o[2] = {Out(planned->f[0]), Out(planned->f[1])};
     static int kStop = -1;
+    // A window leaves the device on a stream of its own while the kernels of the next one run: the writer thread waits
+    // for the copy, not this loop.  (A slot's device buffers are free again when its pinned buffer is: the writer gives
+    // the slot back after it has written it.)
+    hipStream_t down = nullptr;
+    hipEvent_t made = nullptr;
+    HIP_OK(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&made, hipEventDisableTiming));
+    for (int s = 0; s < S; ++s) for (int k = 0; k < 2; ++k) HIP_OK(hipEventCreateWithFlags(&o[s].copied[k], hipEventDisableTiming));
+    struct DownGuard { hipStream_t& d; hipEvent_t& m; Out* o; ~DownGuard() {
+        if (d) { (void)hipStreamSynchronize(d); (void)hipStreamDestroy(d); }
+        if (m) (void)hipEventDestroy(m);
+        for (int s = 0; s < 2; ++s) for (int k = 0; k < 2; ++k) if (o[s].copied[k]) (void)hipEventDestroy(o[s].copied[k]);
+    } } down_guard{down, made, o};
     for (int s = 0; s < S; ++s) {
         o[s].free_bufs.push(&o[s].slot_id[0]); o[s].free_bufs.push(&o[s].slot_id[1]);
         o[s].writer = std::thread([&, s] {
@@ -1272,6 +1288,8 @@ static void write_survivors(fqd_engine* e, hipStream_t stream, int S, FileOnDevi
                 int* id = o[s].full_bufs.pop();
                 if (*id < 0) break;
                 try {
+                    { StageClock::Scope t("  survivors: writer waits for the window's copy"); HIP_OK(hipEventSynchronize(o[s].copied[*id])); }
+                    StageClock::Scope t("  survivors: writer writes");
                     if (!o[s].error) {
                         if (o[s].on_device) sinks[s]->write_members(o[s].buf[*id].p, o[s].bytes[*id], write_threads());
                         else if (sinks[s]->is_gz()) sinks[s]->write_borrowed(o[s].buf[*id].p, o[s].bytes[*id]);
@@ -1313,27 +1331,33 @@ static void write_survivors(fqd_engine* e, hipStream_t stream, int S, FileOnDevi
                 }
                 const uint64_t bytes = hi - lo;
                 if (bytes) {
-                    int* id = o[s].free_bufs.pop();
+                    int* id = nullptr;
+                    { StageClock::Scope t("  survivors: the device waits for a free buffer"); id = o[s].free_bufs.pop(); }
+                    StageClock::Scope t("  survivors: windows made on the device");
                     // every buffer is sized once, for the largest window the loop above lets through: a window a little
                     // larger than all before it must not cost a new pinned allocation (tens of milliseconds each)
                     const uint64_t room = std::max(bytes, std::min<uint64_t>(roomy, o[s].total));      // (a small output: what it needs)
-                    o[s].d_win.reserve(room + 64);
+                    Device<char>& d_win = o[s].d_win[*id];
+                    d_win.reserve(room + 64);
                     o[s].buf[*id].reserve((o[s].on_device ? std::max<uint64_t>(room / 2, 1u << 20) : room) + 64);
                     // dst_off is absolute in the output: the window's buffer starts `lo` bytes in
                     engine_ok(fqd_copy_spans(e, reinterpret_cast<const uint8_t*>(file[s]->text.p), o[s].src_off.p + at[s], o[s].len.p + at[s], take,
-                                             reinterpret_cast<uint8_t*>(o[s].d_win.p) - lo, o[s].dst_off.p + at[s]));
+                                             reinterpret_cast<uint8_t*>(d_win.p) - lo, o[s].dst_off.p + at[s]));
                     uint64_t out_bytes = bytes;
-                    const char* from = o[s].d_win.p;
+                    const char* from = d_win.p;
                     if (o[s].on_device) {
+                        Device<char>& d_members = o[s].d_members[*id];
                         const uint64_t cap = fqd_bgzf_bound(room);
-                        o[s].d_members.reserve(cap);
-                        engine_ok(fqd_bgzf_deflate(e, reinterpret_cast<const uint8_t*>(o[s].d_win.p), bytes, lines_per_record,
-                                                   reinterpret_cast<uint8_t*>(o[s].d_members.p), cap, &out_bytes));
-                        from = o[s].d_members.p;
+                        d_members.reserve(cap);
+                        engine_ok(fqd_bgzf_deflate(e, reinterpret_cast<const uint8_t*>(d_win.p), bytes, lines_per_record,
+                                                   reinterpret_cast<uint8_t*>(d_members.p), cap, &out_bytes));
+                        from = d_members.p;
                         o[s].buf[*id].reserve(out_bytes + 64);           // (text that does not shrink to half)
                     }
-                    HIP_OK(hipMemcpyAsync(o[s].buf[*id].p, from, out_bytes, hipMemcpyDeviceToHost, stream));
-                    HIP_OK(hipStreamSynchronize(stream));
+                    HIP_OK(hipEventRecord(made, stream));
+                    HIP_OK(hipStreamWaitEvent(down, made, 0));
+                    HIP_OK(hipMemcpyAsync(o[s].buf[*id].p, from, out_bytes, hipMemcpyDeviceToHost, down));
+                    HIP_OK(hipEventRecord(o[s].copied[*id], down));
                     o[s].bytes[*id] = out_bytes;
                     o[s].full_bufs.push(id);
                 }

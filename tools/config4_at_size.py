@@ -114,7 +114,7 @@ def main():
         f"{outs[0].stat().st_size / 1e9:.2f} + {outs[1].stat().st_size / 1e9:.2f} GB)")
     print(r.stdout, end="")
     for line in r.stderr.splitlines():
-        if "unordered" in line or "on the GPU" in line or "process:" in line or "error" in line.lower():
+        if any(w in line for w in ("unordered", "on the GPU", "process:", "survivors", "engine timing")) or "error" in line.lower():
             print(line)
     ok = r.returncode == 0 and r.stdout == (f"{n} valid read pairs processed, out of which {dups} duplicates were removed.\n"
                                              f"0 Non-matching entries from both files were skipped.\n")
@@ -130,7 +130,7 @@ def main():
         t1 = time.perf_counter()
         r2 = subprocess.run(wrap + cmd, capture_output=True, text=True, cwd=str(d), env=env)
         dt2 = time.perf_counter() - t1
-        stages = "; ".join(" ".join(l.split("] ", 1)[1].split("  (")[0].split()) for l in r2.stderr.splitlines() if "unordered" in l or "on the GPU" in l or "process:" in l)
+        stages = "; ".join(" ".join(l.split("] ", 1)[1].split("  (")[0].split()) for l in r2.stderr.splitlines() if any(w in l for w in ("unordered", "on the GPU", "process:", "survivors", "engine timing")))
         log(f"also [{extra}]: rc={r2.returncode} {dt2:.1f} s = {n / dt2 / 1e6:.3f} M pairs/s, same -v lines: {r2.stdout == r.stdout} | {stages}")
         ok &= r2.returncode == 0 and r2.stdout == r.stdout
     # outputs: ids of every record, in order

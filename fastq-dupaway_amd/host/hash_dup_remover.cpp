@@ -245,7 +245,7 @@ namespace {
 // the order the batches are handed over.
 unsigned write_threads()
 {
-    static const unsigned t = [] { const char* v = std::getenv("FQD_WRITE_THREADS"); const int x = v ? std::atoi(v) : 0; return x > 0 ? unsigned(x) : std::min(4u, host_threads()); }();
+    static const unsigned t = [] { const char* v = std::getenv("FQD_WRITE_THREADS"); const int x = v ? std::atoi(v) : 0; return x > 0 ? unsigned(x) : std::min(8u, host_threads()); }();
     return t;
 }
 

@@ -175,7 +175,25 @@ size_t InputFile::read_bgzf(char* dst, size_t n, unsigned threads)
         for (;;) {
             Member m{};
             const int r = member_at(at, m);
-            if (r < 0) throw std::runtime_error("gzip input is corrupt or truncated");
+            if (r < 0) {
+                // A gzip member that is no BGZF member, after some that were (files put together with `cat`): the
+                // reference's gzip_decompressor reads members of any kind one after the other (file_utils.hpp:58-69),
+                // so from here on the stream goes through zlib, which does the same.  Anything else is damage.
+                const unsigned char* q = comp_.data() + at;
+                size_t ignored = 0;
+                const bool plain_member = comp_.size() - at >= 18 && q[0] == 31 && q[1] == 139 && q[2] == 8 &&
+                                          bgzf_member_size(q, comp_.size() - at, &ignored) == 0;
+                if (!plain_member) throw std::runtime_error("gzip input is corrupt or truncated");
+                if (!batch.empty()) break;                       // first what came before it
+                const uint64_t file_at = offset_ - (comp_.size() - at);
+                if (::lseek(fd_, static_cast<off_t>(file_at), SEEK_SET) < 0) throw std::runtime_error("gzip input is corrupt or truncated");
+                g_ = gzdopen(fd_, "rb");
+                if (!g_) throw std::runtime_error("gzip input is corrupt or truncated");
+                fd_ = -1;                                          // (the stream owns the descriptor now)
+                gzbuffer(g_, 4u << 20);
+                bgzf_ = false; comp_.clear(); comp_pos_ = 0;
+                return got + read(dst + got, n - got, threads);
+            }
             if (r == 1) {
                 batch.push_back(m); out_bytes += m.isize; at += m.total;
                 if (out_bytes >= n - got || batch.size() >= 4096) break;

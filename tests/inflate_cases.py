@@ -46,5 +46,10 @@ def cases():
     periods = b"".join(bytes(range(65, 65 + k)) * (n // k) + b"\n" for k in (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 31, 32, 33) for n in (3, 7, 8, 9, 15, 16, 17, 40, 64, 150, 258, 259, 1000))
     yield "short_periods", periods, bgzf(periods)
     yield "short_periods_level1", periods, bgzf(periods, level=1)
+    import random
+    rnd3 = random.Random(3)
+    words = [bytes([97 + i, 97 + j, 97 + k]) for i in range(3) for j in range(3) for k in range(3)][:8]
+    dense = b"".join(rnd3.choice(words) for _ in range(120_000))            # ten thousand three-byte matches per member:
+    yield "more_matches_than_a_window_holds", dense, bgzf(dense, level=1)    # windows of the wave decoder are cut short
     yield "one_byte", b"x", bgzf(b"x")
     yield "empty_members_between", fq[:70_000], member(fq[:30_000]) + member(b"") + member(fq[30_000:70_000]) + EOF_MARK

@@ -430,7 +430,7 @@ def test_unordered_gz_outputs_deflated_on_the_device(exe, oracle, tmp_path, case
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["fastq", "fasta", "stored_and_fixed_blocks", "flipped_bit", "bad_record", "no_final_newline",
-                                  "plain_gzip", "truncated"])
+                                  "plain_gzip", "truncated", "plain_member_inside"])
 def test_unordered_bgzf_inputs_inflated_on_the_device(exe, oracle, tmp_path, case):
     """BGZF inputs of the resident --unordered run are inflated and cut into records on the GPU
     (fqd_bgzf_inflate, fqd_scan_records); anything but a well-formed BGZF file of whole records is read the
@@ -464,6 +464,9 @@ def test_unordered_bgzf_inputs_inflated_on_the_device(exe, oracle, tmp_path, cas
         z2 = z2[: len(z2) * 2 // 3]
     if case == "plain_gzip":
         z2 = gzip.compress(t2, 1)
+    if case == "plain_member_inside":                        # `cat blocked.gz ordinary.gz blocked.gz`: the host reads it on, as the reference's decompressor does
+        third = len(t2) // 3
+        z2 = bgzf(t2[:third])[:-len(EOF_MARK)] + gzip.compress(t2[third:2 * third], 6) + bgzf(t2[2 * third:])
     ext = "fa" if fasta else "fq"
     f1, f2 = tmp_path / f"r1.{ext}.gz", tmp_path / f"r2.{ext}.gz"
     f1.write_bytes(z1); f2.write_bytes(z2)
@@ -479,7 +482,7 @@ def test_unordered_bgzf_inputs_inflated_on_the_device(exe, oracle, tmp_path, cas
             assert ("inflate + record scan on the GPU" in r.stderr) == (gunzip == "1"), r.stderr    # file 1 is always good BGZF
     assert runs["1"] == runs["0"]
     rc, out, said, b1, b2 = runs["1"]
-    if case in ("fastq", "fasta", "stored_and_fixed_blocks", "plain_gzip"):
+    if case in ("fastq", "fasta", "stored_and_fixed_blocks", "plain_gzip", "plain_member_inside"):
         p1, p2 = tmp_path / f"p1.{ext}", tmp_path / f"p2.{ext}"
         p1.write_bytes(t1); p2.write_bytes(t2)
         e1, e2 = tmp_path / f"e1.{ext}", tmp_path / f"e2.{ext}"

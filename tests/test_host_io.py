@@ -113,3 +113,25 @@ def test_finished_members_are_passed_through(build, tmp_path, threads):
     run("m", src, out, threads)
     assert subprocess.run(["gzip", "-t", str(out)]).returncode == 0
     assert gzip.open(out, "rb").read() == b"@before\n" + body + b"@after\n"
+
+
+def test_plain_members_after_bgzf_members_are_read_on(io, tmp_path):
+    """`cat blocked.gz ordinary.gz blocked.gz`: the reference's gzip_decompressor reads members of any kind one after
+    the other (file_utils.hpp:58-69); the member-parallel reader hands the rest of such a file to zlib."""
+    (length, h), _ = io("w", tmp_path / "a.fq.gz", 700_001, 5)
+    a = (tmp_path / "a.fq.gz").read_bytes()
+    text_a = gzip.decompress(a)
+    middle = bytes(range(256)) * 3000
+    mixed = a[:-28] + gzip.compress(middle, 6) + a            # (the first copy without its end-of-file member, the second with it)
+    (tmp_path / "mixed.fq.gz").write_bytes(mixed)
+    want = text_a + middle + text_a
+    assert gzip.decompress(mixed) == want
+    for chunk, threads in [(1000, 1), (70_000, 4), (4_000_000, 8)]:
+        (l2, h2), _ = io("r", tmp_path / "mixed.fq.gz", chunk, threads)
+        assert (int(l2), int(h2)) == (len(want), fnv(want))
+    # damage inside the plain member is still damage
+    bad = bytearray(mixed)
+    bad[len(a) - 28 + 40] ^= 0x5A
+    (tmp_path / "bad.fq.gz").write_bytes(bad)
+    _, err = io("r", tmp_path / "bad.fq.gz", 1 << 20, 4, ok=False)
+    assert "corrupt or truncated" in err

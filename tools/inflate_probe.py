@@ -30,7 +30,9 @@ def main():
     ap.add_argument("--records", type=int, default=1_900_000)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--host-packed", action="store_true", help="also inflate the same text packed by the host codec (libdeflate / zlib level 1: many more matches)")
-    ap.add_argument("--quality", choices=["mixed", "flat"], default="mixed", help="flat: every quality 'I' (long runs, as the configs[4] generator writes)")
+    ap.add_argument("--quality", choices=["mixed", "flat", "binned"], default="mixed", help="flat: every quality 'I' (long runs, as the configs[4] generator writes); "
+                    "binned: nine in ten 'F', the rest ':', ',' or '#' (what current sequencers write)")
+    ap.add_argument("--gz-level", default="1", help="--host-packed: the level the host codec packs at (FQD_GZ_LEVEL; 6 is what bgzip uses)")
     a = ap.parse_args()
     import torch
     from fastq_dupaway_amd import Engine
@@ -47,6 +49,9 @@ def main():
     rec[:, 18 + L] = 10; rec[:, 19 + L] = ord("+"); rec[:, 20 + L] = 10
     if a.quality == "flat":
         rec[:, 21 + L:21 + 2 * L] = ord("I")
+    elif a.quality == "binned":
+        q = torch.tensor(list(b":,#"), dtype=torch.uint8, device=dev)[torch.randint(0, 3, (n, L), device=dev, generator=g)]
+        rec[:, 21 + L:21 + 2 * L] = torch.where(torch.rand((n, L), device=dev, generator=g) < 0.9, torch.full_like(q, ord("F")), q)
     else:
         rec[:, 21 + L:21 + 2 * L] = torch.tensor(list(b"FFFFFFFF:,#"), dtype=torch.uint8, device=dev)[torch.randint(0, 11, (n, L), device=dev, generator=g)]
     rec[:, 21 + 2 * L] = 10
@@ -73,7 +78,7 @@ def main():
             subprocess.run(["g++", "-O2", "-std=c++17", "-o", packer, str(ROOT / "tools" / "bgzf_pack.cpp"),
                             str(ROOT / "fastq-dupaway_amd" / "host" / "file_io.cpp"), "-lz", "-lpthread"], check=True)
             src.cpu().numpy().tofile(os.path.join(d, "t.fq"))
-            subprocess.run([packer, os.path.join(d, "t.fq"), os.path.join(d, "t.fq.gz")], check=True, env=dict(os.environ, FQD_GZ_LEVEL="1"))
+            subprocess.run([packer, os.path.join(d, "t.fq"), os.path.join(d, "t.fq.gz")], check=True, env=dict(os.environ, FQD_GZ_LEVEL=a.gz_level))
             raw = open(os.path.join(d, "t.fq.gz"), "rb").read()
             arrs, total = walk(raw)
             comp = torch.frombuffer(bytearray(raw + bytes(16)), dtype=torch.uint8).to(dev)

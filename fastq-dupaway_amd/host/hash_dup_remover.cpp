@@ -707,6 +707,15 @@ struct DeviceSide {
 struct JoinedPairs {
     Device<uint32_t> perm[2], match[2], pair[2];
     Device<uint8_t>  keep;
+    Device<uint64_t> seq_off[2]; Device<uint32_t> seq_len[2];     // the pairs' sequences in tag order (the dedup's input)
+    // Room for about `reads` records per file, made ahead of time (on a helper thread, under the reads of the inputs):
+    // these are gigabytes, and a hipMalloc that has to wait for the driver to clear pages costs the stage that meets it
+    // tenths of a second.  A guess that is too small costs what it always cost.
+    void prepare(uint64_t reads)
+    {
+        for (int s = 0; s < 2; ++s) { perm[s].reserve(reads); match[s].reserve(reads); pair[s].reserve(reads); seq_off[s].reserve(reads); seq_len[s].reserve(reads); }
+        keep.reserve(reads);
+    }
     uint64_t n_proc = 0;            // pairs the reference processes
     uint64_t unmatched = 0;
     uint64_t written_below = 0;     // pairs at or beyond this index are not written (unknown base)
@@ -748,7 +757,7 @@ void join_and_dedup(fqd_engine* e, hipStream_t stream, const DeviceSide (&side)[
     // arrays gathered on the device; batches are queued back to back, the host waits once
     StageClock::Scope t("unordered: pair dedup on the GPU");
     const uint64_t n_proc = jp.n_proc;
-    Device<uint64_t> d_off[2]; Device<uint32_t> d_len[2];
+    Device<uint64_t>* d_off = jp.seq_off; Device<uint32_t>* d_len = jp.seq_len;
     for (int s = 0; s < 2; ++s) {
         d_off[s].reserve(n_proc); d_len[s].reserve(n_proc);
         engine_ok(fqd_gather_seqs(e, jp.pair[s].p, n_proc, side[s].seq_off, side[s].seq_len, d_off[s].p, d_len[s].p));
@@ -1019,8 +1028,12 @@ static bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, 
     hipStream_t up = nullptr;
     HIP_OK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
     struct Guard { hipStream_t s; ~Guard() { (void)hipStreamDestroy(s); } } g{up};
-    Pinned<char> block;
-    block.reserve(block_bytes);
+    // two blocks: the copy of one to HBM runs under the read of the next (its event is waited for before the block is read into again)
+    Pinned<char> blocks[2];
+    hipEvent_t sent[2] = {nullptr, nullptr};
+    bool in_flight[2] = {false, false};
+    struct SentGuard { hipEvent_t* e; ~SentGuard() { for (int k = 0; k < 2; ++k) if (e[k]) (void)hipEventDestroy(e[k]); } } sent_guard{sent};
+    for (int k = 0; k < 2; ++k) { blocks[k].reserve(block_bytes); HIP_OK(hipEventCreateWithFlags(&sent[k], hipEventDisableTiming)); }
     c.bytes.reserve(size + 64);
     // ---- inflate under the read ---------------------------------------------------------------------------------
     static const bool overlap = [] { const char* v = std::getenv("FQD_INFLATE_OVERLAP"); return !v || std::atoi(v) != 0; }();
@@ -1079,11 +1092,14 @@ static bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, 
     };
     std::string tail;                          // bytes already read from `tail_at` on: a member may straddle two blocks
     uint64_t tail_at = 0, at = 0, member = 0;  // file offsets: of the tail, of the current block, of the member being parsed
-    for (;;) {
+    for (int turn = 0;; turn ^= 1) {
+        Pinned<char>& block = blocks[turn];
+        if (in_flight[turn]) { HIP_OK(hipEventSynchronize(sent[turn])); in_flight[turn] = false; }
         const size_t got = file.read(block.p, block_bytes, host_threads());
         if (got == 0) break;
-        if (at + got > size) return false;                             // the file grew under us
+        if (at + got > size) { (void)hipStreamSynchronize(up); return false; }     // the file grew under us
         HIP_OK(hipMemcpyAsync(c.bytes.p + at, block.p, got, hipMemcpyHostToDevice, up));
+        HIP_OK(hipEventRecord(sent[turn], up)); in_flight[turn] = true;
         auto fetch = [&](uint64_t from, size_t len, unsigned char* dst) {
             if (from + len > at + got) return false;
             for (size_t k = 0; k < len; ++k)
@@ -1108,8 +1124,7 @@ static bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, 
             }
             member += total;
         }
-        HIP_OK(hipStreamSynchronize(up));
-        if (!ok) { if (inflating) (void)hipStreamSynchronize(codec_stream); return false; }
+        if (!ok) { (void)hipStreamSynchronize(up); if (inflating) (void)hipStreamSynchronize(codec_stream); return false; }
         launch_batch(false);
         std::string keep;
         if (member < at + got) {
@@ -1120,6 +1135,7 @@ static bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, 
         tail.swap(keep); tail_at = member;
         at += got;
     }
+    HIP_OK(hipStreamSynchronize(up));                          // every byte of the file is in HBM
     const bool whole = at == size && member == size && c.text_bytes > 0;
     if (inflating) {
         if (whole) launch_batch(true);
@@ -1440,6 +1456,8 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
     HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
     const size_t block_bytes = std::max<size_t>(1u << 20, std::min<size_t>(tuning_.block_bytes, static_cast<size_t>(memlimit_ > 0 ? memlimit_ / 16 : tuning_.block_bytes)));
+    // a file fetched whole is read in larger pieces than the streaming run's blocks: the parallel read of a piece needs 16 MB per thread
+    const size_t fetch_bytes = std::max<size_t>(block_bytes, std::min<size_t>(64u << 20, static_cast<size_t>(memlimit_ > 0 ? memlimit_ / 16 : (64 << 20))));
     FileOnDevice dev[2];
     Device<uint8_t> keep;
     uint64_t n = 0, dups = 0;
@@ -1463,8 +1481,8 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
             StageClock::Scope t("ordered/resident: files to HBM");
             auto fetch = [&](int s) {
                 try {
-                    fetched[s] = has_gz_extension(in[s]) ? fetch_bgzf(in[s], block_bytes, tuning_.device, packed[s], &dev[s])
-                                                         : fetch_plain(in[s], block_bytes, tuning_.device, dev[s], plain_bytes[s]);
+                    fetched[s] = has_gz_extension(in[s]) ? fetch_bgzf(in[s], fetch_bytes, tuning_.device, packed[s], &dev[s])
+                                                         : fetch_plain(in[s], fetch_bytes, tuning_.device, dev[s], plain_bytes[s]);
                 } catch (const DeviceOutOfMemory&) { fetched[s] = false; }
                 catch (const DeviceError&) { fetched[s] = false; fetch_error[s] = std::current_exception(); }
                 catch (const std::exception&) { fetched[s] = false; }      // the host reader will say what is wrong with the file
@@ -1550,6 +1568,7 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{stream};
     // the engine — key store and table sized from the files' sizes — is made on a helper thread under the reads of the
     // inputs: its first use comes after them (guess_capacity)
+    JoinedPairs jp;                                           // (before `eng`: the helper thread makes room in it, and eng's destructor joins that thread first)
     struct LazyEngine {
         std::unique_ptr<EngineHandle> holder; std::thread maker; std::exception_ptr error;
         ~LazyEngine() { if (maker.joinable()) maker.join(); }
@@ -1558,13 +1577,20 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
     {
         uint64_t cap_reads = 0, cap_bases = 0;
         guess_capacity(2, in, cap_reads, cap_bases);
-        eng.maker = std::thread([this, &eng, stream, cap_reads, cap_bases] {
-            try { HIP_OK(hipSetDevice(tuning_.device)); StageClock::Scope t("  on the GPU: engine, key store, table (under the read)"); eng.holder = std::make_unique<EngineHandle>(2, tuning_.device, stream, cap_reads, cap_bases); }
+        eng.maker = std::thread([this, &eng, &jp, stream, cap_reads, cap_bases] {
+            try {
+                HIP_OK(hipSetDevice(tuning_.device));
+                StageClock::Scope t("  on the GPU: engine, key store, table, join arrays (under the read)");
+                eng.holder = std::make_unique<EngineHandle>(2, tuning_.device, stream, cap_reads, cap_bases);
+                if (cap_reads) jp.prepare(cap_reads);
+            }
             catch (...) { eng.error = std::current_exception(); }
         });
     }
     auto engine_ok = [&](int rc) { if (rc != FQD_OK) throw std::runtime_error(std::string("GPU engine: ") + fqd_last_error(eng.get())); };
     const size_t block_bytes = std::max<size_t>(1u << 20, std::min<size_t>(tuning_.block_bytes, static_cast<size_t>(memlimit_ > 0 ? memlimit_ / 16 : tuning_.block_bytes)));
+    // a file fetched whole is read in larger pieces than the streaming run's blocks: the parallel read of a piece needs 16 MB per thread
+    const size_t fetch_bytes = std::max<size_t>(block_bytes, std::min<size_t>(64u << 20, static_cast<size_t>(memlimit_ > 0 ? memlimit_ / 16 : (64 << 20))));
 
     FileOnDevice dev[2];
 
@@ -1622,8 +1648,8 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
         auto fetch_or_load = [&](int s) {
             if (inflate_on_device()) {
                 try {
-                    if (has_gz_extension(in[s])) on_device[s] = fetch_bgzf(in[s], block_bytes, tuning_.device, packed[s], &dev[s]);
-                    else plain_on_device[s] = fetch_plain(in[s], block_bytes, tuning_.device, dev[s], plain_bytes[s]);
+                    if (has_gz_extension(in[s])) on_device[s] = fetch_bgzf(in[s], fetch_bytes, tuning_.device, packed[s], &dev[s]);
+                    else plain_on_device[s] = fetch_plain(in[s], fetch_bytes, tuning_.device, dev[s], plain_bytes[s]);
                 }
                 catch (const DeviceOutOfMemory&) { err[s] = std::current_exception(); return; }   // rethrown below: the two-pass run takes over
                 catch (const std::exception&) { on_device[s] = plain_on_device[s] = false; }          // the host way will say what is wrong
@@ -1665,8 +1691,8 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
     // them (DeviceOutOfMemory) still hands the job to the two-pass run.  On disk nothing differs from the reference's
     // order — outputs opened after the sort phase, then the merge (hpp:265-266) — a bad base found by the dedup cuts the
     // output at the same pair either way.
-    JoinedPairs jp;
-    join_and_dedup(eng.get(), stream, side, tuning_.reference_tail_rule, jp);
+    fqd_engine* engine_now = eng.get();                        // (joins the helper thread: jp is ours from here on)
+    join_and_dedup(engine_now, stream, side, tuning_.reference_tail_rule, jp);
     const uint64_t n_proc = jp.n_proc, upto = std::min<uint64_t>(n_proc, jp.written_below);
     uint64_t dups = 0;
     {

@@ -55,7 +55,7 @@ enum : uint32_t { kEndOfBlock = 1u, kBroken = 2u, kOffTheEnd = 4u };
 struct Token { uint32_t dst; uint32_t len_dist; };      // len_dist = length << 16 | distance
 
 #if defined(FQD_WINF_STATS)                             // (the CPU harness counts what the phases did)
-struct Stats { unsigned long long blocks, windows, rounds, lane_decodes, symbols_hint, groups, group_rounds, tokens, cut; };
+struct Stats { unsigned long long blocks, windows, rounds, lane_decodes, symbols_hint, groups, group_rounds, tokens, cut, dep_one_periodic, dep_one_partial, dep_many; };
 inline Stats& stats() { static Stats s{}; return s; }
 #define FQD_WINF_COUNT(field, n) (stats().field += (n))
 #else
@@ -395,28 +395,37 @@ FQD_HD uint64_t period_of(const uint8_t* s, uint32_t dist)
 // What a copy costs is its memory instructions — every one of them is 64 separate requests to the CU's one address
 // unit, whatever the lanes ask for — and the trips to memory that must wait for each other.  So a SHORT match (fewer
 // than kLongMatch bytes) is one lane's work and reads all it may before it writes: three loads and three stores of
-// eight bytes at most.
+// eight bytes at most.  `per` = 0: a plain copy of len bytes from d - dist (dist >= len).  Otherwise the match
+// repeats its first `per` bytes, which lie at d - dist (right before d as the stream had it: dist == per; further
+// back when resolve_matches found where THOSE bytes were copied from).
 constexpr uint32_t kLongMatch = 24;
-FQD_HD void copy_short(uint8_t* d, uint32_t len, uint32_t dist)
+FQD_HD void copy_plain_short(uint8_t* d, const uint8_t* s, uint32_t len)       // len < kLongMatch, nothing read is written here
+{
+    if (len < 8u) {
+        uint64_t v = 0;
+        for (uint32_t i = 0; i < len; ++i) v |= uint64_t(s[i]) << (8u * i);
+        store_low(d, v, len);
+        return;
+    }
+    const uint32_t o2 = len - 8u < 8u ? len - 8u : 8u, o3 = len - 8u;
+    const uint64_t a = load8(s), b = load8(s + o2), c = load8(s + o3);
+    store8(d, a);
+    if (len > 8u) store8(d + o2, b);
+    if (len > 16u) store8(d + o3, c);
+}
+FQD_HD void copy_short(uint8_t* d, uint32_t len, uint32_t dist, uint32_t per)
 {
     const uint8_t* s = d - dist;
-    if (dist >= 8u && dist >= len) {                                            // nothing it reads is its own
-        if (len < 8u) { store_low(d, load8(s), len); return; }
-        const uint32_t o2 = len - 8u < 8u ? len - 8u : 8u, o3 = len - 8u;
-        const uint64_t a = load8(s), b = load8(s + o2), c = load8(s + o3);
-        store8(d, a);
-        if (len > 8u) store8(d + o2, b);
-        if (len > 16u) store8(d + o3, c);
+    if (per == 0u) { copy_plain_short(d, s, len); return; }
+    if (per >= 8u) {                                                            // its first period from where that lies, the rest from itself
+        copy_plain_short(d, s, per);
+        uint32_t k = per;
+        for (; k + 8u <= len; k += 8u) store8(d + k, load8(d + k - per));
+        if (k < len) { uint64_t v = 0; for (uint32_t i = 0; k + i < len; ++i) v |= uint64_t(d[k + i - per]) << (8u * i); store_low(d + k, v, len - k); }
         return;
     }
-    if (dist >= 8u) {                                                           // 8 <= dist < len: a chunk may read the one before
-        uint32_t k = 0;
-        for (; k + 8u <= len; k += 8u) store8(d + k, load8(s + k));
-        if (k < len) store_low(d + k, load8(s + k), len - k);
-        return;
-    }
-    const uint64_t pat = period_of(s, dist);
-    const uint32_t step = (8u / dist) * dist;                                   // a store advances by whole periods
+    const uint64_t pat = period_of(s, per);
+    const uint32_t step = (8u / per) * per;                                     // a store advances by whole periods
     uint32_t k = 0;
     for (; k + 8u <= len; k += step) store8(d + k, pat);
     if (k < len) store_low(d + k, pat, len - k);
@@ -425,25 +434,25 @@ FQD_HD void copy_short(uint8_t* d, uint32_t len, uint32_t dist)
 // A LONG match is the work of many lanes, sixteen bytes each, side by side (chunk i = bytes [16 i, 16 i + 16), the
 // last one moved back to end with the match): one trip to memory for the whole match, and requests that fall into
 // the same few lines.
-FQD_HD void copy_chunk(uint8_t* d, uint32_t len, uint32_t dist, uint32_t i)
+FQD_HD void copy_chunk(uint8_t* d, uint32_t len, uint32_t dist, uint32_t per, uint32_t i)
 {
     uint32_t o = 16u * i;
     if (o >= len) return;
     if (o + 16u > len) o = len - 16u;
     const uint8_t* s = d - dist;
     uint64_t a, b;
-    if (o + 16u <= dist) { a = load8(s + o); b = load8(s + o + 8u); }           // bytes that were there before the match
-    else if (dist < 8u) {                                                       // a short period: from a register
-        const uint64_t pat = load8(s);                                          // (len >= kLongMatch: these eight bytes are the member's)
-        uint32_t at = o % dist;
+    if (per == 0u || o + 16u <= per) { a = load8(s + o); b = load8(s + o + 8u); }      // bytes that were there before the match
+    else if (per < 8u) {                                                        // a short period: from a register
+        const uint64_t pat = period_of(s, per);
+        uint32_t at = o % per;
         a = b = 0;
-        for (uint32_t k = 0; k < 8u; ++k) { a |= ((pat >> (8u * at)) & 0xFFull) << (8u * k); at = at + 1u == dist ? 0u : at + 1u; }
-        for (uint32_t k = 0; k < 8u; ++k) { b |= ((pat >> (8u * at)) & 0xFFull) << (8u * k); at = at + 1u == dist ? 0u : at + 1u; }
+        for (uint32_t k = 0; k < 8u; ++k) { a |= ((pat >> (8u * at)) & 0xFFull) << (8u * k); at = at + 1u == per ? 0u : at + 1u; }
+        for (uint32_t k = 0; k < 8u; ++k) { b |= ((pat >> (8u * at)) & 0xFFull) << (8u * k); at = at + 1u == per ? 0u : at + 1u; }
     } else {                                                                    // the match runs into itself: byte by byte from its first period
-        uint32_t at = o % dist;
+        uint32_t at = o % per;
         a = b = 0;
-        for (uint32_t k = 0; k < 8u; ++k) { a |= uint64_t(s[at]) << (8u * k); at = at + 1u == dist ? 0u : at + 1u; }
-        for (uint32_t k = 0; k < 8u; ++k) { b |= uint64_t(s[at]) << (8u * k); at = at + 1u == dist ? 0u : at + 1u; }
+        for (uint32_t k = 0; k < 8u; ++k) { a |= uint64_t(s[at]) << (8u * k); at = at + 1u == per ? 0u : at + 1u; }
+        for (uint32_t k = 0; k < 8u; ++k) { b |= uint64_t(s[at]) << (8u * k); at = at + 1u == per ? 0u : at + 1u; }
     }
     store8(d + o, a); store8(d + o + 8u, b);
 }
@@ -460,20 +469,23 @@ FQD_HD bool resolve_matches(Ctx& ctx, S& sh, uint8_t* out, const Token* tok, uin
         ctx.lanes([&](uint32_t j) {
             if (j >= n) return;
             const Token t = tok[g0 + j];
-            sh.pl.tok_dst[j] = t.dst; sh.pl.tok_len[j] = t.len_dist >> 16; sh.pl.tok_dist[j] = t.len_dist & 0xFFFFu;
+            const uint32_t len = t.len_dist >> 16, dist = t.len_dist & 0xFFFFu;
+            sh.pl.tok_dst[j] = t.dst; sh.pl.tok_len[j] = len; sh.pl.tok_dist[j] = dist;
+            sh.pl.pre_bytes[j] = dist < len ? dist : 0u;                // its period, if it repeats itself (pre_bytes is free by now)
         });
         const uint64_t broken = ctx.ballot([&](uint32_t j) { return j < n && sh.pl.tok_dist[j] > sh.pl.tok_dst[j]; });
         if (broken) { fine = false; break; }                      // a distance that reaches before the member's first byte
         // Which earlier matches of the group a match must wait for — and, first, whether it must wait at all: a match
         // that reads nothing but what ONE earlier match of the group writes, and that match a plain copy from
         // further back, may as well read where that one reads (a line of qualities copied from the record before,
-        // which was copied from the record before it, ...: every one of them ends up reading the first).  The
-        // chains halve with every turn.
+        // which was copied from the record before it, ...: every one of them ends up reading the first; a run of
+        // one quality that starts with the last byte of such a copy takes that byte from where the copy took it).
+        // The chains halve with every turn.
         for (uint32_t turn = 0;; ++turn) {
             ctx.lanes([&](uint32_t j) {
                 if (j >= n) return;
-                const uint32_t dst = sh.pl.tok_dst[j], dist = sh.pl.tok_dist[j], src = dst - dist, len = sh.pl.tok_len[j];
-                const uint32_t rend = src + len < dst ? src + len : dst;          // the bytes read before any of its own: [src, rend)
+                const uint32_t dst = sh.pl.tok_dst[j], dist = sh.pl.tok_dist[j], src = dst - dist, len = sh.pl.tok_len[j], per = sh.pl.pre_bytes[j];
+                const uint32_t rend = src + (per ? per : len);                    // the bytes read that are not its own: [src, rend)
                 uint64_t dep = 0;
                 uint32_t further = dist;
                 if (j != 0u && rend > sh.pl.tok_dst[0]) {
@@ -485,10 +497,16 @@ FQD_HD bool resolve_matches(Ctx& ctx, S& sh, uint8_t* out, const Token* tok, uin
                     while (lo < hi) { const uint32_t mid = (lo + hi) / 2u; if (sh.pl.tok_dst[mid] >= rend) hi = mid; else lo = mid + 1u; }
                     const uint32_t b1 = lo;
                     if (b1 > a) dep = (b1 - a >= 64u ? ~0ull : ((1ull << (b1 - a)) - 1ull)) << a;
-                    if (b1 == a + 1u && turn < 7u && dist >= len) {
+                    if (b1 == a + 1u && turn < 7u) {
                         const uint32_t adst = sh.pl.tok_dst[a], alen = sh.pl.tok_len[a], adist = sh.pl.tok_dist[a];
-                        if (adist >= alen && adst <= src && src + len <= adst + alen) further = dist + adist;
+                        if (sh.pl.pre_bytes[a] == 0u && adst <= src && rend <= adst + alen) further = dist + adist;
                     }
+#if defined(FQD_WINF_STATS)                                                     // what a match still waits for, per turn
+                    if (b1 == a + 1u && further == dist) {
+                        const bool inside = sh.pl.tok_dst[a] <= src && rend <= sh.pl.tok_dst[a] + sh.pl.tok_len[a];
+                        if (inside) FQD_WINF_COUNT(dep_one_periodic, 1); else FQD_WINF_COUNT(dep_one_partial, 1);
+                    } else if (b1 > a + 1u) FQD_WINF_COUNT(dep_many, 1);
+#endif
                 }
                 sh.pl.dep_lo[j] = uint32_t(dep); sh.pl.dep_hi[j] = uint32_t(dep >> 32);
                 sh.pl.pre_tok[j] = further;
@@ -511,7 +529,7 @@ FQD_HD bool resolve_matches(Ctx& ctx, S& sh, uint8_t* out, const Token* tok, uin
             const uint64_t big = go & ctx.ballot([&](uint32_t j) { return j < n && sh.pl.tok_len[j] >= kLongMatch; });
             ctx.lanes_open([&](uint32_t j) {
                 if (!(((go & ~big) >> j) & 1ull)) return;
-                copy_short(out + sh.pl.tok_dst[j], sh.pl.tok_len[j], sh.pl.tok_dist[j]);
+                copy_short(out + sh.pl.tok_dst[j], sh.pl.tok_len[j], sh.pl.tok_dist[j], sh.pl.pre_bytes[j]);
             });
             // (matches that go in the same round neither read nor write each other's bytes: no need to wait in between)
             constexpr uint32_t kAtOnce = L >= 63u ? 3u : 1u, kPerMatch = L / kAtOnce;     // 17 chunks hold 258 bytes
@@ -526,7 +544,7 @@ FQD_HD bool resolve_matches(Ctx& ctx, S& sh, uint8_t* out, const Token* tok, uin
                     const uint32_t j = q == 0u ? t0 : q == 1u ? t1 : t2;
                     if (j >= 64u) return;
                     for (uint32_t i = k % kPerMatch; i < 17u; i += kPerMatch)
-                        copy_chunk(out + sh.pl.tok_dst[j], sh.pl.tok_len[j], sh.pl.tok_dist[j], i);
+                        copy_chunk(out + sh.pl.tok_dst[j], sh.pl.tok_len[j], sh.pl.tok_dist[j], sh.pl.pre_bytes[j], i);
                 });
             }
             ctx.sync();

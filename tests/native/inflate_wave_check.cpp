@@ -62,8 +62,8 @@ static int run(const std::vector<uint8_t>& in, size_t n, const char* out_name)
     std::printf("%llu %llu %llu\n", members, bad, bytes);
 #if defined(FQD_WINF_STATS)
     const Stats& s = stats();
-    std::fprintf(stderr, "blocks %llu windows %llu rounds %llu lane_decodes %llu | tokens %llu groups %llu group_rounds %llu cut %llu\n",
-                 s.blocks, s.windows, s.rounds, s.lane_decodes, s.tokens, s.groups, s.group_rounds, s.cut);
+    std::fprintf(stderr, "blocks %llu windows %llu rounds %llu lane_decodes %llu | tokens %llu groups %llu group_rounds %llu cut %llu | waits (per turn): one periodic %llu, one partly %llu, several %llu\n",
+                 s.blocks, s.windows, s.rounds, s.lane_decodes, s.tokens, s.groups, s.group_rounds, s.cut, s.dep_one_periodic, s.dep_one_partial, s.dep_many);
 #endif
     return 0;
 }

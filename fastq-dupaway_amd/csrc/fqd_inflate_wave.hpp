@@ -403,12 +403,15 @@ FQD_HD void copy_plain_short(uint8_t* d, const uint8_t* s, uint32_t len)       /
 {
     if (len < 8u) {
         uint64_t v = 0;
-        for (uint32_t i = 0; i < len; ++i) v |= uint64_t(s[i]) << (8u * i);
+        if (s + 8 <= d) v = load8(s);                                           // (eight bytes from s on are the member's: they end before d)
+        else for (uint32_t i = 0; i < len; ++i) v |= uint64_t(s[i]) << (8u * i);
         store_low(d, v, len);
         return;
     }
     const uint32_t o2 = len - 8u < 8u ? len - 8u : 8u, o3 = len - 8u;
-    const uint64_t a = load8(s), b = load8(s + o2), c = load8(s + o3);
+    const uint64_t a = load8(s), b = load8(s + o2);
+    uint64_t c = 0;
+    if (len > 16u) c = load8(s + o3);
     store8(d, a);
     if (len > 8u) store8(d + o2, b);
     if (len > 16u) store8(d + o3, c);

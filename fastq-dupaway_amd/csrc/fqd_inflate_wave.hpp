@@ -165,6 +165,10 @@ struct Bits {
             if (--have == 0u) fetch(next);
         }
     }
+    // Called by all lanes of a wave at the same turns: a lane that is running low fetches NOW, with the others, instead
+    // of alone a few turns later — one memory instruction for the wave every few turns instead of one per turn (some
+    // lane of 64 always is about to run dry).  The words still queued are fetched again with the rest.
+    FQD_HD void top_up() { if (have <= 2u) fetch(next); }
     FQD_HD uint32_t peek(uint32_t n) const { return uint32_t(buf) & ((1u << n) - 1u); }     // n <= 31
     FQD_HD void skip(uint32_t n) { buf >>= n; cnt -= n; at += n; }
     FQD_HD uint32_t take(uint32_t n) { const uint32_t v = peek(n); skip(n); return v; }
@@ -328,7 +332,9 @@ FQD_HD void decode_range(const S& sh, Bits& in, uint32_t from, uint32_t stop, ui
     // A turn of this loop costs every lane of the wave every branch some lane takes, and literals are most of what
     // a FASTQ stream holds: while most lanes have a literal next, a turn is the literal's few instructions only and
     // the lanes that have a length code next wait (kBurst turns at most).
+    uint32_t turn = 0;
     while (in.at < limit) {
+        if ((turn++ & 3u) == 0u) in.top_up();
         in.ensure();
         uint32_t e = sh.lit_lut[in.peek(kLitBits)], len = e & 15u, sym = e >> 8;
         uint32_t n = (e >> 4) & 3u;

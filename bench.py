@@ -348,6 +348,8 @@ def end_to_end(a, torch, bases, expect, L):
            "input_GBps": round(size_in / min(runs) / 1e9, 2),
            "what": f"fastq-dupaway -i in.fq -o out.fq --fast -v on {n} reads ({size_in / 1e9:.2f} GB FASTQ, 316 B/record), plain files on {d}, "
                    f"page cache warm (the input was just written), process start-up and output close included; best of 2 runs",
+           "size_note": (f"{n} of the workload's {a.reads} reads: the full size needs about 70 GB of scratch files and four more minutes "
+                         f"(python bench.py --e2e-reads {a.reads} [--e2e-dir DIR]; profiles/r03_bench_e2e_100m_reads.json is such a run)") if n < a.reads else "the workload's full size",
            "parity": "-v line and output size == closed form" if ok else f"MISMATCH rc={out.returncode} {out.stdout!r} {out.stderr[-300:]!r}"}
     # the same reads as a BGZF file in and a .gz file out: inflated, cut into records, deduplicated and deflated on the GPU
     try:

@@ -1,6 +1,6 @@
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(d["value"], d["ms_per_step"], d.get("step_ms_spread"), d["roofline"]["frac"], d["cpu_baseline"])
+print(d["value"], d["ms_per_step"], d.get("step_ms_spread"), d["roofline"]["frac"], d.get("cpu_baseline"))
 for k,v in d.items():
     if k.startswith("end_to_end"):
         print(k, {a:b for a,b in v.items() if not isinstance(b,(dict,list)) and a not in ("what","parity")})

@@ -53,3 +53,40 @@ def cases():
     yield "more_matches_than_a_window_holds", dense, bgzf(dense, level=1)    # windows of the wave decoder are cut short
     yield "one_byte", b"x", bgzf(b"x")
     yield "empty_members_between", fq[:70_000], member(fq[:30_000]) + member(b"") + member(fq[30_000:70_000]) + EOF_MARK
+
+
+def random_cases(seed: int, trials: int):
+    """(data, BGZF bytes) pairs: texts of every texture under every zlib level, strategy and memory level, with flushes
+    in odd places, in members of odd sizes."""
+    import random
+    rnd = random.Random(seed)
+
+    def text(n):
+        out = bytearray()
+        lines = []
+        while len(out) < n:
+            kind = rnd.randrange(6)
+            if kind == 0: piece = bytes([rnd.randrange(256)]) * rnd.randrange(1, 400)
+            elif kind == 1: piece = bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 9))) * rnd.randrange(1, 60)
+            elif kind == 2 and lines: piece = rnd.choice(lines)
+            elif kind == 3: piece = bytes(rnd.choice(b"ACGT") for _ in range(rnd.randrange(1, 200))) + b"\n"
+            elif kind == 4: piece = bytes(rnd.choice(b"FFFFFFF:,#") for _ in range(rnd.randrange(1, 200))) + b"\n"
+            else: piece = bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 50)))
+            lines.append(piece)
+            out += piece
+        return bytes(out[:n])
+
+    for _ in range(trials):
+        data = text(rnd.randrange(1, 200_000))
+        raw, at = b"", 0
+        while at < len(data):
+            size = rnd.choice([97, 1000, 20_000, 65_280, 65_536])
+            kw = dict(level=rnd.randrange(0, 10), strategy=rnd.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]),
+                      mem_level=rnd.randrange(1, 10), flush_every=rnd.choice([0, 0, 777, 5000]))
+            chunk = data[at:at + size]
+            try:
+                raw += member(chunk, **kw)
+            except AssertionError:                               # (did not fit a BGZF member: noise at level 0)
+                raw += member(chunk[: len(chunk) // 2], level=1) + member(chunk[len(chunk) // 2:], level=1)
+            at += size
+        yield data, raw + EOF_MARK

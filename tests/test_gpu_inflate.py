@@ -55,6 +55,15 @@ def test_every_block_type_inflates_as_zlib_does(eng, name, data, raw):
     assert bad == 0 and got == data
 
 
+def test_whatever_zlib_writes_comes_back(eng):
+    """The property test of tests/test_inflate_core.py on the kernels: the same random members, other seeds too."""
+    from inflate_cases import random_cases
+    for seed in (77, 5):
+        for trial, (data, raw) in enumerate(random_cases(seed, 40)):
+            bad, got = device_inflate(eng, raw)
+            assert bad == 0 and got == data, (seed, trial)
+
+
 def test_damaged_members_are_counted(eng):
     data = fastq_text(1200, 3)
     raw = bgzf(data)

@@ -233,7 +233,9 @@ def test_device_halves_of_the_streaming_run():
     n = 50000
     src = rng.integers(0, 256, size=4_000_000, dtype=np.uint8)
     lens = rng.integers(0, 70, size=n).astype(np.uint32); lens[:5] = [0, 1, 7, 8, 9]
-    src_off = rng.integers(0, len(src) - 80, size=n).astype(np.uint64)
+    lens[5:21] = [15, 16, 17, 31, 32, 33, 127, 128, 129, 143, 144, 145, 300, 322, 1000, 1001]   # eight lanes, sixteen bytes each: every edge of that
+    lens[1000:3000] = rng.integers(100, 400, size=2000)                                           # (and records of the usual size)
+    src_off = rng.integers(0, len(src) - 1100, size=n).astype(np.uint64)
     dst_off = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
     total = int(lens.sum())
     d_src, d_so, d_ln, d_do = to_dev(src, src_off, lens, dst_off)

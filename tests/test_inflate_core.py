@@ -73,3 +73,13 @@ def test_what_the_device_deflater_writes_comes_back(tmp_path, quality):
     for lanes in (64, 8):
         members, bad, got = run(raw, tmp_path, lanes)
         assert bad == 0 and got == data
+
+
+def test_whatever_zlib_writes_comes_back(tmp_path):
+    """Property test: texts of every texture (runs, short periods, repeats of earlier lines, noise) under every zlib
+    level, strategy and memory level, with flushes in odd places, in members of odd sizes (inflate_cases.random_cases)."""
+    from inflate_cases import random_cases
+    for trial, (data, raw) in enumerate(random_cases(77, 40)):
+        for lanes in (64, 8):
+            members, bad, got = run(raw, tmp_path, lanes)
+            assert bad == 0 and got == data, (trial, lanes)

@@ -30,7 +30,31 @@ def log(*a):
     print(f"[{time.strftime('%H:%M:%S')}]", *a, flush=True)
 
 
+def _gzip_piece(args):
+    import zlib
+    path, lo, n = args
+    with open(path, "rb") as f:
+        f.seek(lo)
+        raw = f.read(n)
+    c = zlib.compressobj(1, zlib.DEFLATED, 31)                  # a whole gzip member (header, trailer), level 1
+    return c.compress(raw) + c.flush()
+
+
+def ordinary_gzip(plain, out, piece=256 << 20):
+    """`plain` as an ordinary .gz: gzip members of `piece` bytes of text each, one after the other (what `cat a.gz b.gz`
+    gives; readers take it as one stream), packed by a pool of processes."""
+    import multiprocessing as mp
+    size = plain.stat().st_size
+    jobs = [(str(plain), lo, min(piece, size - lo)) for lo in range(0, size, piece)]
+    with mp.get_context("fork").Pool(min(16, len(jobs))) as pool, open(out, "wb") as f:
+        for member in pool.imap(_gzip_piece, jobs):
+            f.write(member)
+
+
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--gzip-helper":   # (a process of its own, which has never touched the GPU, forks the packers)
+        ordinary_gzip(Path(sys.argv[2]), Path(sys.argv[3]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=100_000_000)
     ap.add_argument("--dir", default="/dev/shm/fqd_c4")
@@ -39,6 +63,8 @@ def main():
     ap.add_argument("--mem-limit", default="", help="-m value in MB (default: the CLI's 2048)")
     ap.add_argument("--keep-inputs", action="store_true", help="leave r1.fq.gz / r2.fq.gz in --dir (for a profiler run of the CLI on them)")
     ap.add_argument("--no-check", action="store_true", help="skip reading the outputs back")
+    ap.add_argument("--plain-gzip", action="store_true", help="inputs as ORDINARY gzip (members of 256 MB of text made by zlib level 1, no BGZF fields: "
+                                                              "what gzip / pigz / a sequencer's software write): no member-parallel reader can split them")
     ap.add_argument("--settle", type=float, default=0.0, help="seconds to wait before the first timed run (the kernel clears the device memory a process that "
                                                               "has just exited gave back; an allocation waits for that clearing)")
     ap.add_argument("--wrap", default="", help="command prefix for the --also runs that carry WRAP=1, ({i} = the run's index) e.g. 'rocprofv3 --kernel-trace --output-format csv -d DIR/{i} -o c4 --'")
@@ -90,8 +116,11 @@ def main():
             del seqs
             out = d / f"r{mate + 1}.fq.gz"
             t0 = time.perf_counter()
-            subprocess.run([str(packer), str(plain), str(out)], check=True, env=dict(os.environ, FQD_GZ_LEVEL="1"))
-            log(f"file {mate + 1}: {plain.stat().st_size / 1e9:.1f} GB -> {out.stat().st_size / 1e9:.2f} GB BGZF in {time.perf_counter() - t0:.0f} s")
+            if a.plain_gzip:
+                subprocess.run([sys.executable, str(Path(__file__).resolve()), "--gzip-helper", str(plain), str(out)], check=True)
+            else:
+                subprocess.run([str(packer), str(plain), str(out)], check=True, env=dict(os.environ, FQD_GZ_LEVEL="1"))
+            log(f"file {mate + 1}: {plain.stat().st_size / 1e9:.1f} GB -> {out.stat().st_size / 1e9:.2f} GB {'ordinary gzip' if a.plain_gzip else 'BGZF'} in {time.perf_counter() - t0:.0f} s")
             plain.unlink()
             gz.append(out)
     dups = int((expect == 0).sum())

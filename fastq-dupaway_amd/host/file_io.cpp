@@ -1,4 +1,5 @@
 #include "file_io.hpp"
+#include "pgzip.hpp"
 
 #include <cerrno>
 #include <cstdlib>
@@ -109,16 +110,16 @@ InputFile::InputFile(const std::string& name, bool as_bytes) : gz_(!as_bytes && 
         if (k >= 18 && bgzf_member_size(head, static_cast<size_t>(k), &off) != 0) {
             bgzf_ = true;
         } else {
-            ::close(fd_); fd_ = -1;
-            g_ = gzopen(name.c_str(), "rb");
-            if (!g_) throw_cannot_open(name);
-            gzbuffer(g_, 4u << 20);
+            // an ordinary gzip file: by several threads (pgzip.hpp) if the first read asks for that and the file is a
+            // regular one of some size; through zlib's gzread otherwise.  Decided at the first read.
+            undecided_ = true;
         }
     }
 }
 
 InputFile::~InputFile()
 {
+    delete static_cast<pgz::Reader*>(pgzip_);
     if (g_) gzclose(g_);
     if (fd_ >= 0) ::close(fd_);
 }
@@ -270,6 +271,27 @@ size_t InputFile::read_bgzf(char* dst, size_t n, unsigned threads)
 
 size_t InputFile::read(char* dst, size_t n, unsigned threads)
 {
+    if (undecided_) {
+        undecided_ = false;
+        static const uint64_t least = [] { const char* v = std::getenv("FQD_PGZIP_MIN_MB"); return (v ? uint64_t(std::atoll(v)) : 8u) << 20; }();
+        static const bool allowed = [] { const char* v = std::getenv("FQD_PGZIP"); return !v || std::atoi(v) != 0; }();
+        if (allowed && regular_ && threads >= 2 && size_ >= least) {
+            try { pgzip_ = new pgz::Reader(fd_, size_, threads); }
+            catch (const std::invalid_argument&) { pgzip_ = nullptr; }            // (a header it does not know: zlib reads the file)
+        }
+        if (!pgzip_) {
+            g_ = gzdopen(fd_, "rb");                                              // (the descriptor has only been pread so far: it stands at 0)
+            if (!g_) throw std::runtime_error("gzip input is corrupt or truncated");
+            fd_ = -1;
+            gzbuffer(g_, 4u << 20);
+        }
+    }
+    if (pgzip_) {
+        if (eof_) return 0;
+        const size_t got = static_cast<pgz::Reader*>(pgzip_)->read(dst, n);
+        if (got < n) eof_ = true;
+        return got;
+    }
     if (bgzf_) return read_bgzf(dst, n, threads);
     constexpr size_t kMinPart = 16u << 20;
     if (!gz_ && regular_ && threads > 1 && n >= 2 * kMinPart && !eof_) {

@@ -52,6 +52,8 @@ private:
     size_t read_bgzf(char* dst, size_t n, unsigned threads);
     bool fill_compressed();
     bool gz_; gzFile g_ = nullptr; int fd_ = -1; bool eof_ = false;
+    bool undecided_ = false;                                    // an ordinary .gz whose reader (several threads, or zlib) the first read picks
+    void* pgzip_ = nullptr;                                     // pgz::Reader (pgzip.hpp), when it was the pick
     bool regular_ = false; uint64_t size_ = 0, offset_ = 0;     // plain regular files: known size, own cursor
     // BGZF (blocked gzip, what bgzip / sequencer software write): every member says how long it
     // is, so a batch of members is cut out of the compressed stream without inflating and then

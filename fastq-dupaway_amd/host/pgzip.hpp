@@ -1,0 +1,498 @@
+// pgzip.hpp — an ORDINARY gzip file (one long deflate stream, no member sizes: what gzip, pigz and sequencer software
+// write) inflated by several threads.  Header-only: file_io.cpp includes it, nothing else does.
+//
+// The reference reads `.gz` inputs through Boost's gzip_decompressor on its one thread (file_utils.hpp:58-69), and so
+// did this reader (zlib's gzread: 0.45-0.5 GB/s of text per file, 13 s of a 13.8 s run on 2 x 6.4 GB).  A deflate
+// stream hides two things from a second thread: where a block starts, and the 32 KiB of text before it that its
+// matches may reach into.  Both are dealt with the way pugz and rapidgzip do:
+//
+//   * the compressed bytes are cut into chunks; the worker of a chunk LOOKS for the first bit offset at or after its
+//     chunk's start where a dynamic block header parses and both of its codes are complete — a guess, right but for
+//     one time in many millions — and decodes from there to the first such block boundary at or after the next
+//     chunk's start;
+//   * what it decodes are 16-bit symbols: a byte, or "the byte that lies this far back in the 32 KiB before my
+//     start" wherever a match reaches there;
+//   * the reader walks the chunks in order: a chunk counts only if it starts exactly where the chunk before it
+//     ended (a chain of block boundaries that begins at the stream's true start — a wrong guess breaks the chain
+//     and the stretch is decoded again from the right place, on the spot); then the window it needed is known, its
+//     symbols become bytes (a worker's job again, with the CRC-32 of the piece), and the pieces' CRCs are combined
+//     and held against the member's trailer, ISIZE too, as zlib would.
+//
+// Anything this cannot do (no regular file, a header field it does not know) leaves the file to gzread as before.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <future>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <sys/mman.h>
+#include <zlib.h>
+
+namespace fqdhost {
+namespace pgz {
+
+// ---- bits ----------------------------------------------------------------------------------------------------------
+struct BitIn {
+    const uint8_t* base = nullptr;
+    uint64_t nbytes = 0;
+    // at least 56 valid bits of the stream from bit `pos` on (zeros beyond its end)
+    uint64_t window(uint64_t pos) const
+    {
+        const uint64_t byte = pos >> 3;
+        uint64_t v = 0;
+        if (byte + 8 <= nbytes) std::memcpy(&v, base + byte, 8);
+        else for (uint64_t k = 0; byte + k < nbytes && k < 8; ++k) v |= uint64_t(base[byte + k]) << (8 * k);
+        return v >> (pos & 7);
+    }
+    uint64_t bits() const { return nbytes * 8; }
+};
+
+// ---- one canonical Huffman code ------------------------------------------------------------------------------------
+struct Code {
+    static constexpr int kLut = 11;
+    uint16_t lut[1 << kLut];            // symbol << 4 | length; 0: a longer code, or none
+    uint32_t lim[16];                   // [l]: end of the codes of length <= l, left-justified in 15 bits
+    int32_t base[16];
+    uint16_t sorted[288];
+
+    // false: over-subscribed, or incomplete where zlib does not let that pass
+    bool build(const uint8_t* lens, int n, bool may_be_single)
+    {
+        int count[16] = {0};
+        for (int s = 0; s < n; ++s) ++count[lens[s]];
+        int left = 1, codes = 0;
+        for (int l = 1; l <= 15; ++l) { left = (left << 1) - count[l]; if (left < 0) return false; codes += count[l]; }
+        if (left > 0 && !(may_be_single && (codes == 0 || (codes == 1 && count[1] == 1)))) return false;
+        uint32_t code = 0, offset = 0, offs[16] = {0};
+        for (int l = 1; l <= 15; ++l) {
+            base[l] = int32_t(offset) - int32_t(code);
+            lim[l] = (code + uint32_t(count[l])) << (15 - l);
+            offs[l] = offset;
+            offset += uint32_t(count[l]);
+            code = (code + uint32_t(count[l])) << 1;
+        }
+        std::memset(lut, 0, sizeof lut);
+        uint32_t next_code[16];
+        { uint32_t c = 0; for (int l = 1; l <= 15; ++l) { next_code[l] = c; c = (c + uint32_t(count[l])) << 1; } }
+        for (int s = 0; s < n; ++s) {
+            const int l = lens[s];
+            if (!l) continue;
+            sorted[offs[l]++] = uint16_t(s);
+            const uint32_t c = next_code[l]++;
+            if (l <= kLut) {
+                uint32_t rev = 0;
+                for (int b = 0; b < l; ++b) rev |= ((c >> b) & 1u) << (l - 1 - b);
+                for (uint32_t idx = rev; idx < (1u << kLut); idx += 1u << l) lut[idx] = uint16_t((s << 4) | l);
+            }
+        }
+        return true;
+    }
+    // the symbol at the head of w (stream order, least significant bit first); -1: no code starts so
+    inline int decode(uint64_t w, int& len) const
+    {
+        const uint32_t e = lut[w & ((1u << kLut) - 1)];
+        if (e) { len = int(e & 15); return int(e >> 4); }
+        uint32_t v = uint32_t(w) & 0x7FFFu, r = 0;                  // 15 bits, reversed: the first bit on top
+        for (int b = 0; b < 15; ++b) r |= ((v >> b) & 1u) << (14 - b);
+        int l = 1;
+        for (int k = 1; k < 15; ++k) l += r >= lim[k] ? 1 : 0;
+        if (r >= lim[15]) return -1;
+        len = l;
+        return sorted[uint32_t(base[l] + int32_t(r >> (15 - l)))];
+    }
+};
+
+inline bool parse_dynamic_header(const BitIn& in, uint64_t& pos, Code& lit, Code& dist)
+{
+    uint64_t w = in.window(pos);
+    const int nlen = int(w & 31) + 257, ndist = int((w >> 5) & 31) + 1, ncode = int((w >> 10) & 15) + 4;
+    pos += 14;
+    if (nlen > 286 || ndist > 30) return false;
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint8_t cl[19] = {0};
+    w = in.window(pos);                                             // 19 x 3 = 57 bits at most: two windows
+    for (int i = 0; i < ncode; ++i) {
+        if (i == 16) w = in.window(pos);
+        cl[order[i]] = uint8_t(w & 7); w >>= 3; pos += 3;
+    }
+    {   // the code-length code must be complete (zlib: type CODES), checked before a table is made of it
+        int left = 1, count[8] = {0};
+        for (int i = 0; i < 19; ++i) ++count[cl[i]];
+        for (int l = 1; l <= 7; ++l) { left = (left << 1) - count[l]; if (left < 0) return false; }
+        if (left != 0) return false;
+    }
+    Code clc;
+    if (!clc.build(cl, 19, false)) return false;
+    uint8_t lens[320];
+    int i = 0;
+    const int total = nlen + ndist;
+    while (i < total) {
+        w = in.window(pos);
+        int l;
+        const int sym = clc.decode(w, l);
+        if (sym < 0) return false;
+        pos += uint64_t(l); w >>= l;
+        if (sym < 16) { lens[i++] = uint8_t(sym); continue; }
+        int prev = 0, rep;
+        if (sym == 16) { if (i == 0) return false; prev = lens[i - 1]; rep = 3 + int(w & 3); pos += 2; }
+        else if (sym == 17) { rep = 3 + int(w & 7); pos += 3; }
+        else { rep = 11 + int(w & 127); pos += 7; }
+        if (i + rep > total) return false;
+        while (rep--) lens[i++] = uint8_t(prev);
+    }
+    if (pos > in.bits() || lens[256] == 0) return false;
+    return lit.build(lens, nlen, true) && dist.build(lens + nlen, ndist, true);     // (zlib lets a lone one-bit code pass in either)
+}
+
+inline void fixed_codes(Code& lit, Code& dist)
+{
+    uint8_t l[288], d[32];
+    for (int s = 0; s < 288; ++s) l[s] = uint8_t(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+    for (int s = 0; s < 32; ++s) d[s] = 5;
+    lit.build(l, 288, false); dist.build(d, 32, false);
+}
+
+// ---- a stretch of the stream decoded into 16-bit symbols -------------------------------------------------------------
+constexpr uint32_t kWindow = 32768;
+enum class Stop { Boundary, FinalBlock, Error };
+
+struct Piece {
+    uint64_t start_bit = UINT64_MAX, end_bit = 0;   // start: UINT64_MAX = no block start found in the chunk
+    Stop stop = Stop::Error;
+    std::vector<uint16_t> sym;                      // < 256: a byte; else 256 + place in the 32 KiB before the piece's first byte
+    uint32_t deepest = 0;                           // how far back into that window the piece reaches (0: not at all)
+};
+
+// Decodes blocks from `pos` (a block boundary) to the first boundary at or after `stop_bit` where a dynamic, non-final
+// block begins — the kind a chunk's worker looks for — or through the end of a final block.
+inline void decode_piece(const BitIn& in, uint64_t pos, uint64_t stop_bit, Piece& out)
+{
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    out.start_bit = pos; out.stop = Stop::Error; out.deepest = 0;
+    std::vector<uint16_t>& sym = out.sym;
+    const uint64_t total = in.bits();
+    auto codes = std::make_unique<std::pair<Code, Code>>();
+    Code& lit = codes->first; Code& dist = codes->second;
+    for (;;) {
+        if (pos + 3 > total) return;
+        uint64_t w = in.window(pos);
+        const int last = int(w & 1), type = int((w >> 1) & 3);
+        if (!last && type == 2 && pos >= stop_bit && pos != out.start_bit) { out.end_bit = pos; out.stop = Stop::Boundary; return; }
+        pos += 3;
+        if (type == 3) return;
+        if (type == 0) {
+            pos = (pos + 7) & ~uint64_t(7);
+            if (pos + 32 > total) return;
+            const uint64_t h = in.window(pos);
+            const uint32_t n = uint32_t(h & 0xFFFF), nn = uint32_t((h >> 16) & 0xFFFF);
+            if ((n ^ nn) != 0xFFFF) return;
+            pos += 32;
+            if (pos + uint64_t(n) * 8 > total) return;
+            const uint8_t* p = in.base + (pos >> 3);
+            const size_t at = sym.size();
+            sym.resize(at + n);
+            for (uint32_t k = 0; k < n; ++k) sym[at + k] = p[k];
+            pos += uint64_t(n) * 8;
+        } else {
+            if (type == 1) fixed_codes(lit, dist);
+            else if (!parse_dynamic_header(in, pos, lit, dist)) return;
+            // (the symbols go through a bare pointer into the vector's spare room: a push_back per literal is what this
+            //  loop would otherwise mostly do)
+            size_t n = sym.size();
+            auto room = [&](size_t need) { if (sym.size() < n + need) sym.resize(std::max(n + need, sym.size() + sym.size() / 2 + 4096)); };
+            for (;;) {
+                if (pos >= total) { sym.resize(n); return; }          // the stream ends inside a block
+                room(300);
+                uint16_t* const q0 = sym.data();
+                w = in.window(pos);
+                int l;
+                int s = lit.decode(w, l);
+                if (s < 0) { sym.resize(n); return; }
+                pos += uint64_t(l); w >>= l;
+                if (s < 256) {
+                    q0[n++] = uint16_t(s);
+                    // a second literal from the same window, more often than not
+                    s = lit.decode(w, l);
+                    if (s >= 0 && s < 256) { q0[n++] = uint16_t(s); pos += uint64_t(l); }
+                    continue;
+                }
+                if (s == 256) break;
+                if (s > 285) { sym.resize(n); return; }
+                s -= 257;
+                const uint32_t length = lbase[s] + uint32_t(w & ((1u << lext[s]) - 1u));
+                pos += lext[s]; w >>= lext[s];
+                int dl;
+                const int ds = dist.decode(w, dl);
+                if (ds < 0 || ds > 29) { sym.resize(n); return; }
+                pos += uint64_t(dl); w >>= dl;
+                const uint32_t d = dbase[ds] + uint32_t(w & ((1u << dext[ds]) - 1u));
+                pos += dext[ds];
+                uint16_t* q = q0 + n;
+                if (d <= n) {
+                    const uint16_t* from = q - d;
+                    for (uint32_t k = 0; k < length; ++k) q[k] = from[k];
+                } else {                                            // (part of) it lies before the piece: named, not known
+                    const uint32_t before = uint32_t(d - n);        // bytes back from the piece's first byte, of the match's first byte
+                    if (before > kWindow) { sym.resize(n); return; }
+                    if (before > out.deepest) out.deepest = before;
+                    for (uint32_t k = 0; k < length; ++k) {
+                        if (k < before) q[k] = uint16_t(256 + (kWindow - before + k));
+                        else q[k] = q[int64_t(k) - int64_t(d)];
+                    }
+                }
+                n += length;
+            }
+            sym.resize(n);
+        }
+        if (last) { out.end_bit = pos; out.stop = Stop::FinalBlock; return; }
+    }
+}
+
+// The first bit offset in [from, to) where a dynamic non-final block header parses with complete codes; UINT64_MAX: none.
+inline uint64_t find_block(const BitIn& in, uint64_t from, uint64_t to)
+{
+    auto codes = std::make_unique<std::pair<Code, Code>>();
+    const uint64_t total = in.bits();
+    for (uint64_t o = from; o < to && o + 17 <= total; ++o) {
+        const uint64_t w = in.window(o);
+        if ((w & 7) != 4) continue;                                  // BFINAL = 0, BTYPE = 2
+        if (((w >> 3) & 31) > 29 || ((w >> 8) & 31) > 29) continue;
+        uint64_t pos = o + 3;
+        if (parse_dynamic_header(in, pos, codes->first, codes->second)) return o;
+    }
+    return UINT64_MAX;
+}
+
+// ---- symbols to bytes -------------------------------------------------------------------------------------------------
+// `window` = the (up to 32 KiB of) text before the piece's first byte.  false: the piece reaches further back than that.
+inline bool resolve(const std::vector<uint16_t>& sym, size_t from, size_t to, const std::vector<uint8_t>& window, uint8_t* out)
+{
+    const size_t w = window.size();
+    for (size_t k = from; k < to; ++k) {
+        const uint16_t s = sym[k];
+        if (s < 256) { out[k - from] = uint8_t(s); continue; }
+        const uint32_t back = kWindow - (uint32_t(s) - 256u);       // bytes back from the piece's first byte
+        if (back > w) return false;
+        out[k - from] = window[w - back];
+    }
+    return true;
+}
+
+struct Ready { std::vector<uint8_t> bytes; uint32_t crc = 0; bool ok = true; };
+
+// ---- the reader ---------------------------------------------------------------------------------------------------------
+class Reader {
+public:
+    // throws std::invalid_argument where this reader does not apply (the caller reads the file with zlib then)
+    Reader(int fd, uint64_t size, unsigned threads) : size_(size), threads_(std::min(8u, std::max(2u, threads)))
+    {
+        void* m = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) throw std::invalid_argument("mmap");
+        in_.base = static_cast<const uint8_t*>(m); in_.nbytes = size;
+#ifdef MADV_SEQUENTIAL
+        (void)::madvise(m, size, MADV_SEQUENTIAL);
+#endif
+        uint64_t at = 0;
+        if (!member_header(at)) { ::munmap(m, size); throw std::invalid_argument("header"); }
+        cur_bit_ = at * 8;
+        next_chunk_ = cur_bit_ / kChunkBits + 1;
+        first_of_member_ = true;
+    }
+    ~Reader()
+    {
+        for (auto& f : ahead_) if (f.second.valid()) f.second.wait();
+        for (auto& f : ready_) if (f.valid()) f.wait();
+        ::munmap(const_cast<uint8_t*>(in_.base), size_);
+    }
+    Reader(const Reader&) = delete;
+    Reader& operator=(const Reader&) = delete;
+
+    size_t read(char* dst, size_t n)
+    {
+        size_t got = 0;
+        while (got < n) {
+            if (have_pos_ < have_.bytes.size()) {
+                const size_t k = std::min(n - got, have_.bytes.size() - have_pos_);
+                std::memcpy(dst + got, have_.bytes.data() + have_pos_, k);
+                have_pos_ += k; got += k;
+                continue;
+            }
+            if (!next_ready()) break;
+        }
+        return got;
+    }
+
+private:
+    static constexpr uint64_t kChunkBits = uint64_t(1) << 23;       // 1 MiB of compressed bytes per chunk
+
+    [[noreturn]] static void corrupt() { throw std::runtime_error("gzip input is corrupt or truncated"); }
+
+    // the gzip member header at byte `at`; true: at = first byte of its deflate stream
+    bool member_header(uint64_t& at) const
+    {
+        const uint8_t* p = in_.base;
+        if (at + 18 > size_ || p[at] != 31 || p[at + 1] != 139 || p[at + 2] != 8) return false;
+        const uint8_t flg = p[at + 3];
+        if (flg & 0xE0) return false;
+        uint64_t q = at + 10;
+        if (flg & 4) { if (q + 2 > size_) return false; q += 2 + (uint64_t(p[q]) | (uint64_t(p[q + 1]) << 8)); }
+        if (flg & 8) { while (q < size_ && p[q]) ++q; ++q; }
+        if (flg & 16) { while (q < size_ && p[q]) ++q; ++q; }
+        if (flg & 2) q += 2;
+        if (q + 8 > size_) return false;
+        at = q;
+        return true;
+    }
+
+    std::future<Piece> launch(uint64_t chunk)
+    {
+        return std::async(std::launch::async, [this, chunk] {
+            Piece p;
+            const uint64_t lo = chunk * kChunkBits, hi = lo + kChunkBits;
+            const uint64_t s = find_block(in_, lo, hi);
+            if (s == UINT64_MAX) return p;
+            p.sym.reserve(size_t(6) << 20);
+            decode_piece(in_, s, hi, p);
+            return p;
+        });
+    }
+
+    void top_up()
+    {
+        while (ahead_.size() < threads_ && next_chunk_ * kChunkBits < in_.bits()) {
+            ahead_.emplace_back(next_chunk_, launch(next_chunk_));
+            ++next_chunk_;
+        }
+    }
+
+    // The piece that starts at cur_bit_: the worker's, if its guess was that very bit, else decoded here and now.
+    Piece take_piece()
+    {
+        top_up();
+        // chunks whose range lies behind cur_bit_ are of no use any more (a piece ran through them)
+        while (!ahead_.empty() && (ahead_.front().first + 1) * kChunkBits <= cur_bit_) { ahead_.front().second.wait(); ahead_.pop_front(); top_up(); }
+        if (!ahead_.empty() && ahead_.front().first * kChunkBits <= cur_bit_) {
+            Piece p = ahead_.front().second.get();
+            ahead_.pop_front();
+            top_up();
+            if (p.start_bit == cur_bit_ && p.stop != Stop::Error) return p;
+            // a wrong guess, a chunk without a block start, or a stretch the worker could not decode: from the right place
+        }
+        Piece p;
+        const uint64_t stop = (cur_bit_ / kChunkBits + 1) * kChunkBits;
+        decode_piece(in_, cur_bit_, stop, p);
+        return p;
+    }
+
+    // Brings the next run of text into have_; false at the end of the file.
+    bool next_ready()
+    {
+        // keep a few pieces being turned into bytes while the oldest is handed out
+        while (!done_ && ready_.size() < threads_) step();
+        if (ready_.empty()) { if (failed_) corrupt(); return false; }
+        have_ = ready_.front().get();
+        ready_.pop_front();
+        have_pos_ = 0;
+        if (!have_.ok) corrupt();
+        return true;
+    }
+
+    // One piece further along the chain: window known, bytes and CRC left to a worker, member ends checked.
+    void step()
+    {
+        if (failed_) corrupt();
+        auto piece = std::make_shared<Piece>(take_piece());
+        if (piece->deepest > window_.size()) corrupt();             // a match that reaches before the member's first byte
+        if (piece->stop == Stop::Error) {                           // what was decoded before the damage is still text: handed out first,
+            failed_ = true;                                         // as zlib hands out what it has before it reports the error
+            done_ = true;
+            if (piece->sym.empty()) corrupt();
+        }
+        auto window = std::make_shared<std::vector<uint8_t>>(window_);
+        // the window after this piece: its last 32 KiB, resolved here (the next piece cannot start without it)
+        {
+            const size_t n = piece->sym.size();
+            std::vector<uint8_t> tail(std::min<size_t>(n, kWindow));
+            if (!resolve(piece->sym, n - tail.size(), n, window_, tail.data())) corrupt();
+            if (tail.size() < kWindow) {
+                const size_t keep = std::min<size_t>(window_.size(), kWindow - tail.size());
+                std::vector<uint8_t> w(window_.end() - static_cast<ptrdiff_t>(keep), window_.end());
+                w.insert(w.end(), tail.begin(), tail.end());
+                window_.swap(w);
+            } else window_.swap(tail);
+        }
+        member_bytes_ += piece->sym.size();
+        const bool ends_member = piece->stop == Stop::FinalBlock;
+        if (failed_) {
+            ready_.push_back(std::async(std::launch::async, [piece, window] {
+                Ready r;
+                r.bytes.resize(piece->sym.size());
+                r.ok = resolve(piece->sym, 0, piece->sym.size(), *window, r.bytes.data());
+                return r;
+            }));
+            return;
+        }
+        uint32_t want_crc = 0;
+        bool check = false;
+        cur_bit_ = piece->end_bit;
+        pieces_of_member_.push_back(piece->sym.size());
+        if (ends_member) {
+            uint64_t at = (cur_bit_ + 7) / 8;
+            if (at + 8 > size_) corrupt();
+            const uint8_t* t = in_.base + at;
+            want_crc = uint32_t(t[0]) | (uint32_t(t[1]) << 8) | (uint32_t(t[2]) << 16) | (uint32_t(t[3]) << 24);
+            const uint32_t isize = uint32_t(t[4]) | (uint32_t(t[5]) << 8) | (uint32_t(t[6]) << 16) | (uint32_t(t[7]) << 24);
+            if (isize != uint32_t(member_bytes_)) corrupt();
+            check = true;
+            at += 8;
+            // what follows: another member, zero padding, or the end
+            while (at < size_ && in_.base[at] == 0) ++at;
+            if (at >= size_ || !member_header(at)) done_ = true;      // (what follows a member and is no member: ignored, as zlib does)
+            else {
+                cur_bit_ = at * 8;
+                window_.clear(); member_bytes_ = 0;
+                // workers ahead of the new member's start guessed inside the old one or across the seam: the chain decides
+            }
+        } else if (cur_bit_ >= in_.bits()) corrupt();                // the stream ends without a final block
+        // bytes + CRC of the piece on a worker; the CRCs of a member's pieces are combined in order as they are handed out
+        const bool first = first_of_member_;
+        first_of_member_ = ends_member;
+        auto crc_so_far = crc_chain_;
+        auto mine = std::make_shared<std::promise<uint32_t>>();
+        crc_chain_ = mine->get_future().share();
+        ready_.push_back(std::async(std::launch::async, [piece, window, first, crc_so_far, mine, check, want_crc] {
+            Ready r;
+            r.bytes.resize(piece->sym.size());
+            r.ok = resolve(piece->sym, 0, piece->sym.size(), *window, r.bytes.data());
+            uint32_t c = uint32_t(crc32_z(0L, r.bytes.data(), r.bytes.size()));
+            if (!first) c = uint32_t(crc32_combine(crc_so_far.get(), c, static_cast<z_off_t>(r.bytes.size())));
+            mine->set_value(c);
+            if (check && c != want_crc) r.ok = false;
+            return r;
+        }));
+    }
+
+    BitIn in_;
+    uint64_t size_;
+    unsigned threads_;
+    uint64_t cur_bit_ = 0, next_chunk_ = 0, member_bytes_ = 0;
+    bool done_ = false, first_of_member_ = true, failed_ = false;
+    std::vector<uint8_t> window_;
+    std::vector<size_t> pieces_of_member_;
+    std::deque<std::pair<uint64_t, std::future<Piece>>> ahead_;
+    std::deque<std::future<Ready>> ready_;
+    std::shared_future<uint32_t> crc_chain_;
+    Ready have_;
+    size_t have_pos_ = 0;
+};
+
+} // namespace pgz
+} // namespace fqdhost

@@ -475,7 +475,9 @@ def test_unordered_bgzf_inputs_inflated_on_the_device(exe, oracle, tmp_path, cas
     for gunzip in ("1", "0"):
         g1, g2 = tmp_path / f"g1_{gunzip}.{ext}", tmp_path / f"g2_{gunzip}.{ext}"
         r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "--unordered", "-v", *fmt,
-                env={"FQD_HOST_TIMING": "1", "FQD_GUNZIP_DEVICE": gunzip}, cwd=tmp_path)
+                env={"FQD_HOST_TIMING": "1", "FQD_GUNZIP_DEVICE": gunzip, "FQD_PGZIP_MIN_MB": "0" if gunzip == "1" else "8"}, cwd=tmp_path)
+        # (FQD_PGZIP_MIN_MB=0: ordinary gzip inputs of any size go through the several-thread reader, host/pgzip.hpp, in one of
+        #  the two runs and through zlib in the other)
         said = "\n".join(l for l in r.stderr.splitlines() if "[host timing]" not in l)
         runs[gunzip] = (r.returncode, r.stdout, said, g1.read_bytes() if g1.exists() else None, g2.read_bytes() if g2.exists() else None)
         if r.returncode == 0:                               # (the stage clocks are printed by runs that finish)

@@ -217,11 +217,12 @@ inline void decode_piece(const BitIn& in, uint64_t pos, uint64_t stop_bit, Piece
                 int s = lit.decode(w, l);
                 if (s < 0) { sym.resize(n); return; }
                 pos += uint64_t(l); w >>= l;
+                if (pos > total) { sym.resize(n); return; }           // (a code read out of the zeros beyond the stream's last byte)
                 if (s < 256) {
                     q0[n++] = uint16_t(s);
                     // a second literal from the same window, more often than not
                     s = lit.decode(w, l);
-                    if (s >= 0 && s < 256) { q0[n++] = uint16_t(s); pos += uint64_t(l); }
+                    if (s >= 0 && s < 256 && pos + uint64_t(l) <= total) { q0[n++] = uint16_t(s); pos += uint64_t(l); }
                     continue;
                 }
                 if (s == 256) break;

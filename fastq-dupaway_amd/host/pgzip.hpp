@@ -27,6 +27,7 @@
 #include <deque>
 #include <future>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -149,6 +150,33 @@ inline bool parse_dynamic_header(const BitIn& in, uint64_t& pos, Code& lit, Code
     return lit.build(lens, nlen, true) && dist.build(lens + nlen, ndist, true);     // (zlib lets a lone one-bit code pass in either)
 }
 
+// What the decode loop reads per code: everything about it in one 32-bit word.
+//   bits 0-3 code length (0: longer than the table's index, or no code — the slow way decides), bits 4-5 kind
+//   (0 literal, 1 length, 2 end of block, 3 distance), bits 8-12 extra bits, bits 16-31 the literal / the base.
+struct Fast {
+    uint32_t lit[1 << Code::kLut], dist[1 << Code::kLut];
+    void build(const Code& l, const Code& d)
+    {
+        static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+        static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+        static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+        static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+        for (uint32_t i = 0; i < (1u << Code::kLut); ++i) {
+            const uint32_t e = l.lut[i], len = e & 15u, sym = e >> 4;
+            uint32_t v = 0;
+            if (len) {
+                if (sym < 256u) v = len | (sym << 16);
+                else if (sym == 256u) v = len | (2u << 4);
+                else if (sym <= 285u) v = len | (1u << 4) | (uint32_t(lext[sym - 257u]) << 8) | (uint32_t(lbase[sym - 257u]) << 16);
+                // (286, 287: no entry — the slow way reports them)
+            }
+            lit[i] = v;
+            const uint32_t f = d.lut[i], dl = f & 15u, ds = f >> 4;
+            dist[i] = dl && ds < 30u ? dl | (3u << 4) | (uint32_t(dext[ds]) << 8) | (uint32_t(dbase[ds]) << 16) : 0u;
+        }
+    }
+};
+
 inline void fixed_codes(Code& lit, Code& dist)
 {
     uint8_t l[288], d[32];
@@ -181,6 +209,7 @@ inline void decode_piece(const BitIn& in, uint64_t pos, uint64_t stop_bit, Piece
     const uint64_t total = in.bits();
     auto codes = std::make_unique<std::pair<Code, Code>>();
     Code& lit = codes->first; Code& dist = codes->second;
+    auto fast = std::make_unique<Fast>();
     for (;;) {
         if (pos + 3 > total) return;
         uint64_t w = in.window(pos);
@@ -207,8 +236,70 @@ inline void decode_piece(const BitIn& in, uint64_t pos, uint64_t stop_bit, Piece
             // (the symbols go through a bare pointer into the vector's spare room: a push_back per literal is what this
             //  loop would otherwise mostly do)
             size_t n = sym.size();
-            auto room = [&](size_t need) { if (sym.size() < n + need) sym.resize(std::max(n + need, sym.size() + sym.size() / 2 + 4096)); };
+            auto room = [&](size_t need) { if (sym.size() < n + need) sym.resize(n + need + 65536); };     // (a step at a time: the vector is cut back to n at every block's end, and growing fills with zeros)
+            bool at_end_of_block = false;
+            if ((pos >> 3) + 64 < in.nbytes) {
+                // The fast way, while the stream's end is far: the bits in a register, refilled eight bytes at a load;
+                // everything about a code in one table word.  What it cannot settle (a code longer than the table's
+                // index, the last bytes of the stream) is left to the loop below, from the very bit it stopped at.
+                fast->build(lit, dist);
+                const uint8_t* p = in.base + (pos >> 3);
+                const uint8_t* const safe = in.base + in.nbytes - 16;
+                uint64_t bb; std::memcpy(&bb, p, 8);
+                uint32_t bc = 64u - uint32_t(pos & 7);
+                bb >>= (pos & 7); p += 8;
+                // (bc valid bits in bb; the stream's next byte not yet in bb is at p)
+                auto refill = [&]() { while (bc <= 56u) { bb |= uint64_t(*p++) << bc; bc += 8u; } };
+                for (;;) {
+                    if (p >= safe) break;
+                    room(300);
+                    uint16_t* const q0 = sym.data();
+                    refill();
+                    uint32_t e = fast->lit[bb & ((1u << Code::kLut) - 1u)];
+                    if ((e & 15u) == 0u) break;
+                    if ((e & 0x30u) == 0u) {                          // literals, up to three from one fill
+                        bb >>= (e & 15u); bc -= (e & 15u); q0[n++] = uint16_t(e >> 16);
+                        e = fast->lit[bb & ((1u << Code::kLut) - 1u)];
+                        if ((e & 15u) != 0u && (e & 0x30u) == 0u) {
+                            bb >>= (e & 15u); bc -= (e & 15u); q0[n++] = uint16_t(e >> 16);
+                            e = fast->lit[bb & ((1u << Code::kLut) - 1u)];
+                            if ((e & 15u) != 0u && (e & 0x30u) == 0u) { bb >>= (e & 15u); bc -= (e & 15u); q0[n++] = uint16_t(e >> 16); }
+                        }
+                        continue;
+                    }
+                    if ((e & 0x30u) == 0x20u) { bb >>= (e & 15u); bc -= (e & 15u); at_end_of_block = true; break; }
+                    // a length: its code and extra bits, then the distance's (48 bits at most, 57 are there)
+                    const uint32_t f = fast->dist[(bb >> ((e & 15u) + ((e >> 8) & 31u))) & ((1u << Code::kLut) - 1u)];
+                    if ((f & 15u) == 0u) break;                       // (nothing consumed yet: the slow way takes the whole match)
+                    bb >>= (e & 15u); bc -= (e & 15u);
+                    const uint32_t ex = (e >> 8) & 31u;
+                    const uint32_t length = (e >> 16) + uint32_t(bb & ((1u << ex) - 1u));
+                    bb >>= ex; bc -= ex;
+                    bb >>= (f & 15u); bc -= (f & 15u);
+                    const uint32_t dx = (f >> 8) & 31u;
+                    const uint32_t d = (f >> 16) + uint32_t(bb & ((1u << dx) - 1u));
+                    bb >>= dx; bc -= dx;
+                    uint16_t* q = q0 + n;
+                    if (d <= n) {
+                        const uint16_t* from = q - d;
+                        if (d >= 4u) {                                // four symbols a step (the copy may run up to three past the match: room(300) covers it,
+                            for (uint32_t k = 0; k < length; k += 4u) std::memcpy(q + k, from + k, 8);       // and they are overwritten by what comes next)
+                        } else for (uint32_t k = 0; k < length; ++k) q[k] = from[k];
+                    } else {
+                        const uint32_t before = uint32_t(d - n);
+                        if (before > kWindow) { sym.resize(n); return; }
+                        if (before > out.deepest) out.deepest = before;
+                        for (uint32_t k = 0; k < length; ++k) {
+                            if (k < before) q[k] = uint16_t(256 + (kWindow - before + k));
+                            else q[k] = q[int64_t(k) - int64_t(d)];
+                        }
+                    }
+                    n += length;
+                }
+                pos = uint64_t(p - in.base) * 8u - bc;
+            }
             for (;;) {
+                if (at_end_of_block) break;
                 if (pos >= total) { sym.resize(n); return; }          // the stream ends inside a block
                 room(300);
                 uint16_t* const q0 = sym.data();
@@ -287,7 +378,30 @@ inline bool resolve(const std::vector<uint16_t>& sym, size_t from, size_t to, co
     return true;
 }
 
-struct Ready { std::vector<uint8_t> bytes; uint32_t crc = 0; bool ok = true; };
+struct Ready { std::vector<uint8_t> bytes; size_t size = 0; uint32_t crc = 0; bool ok = true; };   // (bytes may be longer than size: a recycled buffer)
+
+// Buffers go round: a piece's symbols and a run's bytes are megabytes, and fresh megabytes are pages the kernel hands
+// out one fault at a time, behind one lock for all threads of the process.
+struct Pool {
+    std::mutex m;
+    std::vector<std::vector<uint16_t>> syms;
+    std::vector<std::vector<uint8_t>> bytes;
+    std::vector<uint16_t> take_syms()
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (syms.empty()) { std::vector<uint16_t> v; v.reserve(size_t(6) << 20); return v; }
+        std::vector<uint16_t> v = std::move(syms.back()); syms.pop_back(); v.clear(); return v;
+    }
+    void give(std::vector<uint16_t>&& v) { std::lock_guard<std::mutex> g(m); if (syms.size() < 32) syms.push_back(std::move(v)); }
+    std::vector<uint8_t> take_bytes(size_t n)
+    {
+        std::vector<uint8_t> v;
+        { std::lock_guard<std::mutex> g(m); if (!bytes.empty()) { v = std::move(bytes.back()); bytes.pop_back(); } }
+        if (v.size() < n) v.resize(n + n / 8);
+        return v;
+    }
+    void give(std::vector<uint8_t>&& v) { std::lock_guard<std::mutex> g(m); if (bytes.size() < 32) bytes.push_back(std::move(v)); }
+};
 
 // ---- the reader ---------------------------------------------------------------------------------------------------------
 class Reader {
@@ -320,8 +434,8 @@ public:
     {
         size_t got = 0;
         while (got < n) {
-            if (have_pos_ < have_.bytes.size()) {
-                const size_t k = std::min(n - got, have_.bytes.size() - have_pos_);
+            if (have_pos_ < have_.size) {
+                const size_t k = std::min(n - got, have_.size - have_pos_);
                 std::memcpy(dst + got, have_.bytes.data() + have_pos_, k);
                 have_pos_ += k; got += k;
                 continue;
@@ -360,7 +474,7 @@ private:
             const uint64_t lo = chunk * kChunkBits, hi = lo + kChunkBits;
             const uint64_t s = find_block(in_, lo, hi);
             if (s == UINT64_MAX) return p;
-            p.sym.reserve(size_t(6) << 20);
+            p.sym = pool_.take_syms();
             decode_piece(in_, s, hi, p);
             return p;
         });
@@ -379,15 +493,17 @@ private:
     {
         top_up();
         // chunks whose range lies behind cur_bit_ are of no use any more (a piece ran through them)
-        while (!ahead_.empty() && (ahead_.front().first + 1) * kChunkBits <= cur_bit_) { ahead_.front().second.wait(); ahead_.pop_front(); top_up(); }
+        while (!ahead_.empty() && (ahead_.front().first + 1) * kChunkBits <= cur_bit_) { pool_.give(std::move(ahead_.front().second.get().sym)); ahead_.pop_front(); top_up(); }
         if (!ahead_.empty() && ahead_.front().first * kChunkBits <= cur_bit_) {
             Piece p = ahead_.front().second.get();
             ahead_.pop_front();
             top_up();
             if (p.start_bit == cur_bit_ && p.stop != Stop::Error) return p;
+            pool_.give(std::move(p.sym));
             // a wrong guess, a chunk without a block start, or a stretch the worker could not decode: from the right place
         }
         Piece p;
+        p.sym = pool_.take_syms();
         const uint64_t stop = (cur_bit_ / kChunkBits + 1) * kChunkBits;
         decode_piece(in_, cur_bit_, stop, p);
         return p;
@@ -399,6 +515,7 @@ private:
         // keep a few pieces being turned into bytes while the oldest is handed out
         while (!done_ && ready_.size() < threads_) step();
         if (ready_.empty()) { if (failed_) corrupt(); return false; }
+        pool_.give(std::move(have_.bytes));
         have_ = ready_.front().get();
         ready_.pop_front();
         have_pos_ = 0;
@@ -433,10 +550,12 @@ private:
         member_bytes_ += piece->sym.size();
         const bool ends_member = piece->stop == Stop::FinalBlock;
         if (failed_) {
-            ready_.push_back(std::async(std::launch::async, [piece, window] {
+            ready_.push_back(std::async(std::launch::async, [this, piece, window] {
                 Ready r;
-                r.bytes.resize(piece->sym.size());
+                r.size = piece->sym.size();
+                r.bytes = pool_.take_bytes(r.size);
                 r.ok = resolve(piece->sym, 0, piece->sym.size(), *window, r.bytes.data());
+                pool_.give(std::move(piece->sym));
                 return r;
             }));
             return;
@@ -444,7 +563,6 @@ private:
         uint32_t want_crc = 0;
         bool check = false;
         cur_bit_ = piece->end_bit;
-        pieces_of_member_.push_back(piece->sym.size());
         if (ends_member) {
             uint64_t at = (cur_bit_ + 7) / 8;
             if (at + 8 > size_) corrupt();
@@ -469,12 +587,14 @@ private:
         auto crc_so_far = crc_chain_;
         auto mine = std::make_shared<std::promise<uint32_t>>();
         crc_chain_ = mine->get_future().share();
-        ready_.push_back(std::async(std::launch::async, [piece, window, first, crc_so_far, mine, check, want_crc] {
+        ready_.push_back(std::async(std::launch::async, [this, piece, window, first, crc_so_far, mine, check, want_crc] {
             Ready r;
-            r.bytes.resize(piece->sym.size());
+            r.size = piece->sym.size();
+            r.bytes = pool_.take_bytes(r.size);
             r.ok = resolve(piece->sym, 0, piece->sym.size(), *window, r.bytes.data());
-            uint32_t c = uint32_t(crc32_z(0L, r.bytes.data(), r.bytes.size()));
-            if (!first) c = uint32_t(crc32_combine(crc_so_far.get(), c, static_cast<z_off_t>(r.bytes.size())));
+            pool_.give(std::move(piece->sym));
+            uint32_t c = uint32_t(crc32_z(0L, r.bytes.data(), r.size));
+            if (!first) c = uint32_t(crc32_combine(crc_so_far.get(), c, static_cast<z_off_t>(r.size)));
             mine->set_value(c);
             if (check && c != want_crc) r.ok = false;
             return r;
@@ -482,12 +602,12 @@ private:
     }
 
     BitIn in_;
+    Pool pool_;
     uint64_t size_;
     unsigned threads_;
     uint64_t cur_bit_ = 0, next_chunk_ = 0, member_bytes_ = 0;
     bool done_ = false, first_of_member_ = true, failed_ = false;
     std::vector<uint8_t> window_;
-    std::vector<size_t> pieces_of_member_;
     std::deque<std::pair<uint64_t, std::future<Piece>>> ahead_;
     std::deque<std::future<Ready>> ready_;
     std::shared_future<uint32_t> crc_chain_;

@@ -153,26 +153,29 @@ inline bool parse_dynamic_header(const BitIn& in, uint64_t& pos, Code& lit, Code
 // What the decode loop reads per code: everything about it in one 32-bit word.
 //   bits 0-3 code length (0: longer than the table's index, or no code — the slow way decides), bits 4-5 kind
 //   (0 literal, 1 length, 2 end of block, 3 distance), bits 8-12 extra bits, bits 16-31 the literal / the base.
+inline uint32_t lit_entry(uint32_t sym, uint32_t len)
+{
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    if (sym < 256u) return len | (sym << 16);
+    if (sym == 256u) return len | (2u << 4);
+    if (sym <= 285u) return len | (1u << 4) | (uint32_t(lext[sym - 257u]) << 8) | (uint32_t(lbase[sym - 257u]) << 16);
+    return 0;                                                        // (286, 287: no entry — the slow way reports them)
+}
+inline uint32_t dist_entry(uint32_t ds, uint32_t len)
+{
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    return ds < 30u ? len | (3u << 4) | (uint32_t(dext[ds]) << 8) | (uint32_t(dbase[ds]) << 16) : 0u;
+}
 struct Fast {
     uint32_t lit[1 << Code::kLut], dist[1 << Code::kLut];
     void build(const Code& l, const Code& d)
     {
-        static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-        static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-        static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-        static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
         for (uint32_t i = 0; i < (1u << Code::kLut); ++i) {
-            const uint32_t e = l.lut[i], len = e & 15u, sym = e >> 4;
-            uint32_t v = 0;
-            if (len) {
-                if (sym < 256u) v = len | (sym << 16);
-                else if (sym == 256u) v = len | (2u << 4);
-                else if (sym <= 285u) v = len | (1u << 4) | (uint32_t(lext[sym - 257u]) << 8) | (uint32_t(lbase[sym - 257u]) << 16);
-                // (286, 287: no entry — the slow way reports them)
-            }
-            lit[i] = v;
-            const uint32_t f = d.lut[i], dl = f & 15u, ds = f >> 4;
-            dist[i] = dl && ds < 30u ? dl | (3u << 4) | (uint32_t(dext[ds]) << 8) | (uint32_t(dbase[ds]) << 16) : 0u;
+            const uint32_t e = l.lut[i], f = d.lut[i];
+            lit[i] = (e & 15u) ? lit_entry(e >> 4, e & 15u) : 0u;
+            dist[i] = (f & 15u) ? dist_entry(f >> 4, f & 15u) : 0u;
         }
     }
 };
@@ -245,40 +248,54 @@ inline void decode_piece(const BitIn& in, uint64_t pos, uint64_t stop_bit, Piece
                 fast->build(lit, dist);
                 const uint8_t* p = in.base + (pos >> 3);
                 const uint8_t* const safe = in.base + in.nbytes - 16;
-                uint64_t bb; std::memcpy(&bb, p, 8);
-                uint32_t bc = 64u - uint32_t(pos & 7);
-                bb >>= (pos & 7); p += 8;
-                // (bc valid bits in bb; the stream's next byte not yet in bb is at p)
-                auto refill = [&]() { while (bc <= 56u) { bb |= uint64_t(*p++) << bc; bc += 8u; } };
+                uint64_t bb = 0;
+                uint32_t bc = 0;
+                // bc (56..63 after a refill) bits of bb count; the whole bytes among them lie before p, and what bb holds
+                // above them is a copy of what the next refill ORs in again
+                auto refill = [&]() { uint64_t v; std::memcpy(&v, p, 8); bb |= v << bc; p += (63u - bc) >> 3; bc |= 56u; };
+                refill();
+                bb >>= (pos & 7); bc -= uint32_t(pos & 7);
+                constexpr uint32_t kMask = (1u << Code::kLut) - 1u;
                 for (;;) {
                     if (p >= safe) break;
                     room(300);
                     uint16_t* const q0 = sym.data();
                     refill();
-                    uint32_t e = fast->lit[bb & ((1u << Code::kLut) - 1u)];
-                    if ((e & 15u) == 0u) break;
+                    uint32_t e = fast->lit[bb & kMask];
+                    if ((e & 15u) == 0u) {                            // a code longer than the table's index: the slow way, for this one code
+                        int l;
+                        const int sl = lit.decode(bb, l);
+                        if (sl < 0 || sl > 285) break;                // (nothing consumed: the loop below reports it)
+                        e = lit_entry(uint32_t(sl), uint32_t(l));
+                    }
                     if ((e & 0x30u) == 0u) {                          // literals, up to three from one fill
                         bb >>= (e & 15u); bc -= (e & 15u); q0[n++] = uint16_t(e >> 16);
-                        e = fast->lit[bb & ((1u << Code::kLut) - 1u)];
+                        e = fast->lit[bb & kMask];
                         if ((e & 15u) != 0u && (e & 0x30u) == 0u) {
                             bb >>= (e & 15u); bc -= (e & 15u); q0[n++] = uint16_t(e >> 16);
-                            e = fast->lit[bb & ((1u << Code::kLut) - 1u)];
+                            e = fast->lit[bb & kMask];
                             if ((e & 15u) != 0u && (e & 0x30u) == 0u) { bb >>= (e & 15u); bc -= (e & 15u); q0[n++] = uint16_t(e >> 16); }
                         }
                         continue;
                     }
                     if ((e & 0x30u) == 0x20u) { bb >>= (e & 15u); bc -= (e & 15u); at_end_of_block = true; break; }
-                    // a length: its code and extra bits, then the distance's (48 bits at most, 57 are there)
-                    const uint32_t f = fast->dist[(bb >> ((e & 15u) + ((e >> 8) & 31u))) & ((1u << Code::kLut) - 1u)];
-                    if ((f & 15u) == 0u) break;                       // (nothing consumed yet: the slow way takes the whole match)
-                    bb >>= (e & 15u); bc -= (e & 15u);
+                    // a length: its code and extra bits, then the distance's (48 bits at most, 56 are there)
                     const uint32_t ex = (e >> 8) & 31u;
+                    const uint64_t after = bb >> ((e & 15u) + ex);
+                    uint32_t f = fast->dist[after & kMask];
+                    if ((f & 15u) == 0u) {
+                        int dl;
+                        const int ds = dist.decode(after, dl);
+                        if (ds < 0 || ds > 29) break;                 // (nothing consumed yet)
+                        f = dist_entry(uint32_t(ds), uint32_t(dl));
+                    }
+                    bb >>= (e & 15u);
                     const uint32_t length = (e >> 16) + uint32_t(bb & ((1u << ex) - 1u));
-                    bb >>= ex; bc -= ex;
-                    bb >>= (f & 15u); bc -= (f & 15u);
+                    bb = after >> (f & 15u);
                     const uint32_t dx = (f >> 8) & 31u;
                     const uint32_t d = (f >> 16) + uint32_t(bb & ((1u << dx) - 1u));
-                    bb >>= dx; bc -= dx;
+                    bb >>= dx;
+                    bc -= (e & 15u) + ex + (f & 15u) + dx;
                     uint16_t* q = q0 + n;
                     if (d <= n) {
                         const uint16_t* from = q - d;

@@ -276,7 +276,7 @@ size_t InputFile::read(char* dst, size_t n, unsigned threads)
         static const uint64_t least = [] { const char* v = std::getenv("FQD_PGZIP_MIN_MB"); return (v ? uint64_t(std::atoll(v)) : 8u) << 20; }();
         static const bool allowed = [] { const char* v = std::getenv("FQD_PGZIP"); return !v || std::atoi(v) != 0; }();
         if (allowed && regular_ && threads >= 2 && size_ >= least) {
-            try { pgzip_ = new pgz::Reader(fd_, size_, threads); }
+            try { const FastCodec* fast = FastCodec::get(); pgzip_ = new pgz::Reader(fd_, size_, threads, fast ? fast->crc32 : nullptr); }
             catch (const std::invalid_argument&) { pgzip_ = nullptr; }            // (a header it does not know: zlib reads the file)
         }
         if (!pgzip_) {

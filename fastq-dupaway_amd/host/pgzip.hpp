@@ -424,7 +424,9 @@ struct Pool {
 class Reader {
 public:
     // throws std::invalid_argument where this reader does not apply (the caller reads the file with zlib then)
-    Reader(int fd, uint64_t size, unsigned threads) : size_(size), threads_(std::min(8u, std::max(2u, threads)))
+    // crc: CRC-32 of a buffer continued from a value, as zlib's crc32 (nullptr: zlib's; libdeflate's is several times faster)
+    using CrcFn = uint32_t (*)(uint32_t, const void*, size_t);
+    Reader(int fd, uint64_t size, unsigned threads, CrcFn crc = nullptr) : size_(size), threads_(std::min(8u, std::max(2u, threads))), crc_(crc)
     {
         void* m = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
         if (m == MAP_FAILED) throw std::invalid_argument("mmap");
@@ -604,13 +606,14 @@ private:
         auto crc_so_far = crc_chain_;
         auto mine = std::make_shared<std::promise<uint32_t>>();
         crc_chain_ = mine->get_future().share();
-        ready_.push_back(std::async(std::launch::async, [this, piece, window, first, crc_so_far, mine, check, want_crc] {
+        const CrcFn crc_fn = crc_;
+        ready_.push_back(std::async(std::launch::async, [this, piece, window, first, crc_so_far, mine, check, want_crc, crc_fn] {
             Ready r;
             r.size = piece->sym.size();
             r.bytes = pool_.take_bytes(r.size);
             r.ok = resolve(piece->sym, 0, piece->sym.size(), *window, r.bytes.data());
             pool_.give(std::move(piece->sym));
-            uint32_t c = uint32_t(crc32_z(0L, r.bytes.data(), r.size));
+            uint32_t c = crc_fn ? crc_fn(0u, r.bytes.data(), r.size) : uint32_t(crc32_z(0L, r.bytes.data(), r.size));
             if (!first) c = uint32_t(crc32_combine(crc_so_far.get(), c, static_cast<z_off_t>(r.size)));
             mine->set_value(c);
             if (check && c != want_crc) r.ok = false;
@@ -622,6 +625,7 @@ private:
     Pool pool_;
     uint64_t size_;
     unsigned threads_;
+    CrcFn crc_ = nullptr;
     uint64_t cur_bit_ = 0, next_chunk_ = 0, member_bytes_ = 0;
     bool done_ = false, first_of_member_ = true, failed_ = false;
     std::vector<uint8_t> window_;

@@ -275,6 +275,11 @@ def test_gz_in_and_out(exe, oracle, tmp_path):
     assert r.returncode == 0, r.stderr
     assert gzip.open(got, "rb").read() == exp.read_bytes()
     assert subprocess.run(["gzip", "-t", str(got)]).returncode == 0
+    # the same ordinary .gz through the several-thread reader (host/pgzip.hpp; files this small go through zlib otherwise)
+    got2 = tmp_path / "got2.fq"
+    r = run(exe, "-i", src, "-o", got2, "--fast", env={"FQD_PGZIP_MIN_MB": "0"})
+    assert r.returncode == 0, r.stderr
+    assert got2.read_bytes() == exp.read_bytes()
     # the oracle (zlib's gzread, as Boost's gzip_decompressor) reads the multi-member file back identically
     again = tmp_path / "again.fq"
     oracle.filter_single(got, again, FASTQ)

@@ -190,6 +190,7 @@ inline void fixed_codes(Code& lit, Code& dist)
 
 // ---- a stretch of the stream decoded into 16-bit symbols -------------------------------------------------------------
 constexpr uint32_t kWindow = 32768;
+constexpr size_t kMaxPiece = size_t(24) << 20;          // symbols of a piece before it ends at the next block boundary
 enum class Stop { Boundary, FinalBlock, Error };
 
 struct Piece {
@@ -217,7 +218,8 @@ inline void decode_piece(const BitIn& in, uint64_t pos, uint64_t stop_bit, Piece
         if (pos + 3 > total) return;
         uint64_t w = in.window(pos);
         const int last = int(w & 1), type = int((w >> 1) & 3);
-        if (!last && type == 2 && pos >= stop_bit && pos != out.start_bit) { out.end_bit = pos; out.stop = Stop::Boundary; return; }
+        // (a piece also ends where it has grown large — text that packs a thousandfold would otherwise be held whole, twice)
+        if (!last && type == 2 && pos != out.start_bit && (pos >= stop_bit || sym.size() >= kMaxPiece)) { out.end_bit = pos; out.stop = Stop::Boundary; return; }
         pos += 3;
         if (type == 3) return;
         if (type == 0) {
@@ -409,7 +411,7 @@ struct Pool {
         if (syms.empty()) { std::vector<uint16_t> v; v.reserve(size_t(6) << 20); return v; }
         std::vector<uint16_t> v = std::move(syms.back()); syms.pop_back(); v.clear(); return v;
     }
-    void give(std::vector<uint16_t>&& v) { std::lock_guard<std::mutex> g(m); if (syms.size() < 32) syms.push_back(std::move(v)); }
+    void give(std::vector<uint16_t>&& v) { std::lock_guard<std::mutex> g(m); if (syms.size() < 32 && v.capacity() <= (size_t(16) << 20)) syms.push_back(std::move(v)); }
     std::vector<uint8_t> take_bytes(size_t n)
     {
         std::vector<uint8_t> v;
@@ -417,7 +419,7 @@ struct Pool {
         if (v.size() < n) v.resize(n + n / 8);
         return v;
     }
-    void give(std::vector<uint8_t>&& v) { std::lock_guard<std::mutex> g(m); if (bytes.size() < 32) bytes.push_back(std::move(v)); }
+    void give(std::vector<uint8_t>&& v) { std::lock_guard<std::mutex> g(m); if (bytes.size() < 32 && v.capacity() <= (size_t(16) << 20)) bytes.push_back(std::move(v)); }
 };
 
 // ---- the reader ---------------------------------------------------------------------------------------------------------

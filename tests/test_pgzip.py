@@ -137,3 +137,13 @@ def test_behind_the_input_file(text, tmp_path):
         assert r.returncode == 0, r.stderr
         outs[pg] = r.stdout.split()
     assert outs["1"] == outs["0"] and int(outs["1"][0]) == len(text)
+
+
+def test_text_that_packs_a_thousandfold(tmp_path):
+    """300 MB of runs and repeats in 0.4 MB of gzip, then ordinary text: pieces end early instead of growing with the ratio."""
+    build()
+    rng = np.random.default_rng(3)
+    line = bytes(rng.choice(list(b"ACGT"), 150).tolist()) + b"\n"
+    data = b"\0" * 150_000_000 + line * 1_000_000 + fastq_text(20000, 9)
+    rc, said, got = run(gzip.compress(data, 6), tmp_path, threads=4)
+    assert rc == 0 and got == data

@@ -545,22 +545,24 @@ private:
     }
 
     // One piece further along the chain: window known, bytes and CRC left to a worker, member ends checked.
+    // (damage found here is reported by next_ready once the text before it has been handed out, as zlib would)
+    void fail() { failed_ = true; done_ = true; }
     void step()
     {
-        if (failed_) corrupt();
+        if (failed_) { done_ = true; return; }
         auto piece = std::make_shared<Piece>(take_piece());
-        if (piece->deepest > window_.size()) corrupt();             // a match that reaches before the member's first byte
+        if (piece->deepest > window_.size()) { fail(); return; }    // a match that reaches before the member's first byte
         if (piece->stop == Stop::Error) {                           // what was decoded before the damage is still text: handed out first,
             failed_ = true;                                         // as zlib hands out what it has before it reports the error
             done_ = true;
-            if (piece->sym.empty()) corrupt();
+            if (piece->sym.empty()) return;
         }
         auto window = std::make_shared<std::vector<uint8_t>>(window_);
         // the window after this piece: its last 32 KiB, resolved here (the next piece cannot start without it)
         {
             const size_t n = piece->sym.size();
             std::vector<uint8_t> tail(std::min<size_t>(n, kWindow));
-            if (!resolve(piece->sym, n - tail.size(), n, window_, tail.data())) corrupt();
+            if (!resolve(piece->sym, n - tail.size(), n, window_, tail.data())) { fail(); return; }
             if (tail.size() < kWindow) {
                 const size_t keep = std::min<size_t>(window_.size(), kWindow - tail.size());
                 std::vector<uint8_t> w(window_.end() - static_cast<ptrdiff_t>(keep), window_.end());
@@ -586,11 +588,11 @@ private:
         cur_bit_ = piece->end_bit;
         if (ends_member) {
             uint64_t at = (cur_bit_ + 7) / 8;
-            if (at + 8 > size_) corrupt();
+            if (at + 8 > size_) { fail(); return; }
             const uint8_t* t = in_.base + at;
             want_crc = uint32_t(t[0]) | (uint32_t(t[1]) << 8) | (uint32_t(t[2]) << 16) | (uint32_t(t[3]) << 24);
             const uint32_t isize = uint32_t(t[4]) | (uint32_t(t[5]) << 8) | (uint32_t(t[6]) << 16) | (uint32_t(t[7]) << 24);
-            if (isize != uint32_t(member_bytes_)) corrupt();
+            if (isize != uint32_t(member_bytes_)) { fail(); return; }
             check = true;
             at += 8;
             // what follows: another member, zero padding, or the end
@@ -601,7 +603,7 @@ private:
                 window_.clear(); member_bytes_ = 0;
                 // workers ahead of the new member's start guessed inside the old one or across the seam: the chain decides
             }
-        } else if (cur_bit_ >= in_.bits()) corrupt();                // the stream ends without a final block
+        } else if (cur_bit_ >= in_.bits()) { fail(); return; }       // the stream ends without a final block
         // bytes + CRC of the piece on a worker; the CRCs of a member's pieces are combined in order as they are handed out
         const bool first = first_of_member_;
         first_of_member_ = ends_member;

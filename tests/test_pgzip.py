@@ -35,7 +35,7 @@ def build():
 @pytest.fixture(scope="module")
 def text():
     build()
-    base = fastq_text(30000, 5) * 3                           # ~30 MB: a few dozen chunks of compressed bytes at level 1
+    base = fastq_text(30000, 5) * 2                           # ~21 MB: some seven chunks of compressed bytes
     arr = np.frombuffer(base, dtype=np.uint8).copy()
     rng = np.random.default_rng(1)
     idx = rng.integers(0, len(arr), size=len(arr) // 40)

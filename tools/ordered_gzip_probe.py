@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""The ordered single-end run on an ORDINARY gzip input (host/pgzip.hpp against zlib's gzread):
+  python tools/ordered_gzip_probe.py [--reads 30000000] [--dir /dev/shm/fqd_og]"""
+import argparse
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=30_000_000)
+    ap.add_argument("--dir", default="/dev/shm/fqd_og")
+    a = ap.parse_args()
+    import numpy as np
+    from fastq_dupaway_amd import _lib
+    import config4_at_size as c4
+    d = Path(a.dir); d.mkdir(parents=True, exist_ok=True)
+    n, L = a.reads, 150
+    rng = np.random.default_rng(5)
+    pool = rng.integers(0, 4, size=(n * 8 // 10, L), dtype=np.uint8)                 # 20 % of the reads repeat an earlier one
+    plain = d / "in.fq"
+    with open(plain, "wb") as f:
+        step = 1_000_000
+        for lo in range(0, n, step):
+            cnt = min(step, n - lo)
+            rec = np.empty((cnt, 12 + L + 1 + 2 + L + 1), dtype=np.uint8)
+            rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+            idx = np.arange(lo, lo + cnt, dtype=np.int64)
+            for p in range(9):
+                rec[:, 10 - p] = 48 + (idx % 10); idx //= 10
+            rec[:, 11] = 10
+            pick = rng.integers(0, len(pool), size=cnt)
+            rec[:, 12:12 + L] = np.frombuffer(b"ACGT", dtype=np.uint8)[pool[pick]]
+            rec[:, 12 + L] = 10; rec[:, 13 + L] = ord("+"); rec[:, 14 + L] = 10
+            rec[:, 15 + L:15 + 2 * L] = ord("I"); rec[:, 15 + 2 * L] = 10
+            f.write(rec.tobytes())
+    gz = d / "in.fq.gz"
+    c4.ordinary_gzip(plain, gz)
+    print(f"{plain.stat().st_size / 1e9:.2f} GB of FASTQ -> {gz.stat().st_size / 1e9:.2f} GB of ordinary gzip", flush=True)
+    plain.unlink()
+    said = {}
+    for pg in ("1", "0"):
+        out = d / f"out{pg}.fq"
+        out.unlink(missing_ok=True)
+        t0 = time.perf_counter()
+        r = subprocess.run([str(_lib.CLI_PATH), "-i", str(gz), "-o", str(out), "--fast", "-v"], capture_output=True, text=True, env=dict(os.environ, FQD_PGZIP=pg))
+        dt = time.perf_counter() - t0
+        said[pg] = (r.returncode, r.stdout, out.stat().st_size)
+        print(f"FQD_PGZIP={pg}: rc={r.returncode} {dt:.2f} s = {n / dt / 1e6:.2f} M reads/s | {r.stdout.strip()}", flush=True)
+    print("same lines and output size:", said["1"] == said["0"])
+    for f in d.iterdir():
+        f.unlink()
+
+
+if __name__ == "__main__":
+    main()

@@ -376,6 +376,20 @@ def end_to_end(a, torch, bases, expect, L):
         packer.unlink(missing_ok=True)
     except Exception as ex:
         res["gz"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    # and as an ORDINARY gzip file (no member sizes: what gzip, pigz and sequencers write) in, a plain file out: inflated on
+    # the host by several threads from guessed block starts (host/pgzip.hpp)
+    try:
+        og_src, og_dst = d / "in_ordinary.fq.gz", d / "out_ordinary.fq"
+        subprocess.run([sys.executable, str(ROOT / "tools" / "config4_at_size.py"), "--gzip-helper", str(src), str(og_src)], check=True)
+        t0 = time.perf_counter()
+        ro = subprocess.run([str(_lib.CLI_PATH), "-i", str(og_src), "-o", str(og_dst), "--fast", "-v"], capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        same = ro.returncode == 0 and ro.stdout == expected_line and og_dst.stat().st_size == (n - dups) * rec_len
+        res["ordinary_gzip"] = {"value": round(n / dt / 1e6, 2), "unit": "Mreads/s", "seconds": [round(dt, 3)],
+                                "what": f"the same reads as an ordinary gzip file in ({og_src.stat().st_size / 1e9:.2f} GB, members of 256 MB of text without BGZF fields), plain file out",
+                                "parity": "-v line and output size == closed form" if same else f"MISMATCH rc={ro.returncode} {ro.stdout!r} {ro.stderr[-300:]!r}"}
+    except Exception as ex:
+        res["ordinary_gzip"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if not a.e2e_dir:
         shutil.rmtree(d, ignore_errors=True)
     return res

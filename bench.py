@@ -6,9 +6,10 @@ resident in HBM: empty the set, encode + insert every read, produce keep flags.
   N = 1 : BASELINE.json configs[1] — 100 M single-end 150 bp reads, ~20 % duplicates (the headline),
           and beside it in the same JSON line: configs[2] (100 M pairs 2x150 bp, `pe`), the
           PCIe-inclusive rate (`pcie_inclusive`: sequences start in pinned host memory) and the
-          end-to-end rate of the CLI, FASTQ file in -> FASTQ file out (`end_to_end`).
+          end-to-end rate of the CLI, FASTQ file in -> FASTQ file out (`end_to_end`; `.gz`: BGZF in, .gz out;
+          `.ordinary_gzip`: a gzip file without member sizes in; `end_to_end_unordered` likewise for --unordered).
   N > 1 : weak scaling, the same per-GPU batch on every rank; reads are sharded by hash
-          prefix with an all-to-all over RCCL (fastq-dupaway_amd/sharded.py).
+          prefix with an all-to-all over RCCL (the library's shard group: csrc/fqd_shard.hip, fastq-dupaway_amd/shard.py).
   --config se|pe|sharded1 : only that device-phase measurement (sharded1 = the N > 1 path
           rehearsed on one rank under RCCL).
 Launch: python bench.py [--gpus N --steps K --warmup W].  With N > 1 and no launcher around it the script

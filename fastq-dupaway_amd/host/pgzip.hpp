@@ -219,7 +219,8 @@ inline void decode_piece(const BitIn& in, uint64_t pos, uint64_t stop_bit, Piece
         uint64_t w = in.window(pos);
         const int last = int(w & 1), type = int((w >> 1) & 3);
         // (a piece also ends where it has grown large — text that packs a thousandfold would otherwise be held whole, twice)
-        if (!last && type == 2 && pos != out.start_bit && (pos >= stop_bit || sym.size() >= kMaxPiece)) { out.end_bit = pos; out.stop = Stop::Boundary; return; }
+        //  — at whatever kind of block: a file of stored blocks has no other)
+        if (pos != out.start_bit && ((!last && type == 2 && pos >= stop_bit) || sym.size() >= kMaxPiece)) { out.end_bit = pos; out.stop = Stop::Boundary; return; }
         pos += 3;
         if (type == 3) return;
         if (type == 0) {

@@ -147,3 +147,7 @@ def test_text_that_packs_a_thousandfold(tmp_path):
     data = b"\0" * 150_000_000 + line * 1_000_000 + fastq_text(20000, 9)
     rc, said, got = run(gzip.compress(data, 6), tmp_path, threads=4)
     assert rc == 0 and got == data
+    # and a stream of stored blocks only, longer than a piece may grow: it has no block a worker would look for
+    noise = np.random.default_rng(4).integers(0, 256, size=60_000_000, dtype=np.uint8).tobytes()
+    rc, said, got = run(gzip.compress(noise, 0), tmp_path, threads=4)
+    assert rc == 0 and got == noise

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <future>
@@ -429,7 +430,7 @@ public:
     // throws std::invalid_argument where this reader does not apply (the caller reads the file with zlib then)
     // crc: CRC-32 of a buffer continued from a value, as zlib's crc32 (nullptr: zlib's; libdeflate's is several times faster)
     using CrcFn = uint32_t (*)(uint32_t, const void*, size_t);
-    Reader(int fd, uint64_t size, unsigned threads, CrcFn crc = nullptr) : size_(size), threads_(std::min(8u, std::max(2u, threads))), crc_(crc)
+    Reader(int fd, uint64_t size, unsigned threads, CrcFn crc = nullptr) : size_(size), threads_(std::min(most_threads(), std::max(2u, threads))), crc_(crc)
     {
         void* m = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
         if (m == MAP_FAILED) throw std::invalid_argument("mmap");
@@ -448,6 +449,13 @@ public:
         for (auto& f : ahead_) if (f.second.valid()) f.second.wait();
         for (auto& f : ready_) if (f.valid()) f.wait();
         ::munmap(const_cast<uint8_t*>(in_.base), size_);
+    }
+    // pieces decoded ahead (and as many being turned into bytes): FQD_PGZIP_THREADS, 8 unless told otherwise — two files read
+    // side by side then fill the 16 cores a GPU box gives a job
+    static unsigned most_threads()
+    {
+        static const unsigned n = [] { const char* v = std::getenv("FQD_PGZIP_THREADS"); const int x = v ? std::atoi(v) : 0; return x >= 2 ? unsigned(x) : 8u; }();
+        return n;
     }
     Reader(const Reader&) = delete;
     Reader& operator=(const Reader&) = delete;

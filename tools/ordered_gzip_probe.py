@@ -46,15 +46,18 @@ def main():
     print(f"{plain.stat().st_size / 1e9:.2f} GB of FASTQ -> {gz.stat().st_size / 1e9:.2f} GB of ordinary gzip", flush=True)
     plain.unlink()
     said = {}
-    for pg in ("1", "0"):
-        out = d / f"out{pg}.fq"
+    for pg in ("1", "1:12", "1:16", "1:4", "0"):
+        out = d / f"out{pg[0]}.fq"
         out.unlink(missing_ok=True)
+        env = dict(os.environ, FQD_PGZIP=pg[0])
+        if ":" in pg:
+            env["FQD_PGZIP_THREADS"] = pg.split(":")[1]
         t0 = time.perf_counter()
-        r = subprocess.run([str(_lib.CLI_PATH), "-i", str(gz), "-o", str(out), "--fast", "-v"], capture_output=True, text=True, env=dict(os.environ, FQD_PGZIP=pg))
+        r = subprocess.run([str(_lib.CLI_PATH), "-i", str(gz), "-o", str(out), "--fast", "-v"], capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t0
         said[pg] = (r.returncode, r.stdout, out.stat().st_size)
-        print(f"FQD_PGZIP={pg}: rc={r.returncode} {dt:.2f} s = {n / dt / 1e6:.2f} M reads/s | {r.stdout.strip()}", flush=True)
-    print("same lines and output size:", said["1"] == said["0"])
+        print(f"FQD_PGZIP={pg} (reader on/off[:threads]): rc={r.returncode} {dt:.2f} s = {n / dt / 1e6:.2f} M reads/s | {r.stdout.strip()}", flush=True)
+    print("same lines and output size:", len(set(said.values())) == 1)
     for f in d.iterdir():
         f.unlink()
 

@@ -31,6 +31,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 #include <sys/mman.h>
 #include <zlib.h>
@@ -466,7 +467,7 @@ public:
         while (got < n) {
             if (have_pos_ < have_.size) {
                 const size_t k = std::min(n - got, have_.size - have_pos_);
-                std::memcpy(dst + got, have_.bytes.data() + have_pos_, k);
+                copy_out(dst + got, have_.bytes.data() + have_pos_, k);
                 have_pos_ += k; got += k;
                 continue;
             }
@@ -476,6 +477,17 @@ public:
     }
 
 private:
+    // The text leaves through this one thread: megabytes at a time are copied by four (one core moves 8-10 GB/s, which
+    // is what eight decoding threads make).
+    static void copy_out(char* dst, const uint8_t* src, size_t n)
+    {
+        if (n < (size_t(2) << 20)) { std::memcpy(dst, src, n); return; }
+        constexpr size_t T = 4;
+        std::thread helper[T - 1];
+        for (size_t t = 1; t < T; ++t) helper[t - 1] = std::thread([=] { const size_t a = n / T * t, b = t + 1 == T ? n : n / T * (t + 1); std::memcpy(dst + a, src + a, b - a); });
+        std::memcpy(dst, src, n / T);
+        for (std::thread& h : helper) h.join();
+    }
     static constexpr uint64_t kChunkBits = uint64_t(1) << 23;       // 1 MiB of compressed bytes per chunk
 
     [[noreturn]] static void corrupt() { throw std::runtime_error("gzip input is corrupt or truncated"); }

@@ -107,6 +107,8 @@ def load_library():
     L.fqd_engine_reset.argtypes = [vp]
     L.fqd_submit.argtypes = [vp, C.POINTER(ReadsDesc), u64, i32, vp]
     L.fqd_engine_sync.argtypes = [vp]
+    L.fqd_engine_wait_stream.argtypes = [vp, vp]
+    L.fqd_stream_wait_engine.argtypes = [vp, vp]
     L.fqd_engine_stream.argtypes = [vp]
     L.fqd_engine_stream.restype = vp
     L.fqd_bad_base.argtypes = [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint8)]

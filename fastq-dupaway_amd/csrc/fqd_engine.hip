@@ -46,6 +46,7 @@ struct fqd_engine {
     hipStream_t  aux = nullptr;                      // encoder side of the encode/insert overlap
     std::vector<hipEvent_t> sync_events;             // untimed events for cross-stream ordering
     size_t       sync_next = 0;
+    hipEvent_t   order_event = nullptr;              // fqd_engine_wait_stream / fqd_stream_wait_engine
     int          n_cu = 256;
     uint64_t     chunk_reads = 8u << 20;             // sub-batch of the overlapped pipeline
     uint32_t     enc_blocks_per_cu = 4, ins_blocks_per_cu = 4;
@@ -694,6 +695,7 @@ int fqd_engine_destroy(fqd_engine* e)
     if (e->aux) (void)hipStreamSynchronize(e->aux);
     for (hipEvent_t ev : e->free_events) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
+    if (e->order_event) (void)hipEventDestroy(e->order_event);
     if (e->aux) (void)hipStreamDestroy(e->aux);
     release(e->table); release(e->keys); release(e->koff); release(e->hashes);
     release(e->scan_scratch); release(e->part_scratch); release(e->pad_koff); release(e->slab_records); release(e->st_keep); release(e->bulk_recs); release(e->bulk_meta);
@@ -868,6 +870,21 @@ int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint
 {
     return submit_impl(e, seg, n, memory, keep);
 }
+
+// An event recorded on `from`, waited for by `to`: a later record of the same event does not move a wait already queued.
+static int order_streams(fqd_engine* e, hipStream_t from, hipStream_t to)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (from == to) return FQD_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (!e->order_event) HIP_TRY(e, hipEventCreateWithFlags(&e->order_event, hipEventDisableTiming));
+    HIP_TRY(e, hipEventRecord(e->order_event, from));
+    HIP_TRY(e, hipStreamWaitEvent(to, e->order_event, 0));
+    return FQD_OK;
+}
+
+int fqd_engine_wait_stream(fqd_engine* e, void* stream) { return e ? order_streams(e, static_cast<hipStream_t>(stream), e->stream) : FQD_ERR_ARG; }
+int fqd_stream_wait_engine(fqd_engine* e, void* stream) { return e ? order_streams(e, e->stream, static_cast<hipStream_t>(stream)) : FQD_ERR_ARG; }
 
 int fqd_engine_sync(fqd_engine* e)
 {

@@ -38,15 +38,10 @@ def _addr(x) -> Optional[int]:
     return x.data_ptr()          # torch tensor
 
 
-def _desc_array(segs: Sequence[Reads]):
-    arr = (_lib.ReadsDesc * 2)()
-    for k, s in enumerate(segs):
-        arr[k].bases = _addr(s.bases)
-        arr[k].offsets = _addr(s.offsets)
-        arr[k].lengths = _addr(s.lengths)
-        arr[k].uniform_len = s.uniform_len
-        arr[k].uniform_stride = s.uniform_stride
-    return arr
+def _torch_stream(x) -> int:
+    """hipStream_t (as an integer) of torch's current stream on the tensor's device."""
+    import torch
+    return int(torch.cuda.current_stream(x.device).cuda_stream)
 
 
 class Engine:
@@ -64,6 +59,7 @@ class Engine:
         if rc != _lib.OK:
             raise FqdError(rc, (self._L.fqd_last_error(None) or b"").decode())
         self._h = h
+        self._ordered = False
         self.segments = segments
 
     # -- lifecycle ----------------------------------------------------------------
@@ -84,7 +80,52 @@ class Engine:
         except Exception:
             pass
 
+    # -- ordering against the caller's stream ------------------------------------------
+    # The engine runs on its own non-blocking stream and waits for nobody (include/fqdupaway.h, ORDERING RULE): whatever
+    # torch queued for a tensor on ITS stream (zeros, fill_, copy_) must be ordered before the engine's work explicitly.
+    # The first torch tensor among a call's arguments makes the engine wait for torch's current stream; arguments are
+    # evaluated before the C function runs, so the wait is queued ahead of the call's kernels.
+    def _p(self, x) -> Optional[int]:
+        if x is None:
+            return None
+        if isinstance(x, np.ndarray):
+            return x.ctypes.data
+        if isinstance(x, int):
+            return x
+        if not self._ordered:
+            self._ordered = True
+            rc = self._L.fqd_engine_wait_stream(self._h, _torch_stream(x))
+            if rc != _lib.OK:
+                self._ordered = False
+                raise FqdError(rc, (self._L.fqd_last_error(self._h) or b"").decode())
+        return x.data_ptr()
+
+    def _desc(self, segs: Sequence[Reads]):
+        arr = (_lib.ReadsDesc * 2)()
+        for k, s in enumerate(segs):
+            arr[k].bases = self._p(s.bases)
+            arr[k].offsets = self._p(s.offsets)
+            arr[k].lengths = self._p(s.lengths)
+            arr[k].uniform_len = s.uniform_len
+            arr[k].uniform_stride = s.uniform_stride
+        return arr
+
+    def wait_stream(self, stream: Optional[int] = None):
+        """The engine starts after everything queued so far on `stream` (default: torch's current stream)."""
+        if stream is None:
+            import torch
+            stream = int(torch.cuda.current_stream().cuda_stream)
+        self._check(self._L.fqd_engine_wait_stream(self._h, stream))
+
+    def release_to(self, stream: Optional[int] = None):
+        """`stream` (default: torch's current stream) continues after everything the engine has queued so far."""
+        if stream is None:
+            import torch
+            stream = int(torch.cuda.current_stream().cuda_stream)
+        self._check(self._L.fqd_stream_wait_engine(self._h, stream))
+
     def _check(self, rc: int):
+        self._ordered = False
         if rc != _lib.OK:
             raise FqdError(rc, (self._L.fqd_last_error(self._h) or b"").decode())
 
@@ -116,7 +157,7 @@ class Engine:
             keep = np.empty(n, dtype=np.uint8) if keep is None else keep
         elif keep is None:
             raise ValueError("device submits need a device keep buffer")
-        rc = self._L.fqd_submit(self._h, _desc_array(segs), n, _lib.MEM_HOST if host else _lib.MEM_DEVICE, _addr(keep))
+        rc = self._L.fqd_submit(self._h, self._desc(segs), n, _lib.MEM_HOST if host else _lib.MEM_DEVICE, self._p(keep))
         self._check(rc)
         return keep
 
@@ -143,11 +184,11 @@ class Engine:
         return int(self._L.fqd_key_words(len0, len1))
 
     def encode_uniform(self, segs: Sequence[Reads], n: int, records):
-        self._check(self._L.fqd_encode_uniform(self._h, _desc_array(segs), n, _addr(records)))
+        self._check(self._L.fqd_encode_uniform(self._h, self._desc(segs), n, self._p(records)))
 
     def partition_keys(self, records, n: int, key_words: int, n_parts: int, out_keys, counts, origin):
-        self._check(self._L.fqd_partition_keys(self._h, _addr(records), n, key_words, n_parts,
-                                               _addr(out_keys), _addr(counts), _addr(origin)))
+        self._check(self._L.fqd_partition_keys(self._h, self._p(records), n, key_words, n_parts,
+                                               self._p(out_keys), self._p(counts), self._p(origin)))
 
     def reserve_keys(self, n: int, len0: int, len1: int) -> int:
         """Device address of room for n keys at the tail of the key store (receive in place)."""
@@ -156,46 +197,45 @@ class Engine:
         return slot.value
 
     def insert_keys(self, keys, n: int, len0: int, len1: int, keep):
-        self._check(self._L.fqd_insert_keys(self._h, _addr(keys), n, len0, len1, _addr(keep)))
+        self._check(self._L.fqd_insert_keys(self._h, self._p(keys), n, len0, len1, self._p(keep)))
 
     def partition_slabs(self, records, n: int, key_words: int, n_parts: int, slab_cap: int, out_keys, counts, origin):
-        self._check(self._L.fqd_partition_slabs(self._h, _addr(records), n, key_words, n_parts, slab_cap,
-                                                _addr(out_keys), _addr(counts), _addr(origin)))
+        self._check(self._L.fqd_partition_slabs(self._h, self._p(records), n, key_words, n_parts, slab_cap,
+                                                self._p(out_keys), self._p(counts), self._p(origin)))
 
     def encode_slabs(self, segs: Sequence[Reads], n: int, n_parts: int, chunk_reads: int, n_chunks: int, sub_cap: int, out_keys,
                      chunk_counts, totals, origin, exact: bool = False):
-        self._check(self._L.fqd_encode_slabs(self._h, _desc_array(segs), n, n_parts, chunk_reads, n_chunks, sub_cap, _addr(out_keys),
-                                             _addr(chunk_counts), _addr(totals), _addr(origin), 1 if exact else 0))
+        self._check(self._L.fqd_encode_slabs(self._h, self._desc(segs), n, n_parts, chunk_reads, n_chunks, sub_cap, self._p(out_keys),
+                                             self._p(chunk_counts), self._p(totals), self._p(origin), 1 if exact else 0))
 
     def insert_slabs(self, keys, n_slabs: int, slab_cap: int, slab_count, len0: int, len1: int, keep):
-        self._check(self._L.fqd_insert_slabs(self._h, _addr(keys), n_slabs, slab_cap, _addr(slab_count), len0, len1, _addr(keep)))
+        self._check(self._L.fqd_insert_slabs(self._h, self._p(keys), n_slabs, slab_cap, self._p(slab_count), len0, len1, self._p(keep)))
 
     # -- --unordered ID join ---------------------------------------------------------------
-    @staticmethod
-    def _tags(bytes_, offsets, lengths, n):
-        return _lib.TagsDesc(bytes=_addr(bytes_), offsets=_addr(offsets), lengths=_addr(lengths), n=n)
+    def _tags(self, bytes_, offsets, lengths, n):
+        return _lib.TagsDesc(bytes=self._p(bytes_), offsets=self._p(offsets), lengths=self._p(lengths), n=n)
 
     def sort_tags(self, bytes_, offsets, lengths, n: int, perm):
         t = self._tags(bytes_, offsets, lengths, n)
-        self._check(self._L.fqd_sort_tags(self._h, C.byref(t), _addr(perm)))
+        self._check(self._L.fqd_sort_tags(self._h, C.byref(t), self._p(perm)))
 
     def extract_tags(self, text, id_start, id_len, n: int, tag_off, tag_len):
-        self._check(self._L.fqd_extract_tags(self._h, _addr(text), _addr(id_start), _addr(id_len), n, _addr(tag_off), _addr(tag_len)))
+        self._check(self._L.fqd_extract_tags(self._h, self._p(text), self._p(id_start), self._p(id_len), n, self._p(tag_off), self._p(tag_len)))
 
     def join_tags(self, a, b, perm_a, perm_b, match_a, match_b, pair_a, pair_b) -> int:
         """a, b = (bytes, offsets, lengths, n); returns the number of pairs (the call drains the stream)."""
         ta, tb = self._tags(*a), self._tags(*b)
         n_pairs = C.c_uint64(0)
-        out = _lib.JoinDesc(perm_a=_addr(perm_a), perm_b=_addr(perm_b), match_a=_addr(match_a), match_b=_addr(match_b),
-                            pair_a=_addr(pair_a), pair_b=_addr(pair_b), n_pairs=C.pointer(n_pairs))
+        out = _lib.JoinDesc(perm_a=self._p(perm_a), perm_b=self._p(perm_b), match_a=self._p(match_a), match_b=self._p(match_b),
+                            pair_a=self._p(pair_a), pair_b=self._p(pair_b), n_pairs=C.pointer(n_pairs))
         self._check(self._L.fqd_join_tags(self._h, C.byref(ta), C.byref(tb), C.byref(out)))
         return int(n_pairs.value)
 
     def gather_seqs(self, idx, n: int, off_table, len_table, off_out, len_out):
-        self._check(self._L.fqd_gather_seqs(self._h, _addr(idx), n, _addr(off_table), _addr(len_table), _addr(off_out), _addr(len_out)))
+        self._check(self._L.fqd_gather_seqs(self._h, self._p(idx), n, self._p(off_table), self._p(len_table), self._p(off_out), self._p(len_out)))
 
     def copy_spans(self, src, src_off, lens, n: int, dst, dst_off):
-        self._check(self._L.fqd_copy_spans(self._h, _addr(src), _addr(src_off), _addr(lens), n, _addr(dst), _addr(dst_off)))
+        self._check(self._L.fqd_copy_spans(self._h, self._p(src), self._p(src_off), self._p(lens), n, self._p(dst), self._p(dst_off)))
 
     def bgzf_bound(self, n: int) -> int:
         return int(self._L.fqd_bgzf_bound(n))
@@ -204,26 +244,26 @@ class Engine:
         """BGZF members for the n bytes at src (device) written to dst (device, >= bgzf_bound(n) bytes);
         returns their total size.  The end-of-file marker is the caller's to append."""
         total = C.c_uint64(0)
-        self._check(self._L.fqd_bgzf_deflate(self._h, _addr(src), n, lines_per_record, _addr(dst), dst.numel(), C.byref(total)))
+        self._check(self._L.fqd_bgzf_deflate(self._h, self._p(src), n, lines_per_record, self._p(dst), dst.numel(), C.byref(total)))
         return int(total.value)
 
     def bgzf_inflate(self, comp, comp_off, comp_len, out_off, out_len, crc, n_members: int, text) -> int:
         """Members (device arrays describing them) of the BGZF bytes at comp inflated into text; returns the number
         of members that failed (damaged stream, wrong size or CRC)."""
         bad = C.c_uint64(0)
-        self._check(self._L.fqd_bgzf_inflate(self._h, _addr(comp), _addr(comp_off), _addr(comp_len), _addr(out_off), _addr(out_len),
-                                             _addr(crc), n_members, _addr(text), C.byref(bad)))
+        self._check(self._L.fqd_bgzf_inflate(self._h, self._p(comp), self._p(comp_off), self._p(comp_len), self._p(out_off), self._p(out_len),
+                                             self._p(crc), n_members, self._p(text), C.byref(bad)))
         return int(bad.value)
 
     def count_lines(self, text, n: int) -> int:
         lines = C.c_uint64(0)
-        self._check(self._L.fqd_count_lines(self._h, _addr(text), n, C.byref(lines)))
+        self._check(self._L.fqd_count_lines(self._h, self._p(text), n, C.byref(lines)))
         return int(lines.value)
 
     def scan_records(self, text, n: int, lines_per_record: int, n_records: int, start, seq_off, id_len, seq_len, size) -> bool:
         ok = C.c_int(0)
-        self._check(self._L.fqd_scan_records(self._h, _addr(text), n, lines_per_record, n_records, _addr(start), _addr(seq_off),
-                                             _addr(id_len), _addr(seq_len), _addr(size), C.byref(ok)))
+        self._check(self._L.fqd_scan_records(self._h, self._p(text), n, lines_per_record, n_records, self._p(start), self._p(seq_off),
+                                             self._p(id_len), self._p(seq_len), self._p(size), C.byref(ok)))
         return bool(ok.value)
 
     def count_tags_le(self, t, other, other_index: int) -> int:
@@ -235,18 +275,18 @@ class Engine:
 
     def output_offsets(self, keep, idx, n: int, sizes, dest) -> int:
         total = C.c_uint64(0)
-        self._check(self._L.fqd_output_offsets(self._h, _addr(keep), _addr(idx), n, _addr(sizes), _addr(dest), C.byref(total)))
+        self._check(self._L.fqd_output_offsets(self._h, self._p(keep), self._p(idx), n, self._p(sizes), self._p(dest), C.byref(total)))
         return int(total.value)
 
     def output_plan(self, keep, idx, n: int, starts, sizes, src_off, lens, dst_off) -> int:
         total = C.c_uint64(0)
-        self._check(self._L.fqd_output_plan(self._h, _addr(keep), _addr(idx), n, _addr(starts), _addr(sizes),
-                                            _addr(src_off), _addr(lens), _addr(dst_off), C.byref(total)))
+        self._check(self._L.fqd_output_plan(self._h, self._p(keep), self._p(idx), n, self._p(starts), self._p(sizes),
+                                            self._p(src_off), self._p(lens), self._p(dst_off), C.byref(total)))
         return int(total.value)
 
     def scatter_flags(self, flags, origin, n: int, keep_out):
-        self._check(self._L.fqd_scatter_flags(self._h, _addr(flags), _addr(origin), n, _addr(keep_out)))
+        self._check(self._L.fqd_scatter_flags(self._h, self._p(flags), self._p(origin), n, self._p(keep_out)))
 
     def synth_reads(self, seed: int, first: int, n: int, length: int, dup_permille: int, mate: int, bases, expect_keep=None):
         self._check(self._L.fqd_synth_reads(self._h, seed, first, n, length, dup_permille, mate,
-                                            _addr(bases), _addr(expect_keep)))
+                                            self._p(bases), self._p(expect_keep)))

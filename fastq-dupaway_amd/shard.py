@@ -6,7 +6,7 @@ from typing import Optional, Sequence
 
 from . import _lib
 from ._lib import FqdError, load_library
-from .engine import Engine, Reads, _addr
+from .engine import Engine, Reads
 
 
 def unique_id() -> bytes:
@@ -53,13 +53,16 @@ class ShardGroup:
         nl = len(self.engines)
         arr = (_lib.ReadsDesc * (nl * self.S))()
         for r in range(nl):
+            p = self.engines[r]._p                   # orders rank r's engine after torch's stream (ORDERING RULE of the header)
             for m in range(self.S):
                 s = segs[r][m]
                 d = arr[r * self.S + m]
-                d.bases, d.offsets, d.lengths = _addr(s.bases), _addr(s.offsets), _addr(s.lengths)
+                d.bases, d.offsets, d.lengths = p(s.bases), p(s.offsets), p(s.lengths)
                 d.uniform_len, d.uniform_stride = s.uniform_len, s.uniform_stride
         ns = (C.c_uint64 * nl)(*[int(x) for x in n])
-        ks = (C.c_void_p * nl)(*[_addr(k) for k in keep])
+        ks = (C.c_void_p * nl)(*[self.engines[r]._p(k) for r, k in enumerate(keep)])
+        for e in self.engines:
+            e._ordered = False
         self._check(self._L.fqd_shard_round(self._h, arr, ns, ks))
         self.rounds += 1
         return self.rounds - 1

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FQD_ABI_VERSION 4
+#define FQD_ABI_VERSION 5
 
 /* status codes */
 #define FQD_OK              0
@@ -112,7 +112,8 @@ int  fqd_engine_reset(fqd_engine* e);
  * record i (input order continues across calls) is the first with its key,
  * else 0.  `seg` points at cfg.segments descriptors.  `memory` says where
  * bases/offsets/lengths/keep live.  Device-space calls are asynchronous on
- * the engine's stream and keep must stay valid until fqd_engine_sync();
+ * the engine's stream (the buffers must be complete on it: see the ORDERING RULE
+ * at fqd_engine_wait_stream) and keep must stay valid until fqd_engine_sync();
  * host-space calls return with keep filled.  Flags of a batch are final when
  * it completes: later batches cannot change them. */
 int  fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep);
@@ -120,6 +121,17 @@ int  fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uin
 /* The hipStream_t the engine launches on (its own, or the one given in fqd_config), so a caller
  * can order its own work — copies, collectives — against the engine's with events. */
 void* fqd_engine_stream(fqd_engine* e);
+
+/* ORDERING RULE.  The engine runs on its own non-blocking stream (unless fqd_config.stream gave it the caller's) and
+ * waits for nobody: a device buffer handed to any entry point of this header must be COMPLETE on the engine's stream
+ * when the call is made — a fill, copy or kernel the caller queued on another stream (the null stream included) is
+ * not ordered against the engine's work by itself and may land after it.  Two ways to order, besides a device-wide
+ * synchronise: fqd_engine_wait_stream() before handing buffers over ("the engine starts after everything queued on
+ * `stream` so far"), and fqd_stream_wait_engine() before the caller's stream reads what the engine wrote ("`stream`
+ * continues after everything the engine has queued so far").  Both are an event record plus a stream wait: nothing
+ * blocks on the host.  `stream` is a hipStream_t; NULL = the null stream. */
+int  fqd_engine_wait_stream(fqd_engine* e, void* stream);
+int  fqd_stream_wait_engine(fqd_engine* e, void* stream);
 
 /* Waits for the stream and surfaces deferred errors (FQD_ERR_BAD_BASE). */
 int  fqd_engine_sync(fqd_engine* e);

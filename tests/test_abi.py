@@ -28,7 +28,7 @@ def test_header_symbols_are_all_exported(lib):
 
 
 def test_abi_version_and_key_words(lib):
-    assert lib.fqd_abi_version() == 4
+    assert lib.fqd_abi_version() == 5
     # words(L) = ceil(L/32) + ceil(L/64): 150 bp -> 8 words = 64 B; pairs add up
     assert lib.fqd_key_words(150, 0) == 8
     assert lib.fqd_key_words(150, 150) == 16

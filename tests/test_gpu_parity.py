@@ -495,3 +495,48 @@ def test_capacity_limit_and_allocation_failure_are_errors_not_crashes(oracle):
     assert err.value.code == _lib.ERR_HIP and "hipMalloc" in err.value.message
     with Engine(segments=1) as e:
         assert np.array_equal(e.submit([Reads(data, offs, lens)], len(reads)), oracle.dedup_single(data, offs, lens))
+
+
+# ---- ordering against a caller's stream (include/fqdupaway.h, ORDERING RULE) ---------------------
+
+def test_engine_orders_itself_after_the_callers_stream(torch_cuda):
+    """Round 3's red GPU run: a buffer torch had just zero-filled on ITS stream was handed to the engine, whose own
+    non-blocking stream ran first, and the fill wiped the kernels' output.  fqd_engine_wait_stream closes that: here
+    the caller's stream is kept busy with a long queue of large fills of the very buffers the engine is about to
+    write, with no host synchronisation anywhere in between; every round must still read back the engine's values.
+    fqd_stream_wait_engine is the other direction: torch reads the flags on its stream without a host wait."""
+    torch = torch_cuda
+    import ctypes as C
+    from fastq_dupaway_amd import _lib
+    L = fqd.load_library()
+    dev = torch.device("cuda", 0)
+    n, LL = 4_000_000, 150
+    with Engine(segments=1) as e:
+        bases = torch.empty(n * LL + 16, dtype=torch.uint8, device=dev)
+        expect = torch.empty(n, dtype=torch.uint8, device=dev)
+        e.synth_reads(5, 0, n, LL, 200, 0, bases, expect)
+        e.sync()
+        ballast = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        keep = torch.empty(n, dtype=torch.uint8, device=dev)
+        seg = (_lib.ReadsDesc * 2)()
+        seg[0].bases, seg[0].uniform_len, seg[0].uniform_stride = bases.data_ptr(), LL, LL
+        for step in range(3):
+            e.reset()
+            for _ in range(8):
+                ballast.fill_(step)                      # ≈1 ms of work ahead of the fill below on torch's stream
+            keep.fill_(7)                                # must land BEFORE the engine's flags, not after
+            stream = int(torch.cuda.current_stream(dev).cuda_stream)
+            assert L.fqd_engine_wait_stream(e._h, stream) == _lib.OK          # the raw ABI, not the binding's helper
+            assert L.fqd_submit(e._h, seg, n, _lib.MEM_DEVICE, keep.data_ptr()) == _lib.OK
+            assert L.fqd_stream_wait_engine(e._h, stream) == _lib.OK
+            same = bool(torch.equal(keep, expect))       # on torch's stream, ordered after the engine by the event only
+            assert same, f"step {step}: {int((keep != expect).sum())} flags differ ({int((keep == 7).sum())} still hold the fill)"
+        # the binding does the first half by itself for every tensor it is handed
+        e.reset()
+        for _ in range(8):
+            ballast.fill_(9)
+        keep.fill_(7)
+        e.submit([Reads(bases, uniform_len=LL, uniform_stride=LL)], n, keep)
+        e.release_to()
+        assert torch.equal(keep, expect)
+        assert L.fqd_engine_wait_stream(None, None) == _lib.ERR_ARG and L.fqd_stream_wait_engine(None, None) == _lib.ERR_ARG

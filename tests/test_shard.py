@@ -210,7 +210,11 @@ def test_partition_is_stable_and_complete():
         assert np.array_equal(keys.cpu().numpy().view(np.uint64).reshape(n, W), r[order][:, 1:])
         for cap in (20000, 9000, 16):                         # roomy slabs; slabs that spill a little; nearly everything spills
             slots = parts * cap + n
+            # torch fills these on ITS stream; the binding orders the engine's stream after it (fqd_engine_wait_stream) —
+            # round 3's red run was this fill landing after the kernels' output.  counts is poisoned so that the check
+            # below cannot pass on what partition_keys left there.
             skeys = torch.zeros(slots * W, dtype=torch.int64, device=dev); sorigin = torch.zeros(slots, dtype=torch.int32, device=dev)
+            counts.fill_(-5)
             e.partition_slabs(rec, n, W, parts, cap, skeys, counts, sorigin)
             e.sync()
             assert np.array_equal(counts.cpu().numpy(), true_counts)

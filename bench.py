@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--e2e-pairs", type=int, default=4_000_000, help="pairs of the end-to-end --unordered CLI run (0 = skip)")
     ap.add_argument("--e2e-dir", default="", help="where the end-to-end FASTQ files go (default: a temp dir under /tmp)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-final", action="store_true", help="A/B: plain fqd_submit instead of fqd_submit_final (the set is written back to HBM although nobody reads it)")
     return ap.parse_args()
 
 
@@ -152,8 +153,9 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
             sharded.flush()
     else:
         def step():
+            # one batch per reset: the job IS its last batch, and says so (fqd_submit_final), like the CLI's resident runs do
             eng.reset()
-            eng.submit(segs, n, keep=keep)
+            eng.submit(segs, n, keep=keep, final=not a.no_final)
             eng.sync()
 
     def fence():
@@ -255,6 +257,8 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
                                        f"{n} {what} x {L} bp per GPU"),
                           "input": "150-byte sequence lines extracted from the FASTQ records, resident in HBM when the timed region starts",
                           "reads_per_gpu": n, "read_len": L, "dup_fraction": a.dup_permille / 1000.0,
+                          "batches_per_step": 1 if not sharded_mode else rounds,
+                          "last_batch_declared": bool(not sharded_mode and not a.no_final),
                           "sharding": "none" if not sharded_mode else
                                       (f"hash-prefix sharding over {job_world} rank(s)" + (f" sharing this GPU ({n_rank} reads each)" if sharded_mode == "virtual" else f" = {world} GPU(s), one process each")
                                        + f", fixed-size all-to-all slabs, {rounds} round(s) of {m} reads per rank and step")},
@@ -352,6 +356,38 @@ def end_to_end(a, torch, bases, expect, L):
            "size_note": (f"{n} of the workload's {a.reads} reads: the full size needs about 70 GB of scratch files and four more minutes "
                          f"(python bench.py --e2e-reads {a.reads} [--e2e-dir DIR]; profiles/r03_bench_e2e_100m_reads.json is such a run)") if n < a.reads else "the workload's full size",
            "parity": "-v line and output size == closed form" if ok else f"MISMATCH rc={out.returncode} {out.stdout!r} {out.stderr[-300:]!r}"}
+    # the CPU baseline SURVEY §8(d) specifies, beside it: the oracle's FILE driver (500 MiB block reader, record parser,
+    # base-5/17 keys, std::unordered_set, find-then-insert, survivors written; reference hash_dup_remover.hpp:105-148) on
+    # a prefix of the same input file, one thread.  Its output must be the head of the CLI's output, byte for byte.
+    if ok and a.cpu_sample > 0:
+        try:
+            from oracle import binding
+            m = min(a.cpu_sample, n)
+            pre, pre_out = d / "prefix.fq", d / "prefix_out.fq"
+            with open(src, "rb") as f, open(pre, "wb") as g:
+                left = m * rec_len
+                while left:
+                    blk = f.read(min(left, 64 << 20)); g.write(blk); left -= len(blk)
+            t0 = time.perf_counter()
+            tot, dup = binding.load_oracle().filter_single(pre, pre_out)
+            dt = time.perf_counter() - t0
+            size = pre_out.stat().st_size
+            same = tot == m and dup == int((exp_keep[:m] == 0).sum()) and size == (m - dup) * rec_len
+            if same:
+                with open(pre_out, "rb") as f, open(dst, "rb") as g:
+                    while same:
+                        x = f.read(64 << 20)
+                        if not x:
+                            break
+                        same = x == g.read(len(x))
+            res["cpu_baseline"] = {"value": round(m / dt / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port, file driver",
+                                   "sample": f"first {m} records of the same FASTQ file ({m * rec_len / 1e9:.2f} GB), file in -> file out through the oracle's "
+                                             f"restatement of filterSE (500 MiB block reader, parser, keys, unordered_set, writer), {dt:.1f} s, page cache warm; "
+                                             f"host has {os.cpu_count()} cores, the reference path is single-threaded",
+                                   "parity": "oracle output == head of the CLI's output, byte for byte" if same else "MISMATCH between the oracle's and the CLI's output"}
+            pre.unlink(missing_ok=True); pre_out.unlink(missing_ok=True)
+        except Exception as ex:
+            res["cpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     # the same reads as a BGZF file in and a .gz file out: inflated, cut into records, deduplicated and deflated on the GPU
     try:
         packer = Path("/tmp") / f"fqd_bgzf_pack_{os.getpid()}"

@@ -106,6 +106,7 @@ def load_library():
     L.fqd_engine_destroy.argtypes = [vp]
     L.fqd_engine_reset.argtypes = [vp]
     L.fqd_submit.argtypes = [vp, C.POINTER(ReadsDesc), u64, i32, vp]
+    L.fqd_submit_final.argtypes = [vp, C.POINTER(ReadsDesc), u64, i32, vp]
     L.fqd_engine_sync.argtypes = [vp]
     L.fqd_engine_wait_stream.argtypes = [vp, vp]
     L.fqd_stream_wait_engine.argtypes = [vp, vp]
@@ -139,6 +140,7 @@ def load_library():
     L.fqd_partition_keys.argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]
     L.fqd_reserve_keys.argtypes = [vp, u64, u32, u32, C.POINTER(vp)]
     L.fqd_insert_keys.argtypes = [vp, vp, u64, u32, u32, vp]
+    L.fqd_widen_keys.argtypes = [vp, u32]
     L.fqd_synth_reads.argtypes = [vp, u64, u64, u64, u32, u32, i32, vp, vp]
     L.fqd_padded_key_words.argtypes = [u32, u32]
     L.fqd_padded_key_words.restype = u32

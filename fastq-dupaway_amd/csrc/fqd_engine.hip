@@ -59,6 +59,7 @@ struct fqd_engine {
     bool     table_exact = false;                    // sized once for a known total (capacity hint): may run denser than 50 %
     bool     table_clear = false;                    // every slot is EMPTY right now
     bool     table_stale = false;                    // contents are garbage: clear (or rebuild) before use
+    bool     finalised = false;                      // fqd_submit_final was called: the table was not written back; only a reset reopens the engine
     DevBuf   bulk_recs, bulk_meta;                   // scratch of the bulk (partitioned) insert
     uint64_t bulk_min = 1u << 20;                    // batches at least this large take the bulk path
     DevBuf   keys;     uint64_t keys_used = 0;       // words
@@ -482,7 +483,7 @@ int bulk_plan(fqd_engine* e, uint64_t n, BulkPlan& p)
 // hist1_done: the encoder already folded the level-1 histogram into its own pass.
 int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes, uint32_t hash_stride,
                        uint64_t n, uint64_t first_idx, uint8_t* keep, const BulkPlan& p, bool hist1_done,
-                       uint32_t* first = nullptr)
+                       uint32_t* first = nullptr, bool last_batch = false)
 {
     const Verdicts verdicts{keep, first, uint32_t(first_idx)};
     const BulkGeom g = p.g;
@@ -538,11 +539,15 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
     unsigned long long* counters = reinterpret_cast<unsigned long long*>(e->d_state + 1);
     uint32_t heavy_above = 4u << e->seg_bits;                   // far beyond what a segment can hold at <= 50 % load
     if (const char* v = std::getenv("FQD_HEAVY_ABOVE")) heavy_above = uint32_t(std::max(0, std::atoi(v)));
+    // The last batch of a run (fqd_submit_final): nobody will read the table again, so the segments stay in LDS and the
+    // 8 bytes per slot of write-back (2 GiB for the 100 M-read table) are not moved.  FQD_FINAL_WRITE_BACK=1: the A/B switch.
+    static const bool force_write_back = [] { const char* v = std::getenv("FQD_FINAL_WRITE_BACK"); return v && v[0] == '1'; }();
+    const uint32_t write_back = (last_batch && !force_write_back) ? 0u : 1u;
     auto launch_dedup = [&](auto kernel) -> int {
         if (lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         hipLaunchKernelGGL(kernel, dim3(dgrid), dim3(dthreads), lds, e->stream,
                            final_recs, bstart, n_buckets, e->table.as<uint64_t>(), e->seg_bits, g.seg_bits + g.bits2, ks, verdicts, counters,
-                           heavy_above, p.heavy_count, p.heavy_list);
+                           heavy_above, p.heavy_count, p.heavy_list, write_back);
         return FQD_OK;
     };
     int drc;
@@ -559,7 +564,7 @@ int launch_bulk_insert(fqd_engine* e, const KeyStore& ks, const uint64_t* hashes
                        final_recs, bstart, g, e->table.as<uint64_t>(), ks, verdicts, counters,
                        static_cast<const uint32_t*>(p.heavy_count), static_cast<const uint32_t*>(p.heavy_list));
     HIP_TRY(e, hipGetLastError());
-    e->table_clear = false; e->table_stale = false;
+    e->table_clear = false; e->table_stale = !write_back;     // not written back = garbage from here on (the engine is finalised)
     return FQD_OK;
 }
 
@@ -715,17 +720,20 @@ int fqd_engine_reset(fqd_engine* e)
     e->h_state[0] = kNoError; e->h_state[1] = 0; e->h_state[2] = 0; e->h_state[3] = 0; e->h_state[4] = 0;
     HIP_TRY(e, hipMemcpyAsync(e->d_state, e->h_state, 5 * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    e->n_records = 0; e->keys_used = 0; e->ragged = false; e->have_shape = false;
+    e->n_records = 0; e->keys_used = 0; e->ragged = false; e->have_shape = false; e->finalised = false;
     e->L0 = e->L1 = e->W0 = 0; e->has_bad = false; e->last_error.clear();
     return FQD_OK;
 }
 
-static int submit_impl(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep)
+static const char kFinalised[] = "this engine was given its last batch (fqd_submit_final): fqd_engine_reset before anything else is added";
+
+static int submit_impl(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep, bool last_batch)
 {
     if (!e) return FQD_ERR_ARG;
     if (!seg || (n && !keep) || (memory != FQD_MEM_HOST && memory != FQD_MEM_DEVICE))
         return e->fail(FQD_ERR_ARG, "fqd_submit: bad arguments");
-    if (n == 0) return FQD_OK;
+    if (e->finalised) return e->fail(FQD_ERR_ARG, kFinalised);
+    if (n == 0) { e->finalised = last_batch; return FQD_OK; }
     if (e->n_records + n > 0xFFFFFFFEull) return e->fail(FQD_ERR_CAPACITY, "more than 2^32-2 records in one engine");
     if (e->have_shape && e->L1 == FQD_OPAQUE_KEYS)
         return e->fail(FQD_ERR_ARG, "fqd_submit: this engine holds opaque keys (fqd_insert_keys / fqd_insert_slabs with FQD_OPAQUE_KEYS)");
@@ -821,7 +829,7 @@ static int submit_impl(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memo
         const Hist1 fold{plan.hist1, plan.g, ~0ull};
         static const bool fold_on = [] { const char* v = std::getenv("FQD_FOLD_HIST1"); return !(v && v[0] == '0'); }();
         if ((rc = launch_encode(e, sv, uniform, seg, n, first, ks, e->hashes.as<uint64_t>(), nullptr, 8, fold_on ? &fold : nullptr))) return rc;
-        if ((rc = launch_bulk_insert(e, ks, e->hashes.as<uint64_t>(), 1, n, first, d_keep, plan, fold_on))) return rc;
+        if ((rc = launch_bulk_insert(e, ks, e->hashes.as<uint64_t>(), 1, n, first, d_keep, plan, fold_on, nullptr, last_batch))) return rc;
     } else if (n >= 2 * e->chunk_reads && e->aux) {
         // Overlap: the encoder streams HBM, the insert is bound by memory-side atomics, so the
         // two run side by side on two streams, sub-batch k+1 being encoded while k is inserted.
@@ -856,6 +864,7 @@ static int submit_impl(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memo
     }
     e->n_records += n;
     e->keys_used += new_words;
+    e->finalised = last_batch;
 
     if (memory == FQD_MEM_HOST) {
         HIP_TRY(e, hipMemcpyAsync(keep, d_keep, n, hipMemcpyDeviceToHost, e->stream));
@@ -868,7 +877,12 @@ void* fqd_engine_stream(fqd_engine* e) { return e ? static_cast<void*>(e->stream
 
 int fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep)
 {
-    return submit_impl(e, seg, n, memory, keep);
+    return submit_impl(e, seg, n, memory, keep, false);
+}
+
+int fqd_submit_final(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep)
+{
+    return submit_impl(e, seg, n, memory, keep, true);
 }
 
 // An event recorded on `from`, waited for by `to`: a later record of the same event does not move a wait already queued.
@@ -1150,6 +1164,62 @@ int fqd_reserve_keys(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1, ui
     return FQD_OK;
 }
 
+// The owner side of a key shape that changes in mid-run (a multi-GPU run that meets a read longer than any before,
+// or reads of several lengths after blocks of one length): every key the engine holds is laid out again as an opaque
+// key of `new_words` words — [len0 | len1 << 32][words][zeros] for keys of known mate lengths, [words][zeros] for
+// keys that are opaque already — which is exactly what fqd_encode_padded makes of the same read under the wider
+// maxima, so old and new keys stay comparable word for word.  Record numbers do not change; the set is rebuilt from
+// the new keys (their placement hash runs over all words).
+int fqd_widen_keys(fqd_engine* e, uint32_t new_words)
+{
+    if (!e) return FQD_ERR_ARG;
+    if (new_words == 0) return e->fail(FQD_ERR_ARG, "fqd_widen_keys: empty keys");
+    if (e->finalised) return e->fail(FQD_ERR_ARG, kFinalised);
+    if (e->ragged) return e->fail(FQD_ERR_ARG, "fqd_widen_keys: this engine holds keys of several lengths in the ragged layout (fqd_submit); only uniform key stores are widened");
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (!e->have_shape || e->n_records == 0) {
+        e->have_shape = true; e->ragged = false; e->L0 = new_words; e->L1 = FQD_OPAQUE_KEYS; e->W0 = new_words; e->keys_used = 0;
+        return FQD_OK;
+    }
+    const bool opaque = e->L1 == FQD_OPAQUE_KEYS;
+    const uint32_t lead = opaque ? 0u : 1u;
+    if (new_words < e->W0 + lead) return e->fail(FQD_ERR_ARG, "fqd_widen_keys: the new keys are narrower than the ones held");
+    if (opaque && new_words == e->W0) return FQD_OK;
+    int rc;
+    DevBuf nk;
+    const uint64_t words = e->n_records * uint64_t(new_words);
+    if ((rc = reserve(e, nk, std::max<uint64_t>(words + words / 2, 1024) * sizeof(uint64_t)))) return rc;
+    void* nt = nullptr;
+    const bool have_table = e->table.p && !e->table_clear && !e->table_stale;
+    if (have_table) {
+        const hipError_t err = hipMalloc(&nt, e->slots * sizeof(uint64_t));
+        if (err != hipSuccess) { release(nk); return e->fail_hip("hipMalloc(table)", err); }
+    }
+    {
+        Bracket br(e, K_OTHER, 0);
+        const uint64_t header = uint64_t(e->L0) | (uint64_t(e->L1) << 32);
+        hipLaunchKernelGGL(widen_keys_kernel, dim3(grid_for(e, words)), dim3(kBlock), 0, e->stream,
+                           e->keys.as<uint64_t>(), nk.as<uint64_t>(), e->n_records, e->W0, new_words, lead, header);
+        if (have_table) {
+            HIP_TRY(e, hipMemsetAsync(nt, 0xFF, e->slots * sizeof(uint64_t), e->stream));
+            const KeyStore ks{nk.as<uint64_t>(), nullptr, new_words, new_words, 0};
+            hipLaunchKernelGGL(rehash_kernel, dim3(grid_for(e, e->slots)), dim3(kBlock), 0, e->stream,
+                               e->table.as<uint64_t>(), e->slots, static_cast<uint64_t*>(nt), e->slots - 1,
+                               (1ull << e->seg_bits) - 1, ks, new_words, FQD_OPAQUE_KEYS, 0u,
+                               !(e->flags & FQD_FLAG_WEAK_HASH) ? ~0ull : 0x00000000FFFFFFC0ull,
+                               e->tag_mask, reinterpret_cast<unsigned long long*>(e->d_state + 1));
+        }
+        HIP_TRY(e, hipGetLastError());
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    release(e->keys);
+    e->keys = nk; e->keys_used = words;
+    if (have_table) { HIP_TRY(e, hipFree(e->table.p)); e->table.p = nt; }
+    e->L0 = new_words; e->L1 = FQD_OPAQUE_KEYS; e->W0 = new_words;
+    e->hashed_records = nullptr;
+    return FQD_OK;
+}
+
 static int insert_keys_impl(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep,
                             uint64_t slab_cap, const uint64_t* slab_count);
 
@@ -1170,6 +1240,7 @@ static int insert_keys_impl(fqd_engine* e, const uint64_t* keys, uint64_t n, uin
 {
     if (!e) return FQD_ERR_ARG;
     if (n && (!keys || !keep)) return e->fail(FQD_ERR_ARG, "fqd_insert_keys: bad arguments");
+    if (e->finalised) return e->fail(FQD_ERR_ARG, kFinalised);
     if (n == 0) return FQD_OK;
     int rc;
     if ((rc = prepare_keys(e, n, len0, len1))) return rc;

@@ -857,7 +857,8 @@ __global__ __launch_bounds__(1024)
 void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ bstart, uint32_t n_buckets,
                          uint64_t* __restrict__ table, uint32_t seg_bits, uint32_t qshift, KeyStore ks, Verdicts out,
                          unsigned long long* __restrict__ counters,
-                         uint32_t heavy_above, uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list)
+                         uint32_t heavy_above, uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list,
+                         uint32_t write_back)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long seg[];
     const uint32_t seg_slots = 1u << seg_bits, seg_mask = seg_slots - 1u;
@@ -1078,7 +1079,7 @@ void bucket_dedup_kernel(const uint64_t* __restrict__ recs, const uint32_t* __re
             STAMP(6);                                         // retry + barrier
         }
         __syncthreads();
-        {
+        if (write_back) {                                     // 0: the run's last batch (fqd_submit_final) — nobody reads the table again
             const ulonglong2* seg2 = reinterpret_cast<const ulonglong2*>(seg);
             ulonglong2* gseg2 = reinterpret_cast<ulonglong2*>(gseg);
             for (uint32_t k = threadIdx.x; k < (seg_slots >> 1); k += blockDim.x) {   // written once, not read again by this launch
@@ -1256,6 +1257,20 @@ void relayout_ragged_kernel(const uint64_t* __restrict__ src, uint64_t* __restri
         const uint32_t k = uint32_t(x - j * (W0 + 1u));
         dst[x] = k ? src[j * W0 + (k - 1u)] : header;
         if (k == 0) koff[j] = x;
+    }
+}
+
+// fqd_widen_keys: uniform keys of W0 words -> opaque keys of W1 words: `lead` header words (0 or 1) first, then the old
+// words, then zeros.  One output word per lane and step: both sides stream.
+__global__ __launch_bounds__(kBlock)
+void widen_keys_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, uint64_t n, uint32_t W0, uint32_t W1,
+                       uint32_t lead, uint64_t header)
+{
+    const uint64_t total = n * uint64_t(W1);
+    for (uint64_t x = blockIdx.x * uint64_t(kBlock) + threadIdx.x; x < total; x += uint64_t(gridDim.x) * kBlock) {
+        const uint64_t j = x / W1;
+        const uint32_t k = uint32_t(x - j * W1);
+        dst[x] = k < lead ? header : (k - lead < W0 ? src[j * W0 + (k - lead)] : 0ull);
     }
 }
 

@@ -140,9 +140,9 @@ class Engine:
         return int(self._L.fqd_engine_stream(self._h) or 0)
 
     # -- the hot path ---------------------------------------------------------------
-    def submit(self, segs: Sequence[Reads], n: int, keep=None):
+    def submit(self, segs: Sequence[Reads], n: int, keep=None, final: bool = False):
         """Dedups n more records; returns their keep flags (numpy for host input,
-        the given device buffer otherwise)."""
+        the given device buffer otherwise).  final: this is the run's last batch (fqd_submit_final)."""
         if len(segs) != self.segments:
             raise ValueError(f"engine has {self.segments} mate(s) per record, got {len(segs)}")
         host = _is_host(segs[0].bases)
@@ -157,7 +157,8 @@ class Engine:
             keep = np.empty(n, dtype=np.uint8) if keep is None else keep
         elif keep is None:
             raise ValueError("device submits need a device keep buffer")
-        rc = self._L.fqd_submit(self._h, self._desc(segs), n, _lib.MEM_HOST if host else _lib.MEM_DEVICE, self._p(keep))
+        fn = self._L.fqd_submit_final if final else self._L.fqd_submit
+        rc = fn(self._h, self._desc(segs), n, _lib.MEM_HOST if host else _lib.MEM_DEVICE, self._p(keep))
         self._check(rc)
         return keep
 
@@ -198,6 +199,15 @@ class Engine:
 
     def insert_keys(self, keys, n: int, len0: int, len1: int, keep):
         self._check(self._L.fqd_insert_keys(self._h, self._p(keys), n, len0, len1, self._p(keep)))
+
+    def padded_key_words(self, max_len0: int, max_len1: int = 0) -> int:
+        return int(self._L.fqd_padded_key_words(max_len0, max_len1))
+
+    def encode_padded(self, segs: Sequence[Reads], n: int, max_len0: int, max_len1: int, records):
+        self._check(self._L.fqd_encode_padded(self._h, self._desc(segs), n, max_len0, max_len1, self._p(records)))
+
+    def widen_keys(self, new_words: int):
+        self._check(self._L.fqd_widen_keys(self._h, new_words))
 
     def partition_slabs(self, records, n: int, key_words: int, n_parts: int, slab_cap: int, out_keys, counts, origin):
         self._check(self._L.fqd_partition_slabs(self._h, self._p(records), n, key_words, n_parts, slab_cap,

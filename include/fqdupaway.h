@@ -118,6 +118,14 @@ int  fqd_engine_reset(fqd_engine* e);
  * it completes: later batches cannot change them. */
 int  fqd_submit(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep);
 
+/* fqd_submit for the LAST batch of a run: the caller declares that nothing will be added before the next
+ * fqd_engine_reset.  The reference's loop produces flags, not a set anyone looks at afterwards
+ * (hash_dup_remover.hpp:126-144): the bulk insert path then leaves the set's segments where they were built
+ * (on chip) instead of writing them back to HBM — 8 bytes per slot, 2 GiB for the 100 M-read table.  Same flags as
+ * fqd_submit, bit for bit.  Afterwards fqd_submit* / fqd_insert_* fail with FQD_ERR_ARG until the engine is reset;
+ * stats, flags and fqd_bad_base work as after fqd_submit. */
+int  fqd_submit_final(fqd_engine* e, const fqd_reads* seg, uint64_t n, int memory, uint8_t* keep);
+
 /* The hipStream_t the engine launches on (its own, or the one given in fqd_config), so a caller
  * can order its own work — copies, collectives — against the engine's with events. */
 void* fqd_engine_stream(fqd_engine* e);
@@ -180,6 +188,14 @@ int  fqd_partition_keys(fqd_engine* e, const uint64_t* records, uint64_t n, uint
                         uint32_t n_parts, uint64_t* out_keys, uint64_t* counts, uint32_t* origin);
 int  fqd_reserve_keys(fqd_engine* e, uint64_t n, uint32_t len0, uint32_t len1, uint64_t** slot);
 int  fqd_insert_keys(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep);
+
+/* An owner whose key shape has to change in mid-run: the reference keys a read of any length at any point of the
+ * file (seq_utils.cpp:35-49, hash_dup_remover.hpp:126-144), while the exchange moves keys of ONE width.  Every key the
+ * engine holds (from fqd_insert_keys / fqd_insert_slabs, with known mate lengths or opaque) is laid out again as an
+ * opaque key of new_words words — [len0 | len1 << 32][key words][zeros], the form fqd_encode_padded gives the same
+ * read under maxima with fqd_padded_key_words(..) == new_words — record numbers unchanged, the set rebuilt from the
+ * new keys.  Afterwards the engine takes keys with len0 = new_words, len1 = FQD_OPAQUE_KEYS.  Waits for the stream. */
+int  fqd_widen_keys(fqd_engine* e, uint32_t new_words);
 
 /* The exchange with messages of FIXED size, so that an all-to-all can be queued before anybody knows how many keys
  * go where (fqd_shard below).  fqd_partition_slabs is fqd_partition_keys with part p's keys written to slab p — the

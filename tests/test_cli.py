@@ -645,23 +645,46 @@ def test_multi_gpu_cli_errors(exe, oracle, tmp_path):
     rag.write_bytes(fastq([(b"a", b"ACGT"), (b"b", b"ACGTA"), (b"c", b"ACG")]))
     r = run(exe, "-i", rag, "-o", tmp_path / "o.fq", "--fast", env={"FQD_DEVICES": "0,x"})
     assert r.returncode == 1 and "FQD_DEVICES" in r.stderr
-    # the key shape is fixed by the first round of blocks: what does not fit it later is refused with the way out, not mangled
+    # the key shape of the group follows the file: reads of other lengths after blocks of one length, then a read longer
+    # than the padded width, make the owners lay their keys out again (fqd_widen_keys) — same bytes as the oracle's, which
+    # like the reference keys any length at any point (seq_utils.cpp:35-49); round 3 refused both with exit 1
     recs = [(b"u%05d" % k, bytes(rnd.choice(b"ACGT") for _ in range(60))) for k in range(40000)]
     recs[35000] = (recs[35000][0], recs[35000][1][:41])
+    for k in range(36000, 40000, 7):                                                        # copies of reads from before the change of shape
+        recs[k] = (recs[k][0], recs[k - 30000][1])
     late = tmp_path / "late.fq"; late.write_bytes(fastq(recs))
-    r = run(exe, "-i", late, "-o", tmp_path / "o.fq", "--fast", env={"FQD_DEVICES": "0,0", "FQD_BLOCK_MB": "1"})
-    assert r.returncode == 1 and "FQD_SHARD_PADDED=1" in r.stderr
     tot, dup = oracle.filter_single(late, exp, FASTQ)
-    r = run(exe, "-i", late, "-o", got, "--fast", "-v", env={"FQD_DEVICES": "0,0", "FQD_BLOCK_MB": "1", "FQD_SHARD_PADDED": "1"})
-    assert r.returncode == 0 and got.read_bytes() == exp.read_bytes(), r.stderr
+    for devices in ("0,0", "0,0,0", "0,0,0,0"):
+        for extra in ({}, {"FQD_SHARD_PADDED": "1"}):
+            r = run(exe, "-i", late, "-o", got, "--fast", "-v", env={"FQD_DEVICES": devices, "FQD_BLOCK_MB": "1", **extra})
+            assert r.returncode == 0 and got.read_bytes() == exp.read_bytes(), (devices, extra, r.stderr)
+            assert r.stdout == f"{tot} reads processed, out of which {dup} duplicates were removed.\n" and dup > 500
     recs[35000] = (recs[35000][0], recs[34999][1] + b"ACGTACGTAC")                      # 70 > 64 = the first round's 60 rounded up
     recs[100] = (recs[100][0], recs[100][1][:33])                                           # (the first round is ragged: padded keys)
+    recs[38000] = (recs[38000][0], recs[35000][1])                                          # the long read again, and a still longer one
+    recs[39000] = (recs[39000][0], recs[35000][1] * 3)
     late.write_bytes(fastq(recs))
-    r = run(exe, "-i", late, "-o", tmp_path / "o.fq", "--fast", env={"FQD_DEVICES": "0,0", "FQD_BLOCK_MB": "1"})
-    assert r.returncode == 1 and "FQD_SHARD_MAX_LEN" in r.stderr
     tot, dup = oracle.filter_single(late, exp, FASTQ)
-    r = run(exe, "-i", late, "-o", got, "--fast", "-v", env={"FQD_DEVICES": "0,0", "FQD_BLOCK_MB": "1", "FQD_SHARD_MAX_LEN": "70"})
-    assert r.returncode == 0 and got.read_bytes() == exp.read_bytes(), r.stderr
+    for devices in ("0,0", "0,0,0", "0,0,0,0"):
+        for extra in ({}, {"FQD_SHARD_MAX_LEN": "70"}, {"FQD_SHARD_SLAB": "64"}):
+            r = run(exe, "-i", late, "-o", got, "--fast", "-v", env={"FQD_DEVICES": devices, "FQD_BLOCK_MB": "1", **extra})
+            assert r.returncode == 0 and got.read_bytes() == exp.read_bytes(), (devices, extra, r.stderr)
+            assert r.stdout == f"{tot} reads processed, out of which {dup} duplicates were removed.\n"
+    # paired: mate 2 grows late, mate 1 does not
+    p1 = [(b"p%05d/1" % k, bytes(rnd.choice(b"ACGT") for _ in range(50))) for k in range(30000)]
+    p2 = [(b"p%05d/2" % k, bytes(rnd.choice(b"AC") for _ in range(4)) * 10) for k in range(30000)]
+    for k in range(20000, 30000, 5):
+        p1[k] = (p1[k][0], p1[k - 15000][1]); p2[k] = (p2[k][0], p2[k - 15000][1])
+    p2[25001] = (p2[25001][0], p2[25001][1] + b"GGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGG")
+    p2[26001] = (p2[26001][0], p2[25001][1]); p1[26001] = (p1[26001][0], p1[25001][1])
+    f1, f2 = tmp_path / "l1.fq", tmp_path / "l2.fq"
+    f1.write_bytes(fastq(p1)); f2.write_bytes(fastq(p2))
+    e1, e2, g1, g2 = (tmp_path / x for x in ("le1.fq", "le2.fq", "lg1.fq", "lg2.fq"))
+    tot, dup, _ = oracle.filter_paired(f1, f2, e1, e2, FASTQ)
+    for devices in ("0,0", "0,0,0"):
+        r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "-v", env={"FQD_DEVICES": devices, "FQD_BLOCK_MB": "1"})
+        assert r.returncode == 0 and g1.read_bytes() == e1.read_bytes() and g2.read_bytes() == e2.read_bytes(), (devices, r.stderr)
+        assert r.stdout == f"{tot} read pairs processed, out of which {dup} duplicates were removed.\n" and dup > 500
 
 
 def trimmed_fastq(rnd, n, lo, hi, pool, ident):

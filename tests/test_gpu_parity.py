@@ -540,3 +540,76 @@ def test_engine_orders_itself_after_the_callers_stream(torch_cuda):
         e.release_to()
         assert torch.equal(keep, expect)
         assert L.fqd_engine_wait_stream(None, None) == _lib.ERR_ARG and L.fqd_stream_wait_engine(None, None) == _lib.ERR_ARG
+
+
+# ---- the last batch of a run (fqd_submit_final) ---------------------------------------------------
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("bulk_min", [None, "-1"])
+def test_last_batch_declared_gives_the_same_flags(monkeypatch, torch_cuda, paired, bulk_min):
+    """fqd_submit_final: same flags and counts as fqd_submit bit for bit — as the only batch (set built on chip and never
+    written back), as the last of several (resident set + a bulk batch), on the atomic path (nothing to skip) — then the
+    engine refuses more until it is reset, and after the reset builds a correct set over the garbage the skipped
+    write-back left in the table."""
+    torch = torch_cuda
+    if bulk_min is not None:
+        monkeypatch.setenv("FQD_BULK_MIN", bulk_min)
+    S = 2 if paired else 1
+    sizes = [3_000_000, 1_500_000, 2_500_000]
+    n, L = sum(sizes), 150
+    bases = [torch.empty(n * L + 16, dtype=torch.uint8, device="cuda") for _ in range(S)]
+    expect = torch.empty(n, dtype=torch.uint8, device="cuda")
+    keep = torch.empty(n, dtype=torch.uint8, device="cuda")
+    with Engine(segments=S, capacity_reads=n) as e:
+        for m in range(S):
+            e.synth_reads(31, 0, n, L, 250, m, bases[m], expect if m == S - 1 else None)
+        segs = lambda at: [Reads(bases[m][at * L:], uniform_len=L, uniform_stride=L) for m in range(S)]
+        # (a) the whole job as one declared-last batch
+        keep.fill_(9)
+        e.submit(segs(0), n, keep=keep, final=True)
+        e.sync()
+        assert torch.equal(keep, expect)
+        assert e.stats()["duplicates"] == int((expect == 0).sum().item())
+        # (b) closed until reset, whatever the entry point
+        for call in (lambda: e.submit(segs(0), 10, keep=keep), lambda: e.submit(segs(0), 10, keep=keep, final=True),
+                     lambda: e.insert_keys(e.reserve_keys(4, L, L if paired else 0), 4, L, L if paired else 0, keep)):
+            with pytest.raises(fqd.FqdError) as ei:
+                call()
+            assert ei.value.code == 1 and "fqd_submit_final" in str(ei.value)
+        # (c) after the reset: several batches over the stale table, the last one declared
+        e.reset()
+        keep.fill_(9)
+        at = 0
+        for k, size in enumerate(sizes):
+            e.submit(segs(at), size, keep=keep[at:], final=(k == len(sizes) - 1))
+            at += size
+        e.sync()
+        assert torch.equal(keep, expect)
+        assert e.stats()["duplicates"] == int((expect == 0).sum().item())
+        # (d) and once more from the table (c) left behind, undeclared: the plain path must not trust it either
+        e.reset()
+        keep.fill_(9)
+        e.submit(segs(0), n, keep=keep)
+        e.submit(segs(0), 1000, keep=keep[:1000])            # every one of these is a duplicate of the resident set
+        e.sync()
+        assert int(keep[:1000].sum().item()) == 0 and torch.equal(keep[1000:], expect[1000:])
+
+
+def test_last_batch_with_a_massively_repeated_key(oracle, torch_cuda):
+    """The skew guard under fqd_submit_final: the swollen bucket's segment is cleared in HBM and filled by the atomic
+    protocol although no other segment is written back."""
+    rng = np.random.default_rng(5)
+    n, L = 1_500_000, 60
+    pool = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(5000, L))
+    pool[0, :] = ord("G")
+    pick = rng.integers(1, 5000, size=n)
+    pick[rng.random(n) < 0.7] = 0
+    data = np.concatenate([pool[pick].reshape(-1), np.zeros(16, np.uint8)])
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(L)
+    exp = oracle.dedup_single(data, offs, np.full(n, L, np.uint32))
+    with Engine(segments=1, capacity_reads=n) as e:
+        for _ in range(2):                                    # the second time over a table nobody wrote back
+            e.reset()
+            keep = e.submit([Reads(data, uniform_len=L, uniform_stride=L)], n, final=True)
+            assert e.stats()["duplicates"] == int((exp == 0).sum())
+            assert np.array_equal(keep, exp)

@@ -409,3 +409,79 @@ def test_one_pass_grouping_equals_the_three_step_path(monkeypatch, paired, parts
         # classic counts: full sub-slabs, a partial one, empty ones
         assert list(c3[p]) == [max(0, min(int(t3[p]) - c * sub_cap, sub_cap if c + 1 < G else 1 << 62)) for c in range(G)]
     assert np.all(o1[parts * cap:] == -7) and np.all(k1[parts * cap:] == -7)      # the one-pass form never touches the spill region
+
+
+@pytest.mark.parametrize("bulk_min", ["0", "-1"])
+@pytest.mark.parametrize("paired", [False, True])
+def test_owner_widens_its_keys_in_mid_run(oracle, monkeypatch, bulk_min, paired):
+    """fqd_widen_keys: an owner that holds keys of one exact shape (reads of 60 bases) is told the run goes on with reads
+    of several lengths up to 96, later up to 160: the keys it holds are laid out again as padded keys of the wider shape
+    and the set is rebuilt, so copies of EARLIER reads among the later ones are still found — flags against the oracle
+    on everything in order of arrival, on the bulk and the atomic insert path."""
+    from fastq_dupaway_amd import Engine, Reads, FqdError
+    from fastq_dupaway_amd._lib import OPAQUE_KEYS
+    monkeypatch.setenv("FQD_BULK_MIN", bulk_min)
+    S = 2 if paired else 1
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3 + S)
+    n = 60_000
+    stages = [(60, 60), (96, 96), (160, 128)]                            # widest read allowed per mate while each stage runs
+    pools = []                                                           # per mate: rows every stage draws from, each with a length of its own
+    for m in range(S):
+        rows = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=(n // 2, 160), p=[.245, .245, .245, .245, .02])
+        pools.append(rows)
+    batches = []
+    for k, (m0, m1) in enumerate(stages):
+        pick = rng.integers(0, n // 2, n)
+        per_mate = []
+        for m in range(S):
+            cap = (m0, m1)[m]
+            if k == 0:
+                lens = np.full(n, cap, np.uint32)
+            else:
+                # a row's length depends on the row alone (copies stay copies); rows first met at stage 0 keep 60 bases
+                row_len = np.where(np.arange(n // 2) % 3 == 0, 60, 30 + (np.arange(n // 2) * 7919) % (cap - 29)).astype(np.uint32)
+                lens = row_len[pick]
+            flat = np.concatenate([pools[m][pick[i], : lens[i]] for i in range(n)] + [np.zeros(16, np.uint8)])
+            offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+            per_mate.append((flat, offs, lens))
+        batches.append(per_mate)
+    got = []
+    with Engine(segments=S) as e:
+        for k, (m0, m1) in enumerate(stages):
+            d = [(torch.from_numpy(f).to(dev), torch.from_numpy(o.view(np.int64)).to(dev), torch.from_numpy(l.view(np.int32)).to(dev)) for f, o, l in batches[k]]
+            keep = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+            if k == 0:
+                W = e.key_words(m0, m1 if paired else 0)
+                rec = torch.empty(n * (W + 1), dtype=torch.int64, device=dev)
+                e.encode_uniform([Reads(d[m][0], uniform_len=(m0, m1)[m], uniform_stride=(m0, m1)[m]) for m in range(S)], n, rec)
+                shape = (m0, m1 if paired else 0)
+            else:
+                W = e.padded_key_words(m0, m1 if paired else 0)
+                if k == 1:
+                    with pytest.raises(FqdError):
+                        e.widen_keys(W - 3)                              # narrower than the keys held plus their header
+                e.widen_keys(W)
+                rec = torch.zeros(n * (W + 1), dtype=torch.int64, device=dev)
+                e.encode_padded([Reads(d[m][0], offsets=d[m][1], lengths=d[m][2]) for m in range(S)], n, m0, m1 if paired else 0, rec)
+                shape = (W, OPAQUE_KEYS)
+            e.sync()
+            wire = rec.view(n, W + 1)[:, 1:].contiguous()
+            slot = torch.as_tensor(_Words(e.reserve_keys(n, *shape), n * W), device=dev)
+            slot.copy_(wire.view(-1))
+            e.insert_keys(slot, n, *shape, keep)
+            e.sync()
+            got.append(keep.cpu().numpy())
+        dups = e.stats()["duplicates"]
+    cat = []
+    for m in range(S):
+        flat = np.concatenate([b[m][0][:-16] for b in batches] + [np.zeros(16, np.uint8)])
+        lens = np.concatenate([b[m][2] for b in batches])
+        offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64)
+        cat.append((flat, offs, lens))
+    exp = oracle.dedup_paired(*cat[0], *cat[1]) if paired else oracle.dedup_single(*cat[0])
+    g = np.concatenate(got)
+    assert np.array_equal(g, exp), f"{int((g != exp).sum())} flags differ"
+    assert dups == int((exp == 0).sum())
+    later = exp[n:]
+    assert 0 < int((later == 0).sum())                                   # copies of earlier stages' reads were there to find

@@ -37,10 +37,26 @@ __host__ __device__ inline uint64_t hash_begin(uint32_t len0, uint32_t len1)
     h *= kHashMul;
     return h ^ (h >> 32);
 }
+// One key word into the chain.  The chain only has to keep different keys apart (every step is a bijection of the
+// state for a given word and of the word for a given state, so keys that differ in one word never meet, and keys that
+// differ in more meet with the odds of a 64-bit equation); the spreading over table positions, tags and partition
+// digits is hash_end's.  So the step is kept cheap — the staged encoder issues instructions 80 % of the time (SQ
+// counters) and a 64-bit multiply is three quarter-rate instructions: round 3's step
+// (h ^ w) * K; h ^= h >> 32 cost 16 issue slots per word, this one 6: two Feistel halves over the 32-bit halves of
+// h ^ w, a 24-bit multiply (full rate) for the non-linear one, an add of a rotation for the other.
+// FQD_OLD_HASH: round 3's step (A/B builds).
 __host__ __device__ inline uint64_t hash_word(uint64_t h, uint64_t w)
 {
+#ifdef FQD_OLD_HASH
     h = (h ^ w) * kHashMul;
     return h ^ (h >> 32);
+#else
+    const uint64_t x = h ^ w;
+    uint32_t lo = uint32_t(x), hi = uint32_t(x >> 32);
+    hi ^= (lo & 0xFFFFFFu) * 0x9E3779u;                       // v_mul_u32_u24: low 32 bits of a 24 x 24 bit product
+    lo += (hi << 15) | (hi >> 17);                            // v_alignbit + v_add
+    return (uint64_t(hi) << 32) | lo;
+#endif
 }
 // A record's hash = hash_end of its mate-1 chain (single-end), or of mate-1's chain fed with
 // mate-2's chain (paired): each mate is hashed on its own from hash_begin(len, 0), so the two
@@ -99,6 +115,15 @@ __host__ __device__ __forceinline__ uint32_t shifted_dword(uint32_t lo, uint32_t
     return uint32_t(((uint64_t(hi) << 32) | lo) >> (8u * (shift_bytes & 3u)));
 #endif
 }
+// a | (b ^ c)
+__host__ __device__ __forceinline__ uint32_t or_xor(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xF6);       // truth table over (a, b, c) = 0xF0 | (0xCC ^ 0xAA)
+#else
+    return a | (b ^ c);
+#endif
+}
 __host__ __device__ __forceinline__ uint32_t first_set_bit(uint32_t x)   // x != 0
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -120,8 +145,20 @@ struct Group {
 };
 
 // w[0..7]: the group's dwords, bytes past the sequence end already replaced by 'A'.
+//
+// Three byte-table lookups per dword, all off ONE selector — the byte's low three bits, A=1 C=3 T=4 N=6 G=7 (distinct;
+// 0, 2, 5: no base) — do what round 3 did with shifts and masks:
+//   * the byte the selector stands for (0xFF for 0, 2, 5: no byte with those low bits equals it): any input byte that
+//     does not round-trip is outside {A,C,G,T,N};  diff |= lookup ^ w is one three-input bit operation on gfx950;
+//   * the 2-bit code ALREADY SHIFTED to where dword k of the group keeps it (bits 2(k%4).. of the byte);
+//   * the N bit already at bit k of the byte.
+// So a dword costs AND + 3 x v_perm + 1 bit-op, and the words are plain ORs of the lookups (v_or3): 6 instructions per
+// four bases against 8 (the staged encoder issues instructions 80 % of the time: DESIGN §7).  Same key bits as before.
+// FQD_PACK_V1: round 3's form (A/B builds).
 __host__ __device__ __forceinline__ Group pack_group(const uint32_t (&w)[8])
 {
+    Group g;
+#ifdef FQD_PACK_V1
     uint32_t c[8], diff = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -133,10 +170,25 @@ __host__ __device__ __forceinline__ Group pack_group(const uint32_t (&w)[8])
     const uint32_t hi = (c[4] & M) | ((c[5] & M) << 2) | ((c[6] & M) << 4) | ((c[7] & M) << 6);
     const uint32_t y0 = ((c[0] & N) >> 2) | ((c[1] & N) >> 1) | (c[2] & N) | ((c[3] & N) << 1);
     const uint32_t y1 = ((c[4] & N) << 2) | ((c[5] & N) << 3) | ((c[6] & N) << 4) | ((c[7] & N) << 5);
-    Group g;
     g.codes = uint64_t(lo) | (uint64_t(hi) << 32);
     g.nmask = y0 | y1;
     g.diff = diff;
+#else
+    // table bytes by selector: s1 = selectors 0..3 = (-, A, -, C), s0 = selectors 4..7 = (T, -, N, G)
+    uint32_t cod[8], nb[8], diff = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t sel = w[k] & 0x07070707u;
+        diff = or_xor(diff, perm_bytes(0x474EFF54u, 0x43FF41FFu, sel), w[k]);
+        const uint32_t sh = 2u * (uint32_t(k) & 3u);
+        cod[k] = perm_bytes((2u << sh) | (3u << (16 + sh)) | (3u << (24 + sh)), 1u << (24 + sh), sel);     // A0 C1 T2 N3 G3
+        nb[k]  = perm_bytes(1u << (16 + k), 0u, sel);                                                       // N only
+    }
+    const uint32_t lo = cod[0] | cod[1] | cod[2] | cod[3], hi = cod[4] | cod[5] | cod[6] | cod[7];
+    g.codes = uint64_t(lo) | (uint64_t(hi) << 32);
+    g.nmask = (nb[0] | nb[1] | nb[2] | nb[3]) | (nb[4] | nb[5] | nb[6] | nb[7]);
+    g.diff = diff;
+#endif
     return g;
 }
 

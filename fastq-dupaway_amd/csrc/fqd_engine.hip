@@ -364,14 +364,22 @@ int launch_encode(fqd_engine* e, const SegView* sv, bool uniform, const fqd_read
         const uint32_t rw = ks.W0 + ks.lead;
         const uint32_t magic = rw > 1 ? uint32_t(((1ull << 32) + rw - 1) / rw) : 0xFFFFFFFFu;   // x/rw for x < 2^16
         if (e->S == 1) {
+            // rows of 2^k >= 2 words whose slots are 16-byte aligned: magic 0 selects the kernel's 16-bytes-per-lane stream-out
+            static const bool wide_out = [] { const char* v = std::getenv("FQD_ENC_STREAMOUT"); return !(v && v[0] == '0'); }();   // 0: round 3's 8 bytes per lane (A/B)
+            const bool pow2_rows = wide_out && rw >= 2 && (rw & (rw - 1)) == 0 && (reinterpret_cast<uintptr_t>(ks.keys) & 15u) == 0;
+            const uint32_t magic1 = (c.lds_out && pow2_rows) ? 0u : magic;
             auto launch = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream, sv[0], n, first_idx, ks, hash_out, err, magic, h1);
+                hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream, sv[0], n, first_idx, ks, hash_out, err, magic1, h1);
             };
             if (c.lds_out) launch(encode_staged_kernel<true>); else launch(encode_staged_kernel<false>);
         } else {
+            const uint32_t split = ks.lead + seg_words(seg[0].uniform_len);
+            static const bool wide_out = [] { const char* v = std::getenv("FQD_ENC_STREAMOUT"); return !(v && v[0] == '0'); }();
+            const bool pow2_rows = wide_out && rw >= 2 && (rw & (rw - 1)) == 0 && (split & 1u) == 0 && (reinterpret_cast<uintptr_t>(ks.keys) & 15u) == 0;
+            const uint32_t magic2 = (c.lds_out && pow2_rows) ? 0u : magic;
             auto launch = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3(grid), dim3(c.R), lds, stream,
-                                   sv[0], sv[1], n, first_idx, ks, hash_out, err, c.tile0, magic, h1);
+                                   sv[0], sv[1], n, first_idx, ks, hash_out, err, c.tile0, magic2, h1);
             };
             if (c.lds_out) launch(encode_staged_pe_kernel<true>); else launch(encode_staged_pe_kernel<false>);
         }

@@ -165,7 +165,11 @@ void encode_general_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_id
 // staging values stay in registers; the LDS stores are predicated.  The input is read once:
 // non-temporal loads keep it from displacing anything in L2.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kCopyBatch = 5;                         // 1 -> 5: encoder 4.3 -> 4.0 ms per 100 M; 10: no better
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+#ifndef FQD_COPY_BATCH
+#define FQD_COPY_BATCH 5
+#endif
+constexpr int kCopyBatch = FQD_COPY_BATCH;            // 1 -> 5: encoder 4.3 -> 4.0 ms per 100 M; 10: no better
 template <int BATCH>
 __device__ __forceinline__ void stage_chunks_by(const u32x4* __restrict__ src, u32x4* dst, uint32_t n16, uint32_t R)
 {
@@ -323,7 +327,12 @@ void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
         const uint32_t t = threadIdx.x;
         const uint64_t i = r0 + t;
         const uint32_t l0 = s0.ulen;
+#ifdef FQD_ENC_SKIP_PACK                                            /* diagnostic builds only: what the kernel costs without its packing (results are garbage) */
+        if (t < nr && hash_out) hash_out[i] = lds64[t];
+        if (false) {
+#else
         if (t < nr) {
+#endif
             uint64_t h = hash_begin(l0, 0);
             const uint32_t b0 = in0 + t * s0.ustride;
             uint32_t diff;
@@ -351,12 +360,32 @@ void encode_staged_kernel(SegView s0, uint64_t n, uint64_t first_idx,
             }
         }
         STAMP(3);                                                   // pack + hash
+#ifdef FQD_ENC_SKIP_OUT                                             /* diagnostic builds only: no key leaves the CU */
+        if (false) {
+#else
         if (LDS_OUT) {
+#endif
             // the wave's 64 rows -> one contiguous run of key slots
             const uint32_t wave = t >> 6, lane = t & 63u;
             const uint32_t wave_reads = (nr > wave * 64u) ? ((nr - wave * 64u < 64u) ? nr - wave * 64u : 64u) : 0u;
             uint64_t* __restrict__ gout = ks.keys + (first_idx + r0 + wave * 64u) * uint64_t(ks.stride);
             const uint32_t total = wave_reads * row_words;
+#ifndef FQD_OLD_STREAMOUT
+            if (rw_magic == 0u) {
+                // rows of 2^k words (150 bp: 8): 16 bytes per lane and store — two adjacent words of a row out of LDS, one
+                // global_store_dwordx4 — and a row's number and a word's place in it by shift and mask.  The general form
+                // below costs a lane two quarter-rate multiplies per 8 bytes stored: 130 of the encoder's ~830 issue slots
+                // per read went into moving its 64-byte key out.
+                const uint32_t half_shift = uint32_t(__ffs(int(row_words))) - 2u;          // log2(row_words / 2)
+                u64x2* __restrict__ gout2 = reinterpret_cast<u64x2*>(gout);
+                for (uint32_t y = lane; y < (total >> 1); y += 64u) {
+                    const uint32_t rr = y >> half_shift, k2 = (y - (rr << half_shift)) << 1;
+                    const uint64_t* row = lds64 + ((in0 + __umul24(wave * 64u + rr, s0.ustride) + 4u + 7u) >> 3) + k2;
+                    const u64x2 v = {row[0], row[1]};
+                    __builtin_nontemporal_store(v, &gout2[y]);
+                }
+            } else
+#endif
             for (uint32_t x = lane; x < total; x += 64u) {
                 const uint32_t rr = __umulhi(x, rw_magic), kk = x - rr * row_words;
                 __builtin_nontemporal_store(lds64[((in0 + (wave * 64u + rr) * s0.ustride + 4u + 7u) >> 3) + kk], &gout[x]);
@@ -448,6 +477,20 @@ void encode_staged_pe_kernel(SegView s0, SegView s1, uint64_t n, uint64_t first_
             const uint32_t wave_pairs = (np > wave * 32u) ? ((np - wave * 32u < 32u) ? np - wave * 32u : 32u) : 0u;
             uint64_t* __restrict__ gout = ks.keys + (first_idx + r0 + wave * 32u) * uint64_t(ks.stride);
             const uint32_t total = wave_pairs * row_words, split = ks.lead + W_0;
+#ifndef FQD_OLD_STREAMOUT
+            if (rw_magic == 0u) {                                  // rows of 2^k words, mate 1's part an even number of them: see encode_staged_kernel
+                const uint32_t half_shift = uint32_t(__ffs(int(row_words))) - 2u;
+                u64x2* __restrict__ gout2 = reinterpret_cast<u64x2*>(gout);
+                for (uint32_t y = lane; y < (total >> 1); y += 64u) {
+                    const uint32_t rr = y >> half_shift, kk = (y - (rr << half_shift)) << 1;
+                    const uint32_t m = kk >= split ? 1u : 0u;
+                    const uint32_t pb = in_base[m] + __umul24(wave * 32u + rr, m ? s1.ustride : s0.ustride);
+                    const uint64_t* row = lds64 + ((pb + 4u + 7u) >> 3) + (m ? kk - split : kk);
+                    const u64x2 v = {row[0], row[1]};
+                    __builtin_nontemporal_store(v, &gout2[y]);
+                }
+            } else
+#endif
             for (uint32_t x = lane; x < total; x += 64u) {
                 const uint32_t rr = __umulhi(x, rw_magic), kk = x - rr * row_words;
                 const uint32_t m = kk >= split ? 1u : 0u;

@@ -460,7 +460,7 @@ def test_owner_widens_its_keys_in_mid_run(oracle, monkeypatch, bulk_min, paired)
                 W = e.padded_key_words(m0, m1 if paired else 0)
                 if k == 1:
                     with pytest.raises(FqdError):
-                        e.widen_keys(W - 3)                              # narrower than the keys held plus their header
+                        e.widen_keys(e.key_words(*stages[0][:S]))        # no room for the header word of the keys held
                 e.widen_keys(W)
                 rec = torch.zeros(n * (W + 1), dtype=torch.int64, device=dev)
                 e.encode_padded([Reads(d[m][0], offsets=d[m][1], lengths=d[m][2]) for m in range(S)], n, m0, m1 if paired else 0, rec)

@@ -31,7 +31,9 @@ def main():
             variants.append((name, dict(kv.split("=", 1) for kv in envs.split(",") if kv)))
     rows = []
     for name, env in [v for _ in range(repeat) for v in variants]:      # the whole list, `repeat` times over: runs of one variant are spread out
-        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", "se", "--steps", steps, "--warmup", "2", "--cpu-sample", "0"],
+        env = dict(env)
+        extra = env.pop("ARGS", "").split()                      # ARGS=--no-verify: further bench.py arguments of a variant (diagnostic builds)
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", "se", "--steps", steps, "--warmup", "2", "--cpu-sample", "0", *extra],
                            capture_output=True, text=True, env=dict(os.environ, **env))
         line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
         if r.returncode != 0 or line is None:

@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--e2e-pairs", type=int, default=4_000_000, help="pairs of the end-to-end --unordered CLI run (0 = skip)")
     ap.add_argument("--e2e-dir", default="", help="where the end-to-end FASTQ files go (default: a temp dir under /tmp)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--send-hash", type=int, default=-1, help="sharded configs: 1 = every key's placement hash travels with it (FQD_SHARD_SEND_HASH), 0 = the owners hash arrived keys again; default: 1 from 4 ranks on")
     ap.add_argument("--no-final", action="store_true", help="A/B: plain fqd_submit instead of fqd_submit_final (the set is written back to HBM although nobody reads it)")
     return ap.parse_args()
 
@@ -130,6 +131,7 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
     segs = [Reads(bases[mate], uniform_len=L, uniform_stride=L) for mate in range(S)]
 
     sharded = None
+    send_hash = False
     if sharded_mode:
         from fastq_dupaway_amd.shard import ShardGroup, unique_id
         uid = None
@@ -138,8 +140,11 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
             if world > 1:
                 dist.broadcast_object_list(box, src=0)            # control plane only; the keys travel over the library's own RCCL communicator
             uid = box[0]
+        # with the hash: 72 instead of 64 bytes per read on the links, 1.75 ms per 100 M reads less at the owners.  At 2 ranks ONE
+        # link carries half of a GPU's keys and bounds the step, so fewer bytes win there; from 4 ranks on the links have room
+        send_hash = (job_world >= 4) if a.send_hash < 0 else bool(a.send_hash)
         sharded = ShardGroup(engines, world=job_world, first_rank=0 if sharded_mode == "virtual" else rank, round_reads=m,
-                             len0=L, len1=(L if S == 2 else 0), transport="copy" if sharded_mode == "virtual" else "rccl", uid=uid)
+                             len0=L, len1=(L if S == 2 else 0), transport="copy" if sharded_mode == "virtual" else "rccl", uid=uid, send_hash=send_hash)
         round_args = []
         for lo, cnt in spans:
             sg = [[Reads(bases[mate][(v * n_rank + lo) * L:], uniform_len=L, uniform_stride=L) for mate in range(S)] for v in range(ranks_here)]
@@ -261,7 +266,8 @@ def device_phase(a, torch, dist, dev, local, rank, world, paired, sharded_mode, 
                           "last_batch_declared": bool(not sharded_mode and not a.no_final),
                           "sharding": "none" if not sharded_mode else
                                       (f"hash-prefix sharding over {job_world} rank(s)" + (f" sharing this GPU ({n_rank} reads each)" if sharded_mode == "virtual" else f" = {world} GPU(s), one process each")
-                                       + f", fixed-size all-to-all slabs, {rounds} round(s) of {m} reads per rank and step")},
+                                       + f", fixed-size all-to-all slabs, {rounds} round(s) of {m} reads per rank and step"
+                                       + (", hashes travel with the keys" if send_hash else ", owners hash arrived keys again"))},
                "parity": parity, "roofline": roofline,
                "step_ms_spread": {"min": round(each[0], 3), "median": round(each[len(each) // 2], 3), "max": round(each[-1], 3)}}
         if sharded_mode:

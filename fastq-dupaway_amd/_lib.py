@@ -66,7 +66,7 @@ class ShardStats(C.Structure):
                 ("slab_records", C.c_uint64), ("exchange_ms", C.c_double), ("transport", C.c_int32), ("ranks_in_comm", C.c_int32)]
 
 
-SHARD_RCCL, SHARD_COPY, SHARD_ID_BYTES, SHARD_PADDED, OPAQUE_KEYS = 0, 1, 128, 1, 0xFFFFFFFF
+SHARD_RCCL, SHARD_COPY, SHARD_ID_BYTES, SHARD_PADDED, SHARD_SEND_HASH, OPAQUE_KEYS = 0, 1, 128, 1, 2, 0xFFFFFFFF
 
 
 def build_native(target: str = "all") -> None:
@@ -152,6 +152,8 @@ def load_library():
     L.fqd_partition_slabs.argtypes = [vp, vp, u64, u32, u32, u64, vp, vp, vp]
     L.fqd_encode_slabs.argtypes = [vp, C.POINTER(ReadsDesc), u64, u32, u64, u32, u64, vp, vp, vp, vp, u32]
     L.fqd_insert_slabs.argtypes = [vp, vp, u32, u64, vp, u32, u32, vp]
+    L.fqd_insert_slabs_hashed.argtypes = [vp, vp, vp, u32, u64, vp, u32, u32, vp]
+    L.fqd_encode_slabs_hashed.argtypes = [vp, C.POINTER(ReadsDesc), u64, u32, u64, u32, u64, vp, vp, vp, vp, vp, u32]
     L.fqd_shard_unique_id.argtypes = [vp]
     L.fqd_shard_slab_capacity.argtypes = [u64, C.c_int32, u32]
     L.fqd_shard_slab_capacity.restype = u64

@@ -1036,6 +1036,12 @@ int fqd_partition_slabs(fqd_engine* e, const uint64_t* records, uint64_t n, uint
 int fqd_encode_slabs(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t n_parts, uint64_t chunk_reads, uint32_t n_chunks, uint64_t sub_cap,
                      uint64_t* out_keys, uint64_t* chunk_counts, uint64_t* totals, uint32_t* origin, uint32_t flags)
 {
+    return fqd_encode_slabs_hashed(e, seg, n, n_parts, chunk_reads, n_chunks, sub_cap, out_keys, nullptr, chunk_counts, totals, origin, flags);
+}
+
+int fqd_encode_slabs_hashed(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t n_parts, uint64_t chunk_reads, uint32_t n_chunks, uint64_t sub_cap,
+                            uint64_t* out_keys, uint64_t* out_hashes, uint64_t* chunk_counts, uint64_t* totals, uint32_t* origin, uint32_t flags)
+{
     if (!e) return FQD_ERR_ARG;
     const uint64_t slab_cap = uint64_t(n_chunks) * sub_cap;
     if (!seg || !n_parts || !n_chunks || !sub_cap || !chunk_reads || !chunk_counts || !totals || (n && (!out_keys || !origin)) || n > 0xFFFFFFFFull ||
@@ -1092,11 +1098,11 @@ int fqd_encode_slabs(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t n
     Bracket br(e, K_ENCODE, n);
     if (e->S == 1)
         hipLaunchKernelGGL(encode_chunks_kernel, dim3(grid), dim3(kBlock), size_t(tile_bytes), e->stream, sv, n, W, n_parts, chunk_tiles, n_chunks, used_chunks, sub_cap,
-                           out_keys, origin, chunk_counts, reinterpret_cast<unsigned long long*>(totals), next_chunk, e->d_state, magic, hash_and);
+                           out_keys, origin, chunk_counts, reinterpret_cast<unsigned long long*>(totals), next_chunk, e->d_state, magic, hash_and, out_hashes);
     else {
         SegView sv1{seg[1].bases, nullptr, nullptr, seg[1].uniform_len, seg[1].uniform_stride};
         hipLaunchKernelGGL(encode_chunks_pe_kernel, dim3(grid), dim3(kBlock), size_t(tile_bytes), e->stream, sv, sv1, n, W_0, W_1, n_parts, chunk_tiles, n_chunks, used_chunks, sub_cap,
-                           out_keys, origin, chunk_counts, reinterpret_cast<unsigned long long*>(totals), next_chunk, e->d_state, uint32_t(tile0), magic, hash_and);
+                           out_keys, origin, chunk_counts, reinterpret_cast<unsigned long long*>(totals), next_chunk, e->d_state, uint32_t(tile0), magic, hash_and, out_hashes);
     }
     HIP_TRY(e, hipGetLastError());
     return FQD_OK;
@@ -1229,7 +1235,15 @@ int fqd_widen_keys(fqd_engine* e, uint32_t new_words)
 }
 
 static int insert_keys_impl(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep,
-                            uint64_t slab_cap, const uint64_t* slab_count);
+                            uint64_t slab_cap, const uint64_t* slab_count, uint64_t* hashes = nullptr);
+
+int fqd_insert_slabs_hashed(fqd_engine* e, const uint64_t* keys, uint64_t* hashes, uint32_t n_slabs, uint64_t slab_cap, const uint64_t* slab_count,
+                            uint32_t len0, uint32_t len1, uint8_t* keep)
+{
+    if (e && (!slab_cap || !slab_count || !hashes)) return e->fail(FQD_ERR_ARG, "fqd_insert_slabs_hashed: bad arguments");
+    if (e && len1 == FQD_OPAQUE_KEYS) return e->fail(FQD_ERR_ARG, "fqd_insert_slabs_hashed: opaque keys are hashed by their owner (the source's hash runs over the read, the owner's over the padded key)");
+    return insert_keys_impl(e, keys, uint64_t(n_slabs) * slab_cap, len0, len1, keep, slab_cap, slab_count, hashes);
+}
 
 int fqd_insert_keys(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep)
 {
@@ -1244,7 +1258,7 @@ int fqd_insert_slabs(fqd_engine* e, const uint64_t* keys, uint32_t n_slabs, uint
 }
 
 static int insert_keys_impl(fqd_engine* e, const uint64_t* keys, uint64_t n, uint32_t len0, uint32_t len1, uint8_t* keep,
-                            uint64_t slab_cap, const uint64_t* slab_count)
+                            uint64_t slab_cap, const uint64_t* slab_count, uint64_t* given_hashes)
 {
     if (!e) return FQD_ERR_ARG;
     if (n && (!keys || !keep)) return e->fail(FQD_ERR_ARG, "fqd_insert_keys: bad arguments");
@@ -1260,8 +1274,14 @@ static int insert_keys_impl(fqd_engine* e, const uint64_t* keys, uint64_t n, uin
         HIP_TRY(e, hipMemcpyAsync(tail, keys, words * sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream));
     }
     e->hashed_records = nullptr;                              // the hash scratch is reused
-    if ((rc = reserve(e, e->hashes, n * sizeof(uint64_t)))) return rc;
-    {
+    const uint64_t* hashes = given_hashes;
+    if (given_hashes) {
+        // the hashes came with the keys (the source's encoder had them anyway): only the slots without a key get their word
+        Bracket br(e, K_OTHER, 0);
+        hipLaunchKernelGGL(mask_unused_hashes_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream, given_hashes, n, slab_cap, slab_count);
+    } else {
+        if ((rc = reserve(e, e->hashes, n * sizeof(uint64_t)))) return rc;
+        hashes = e->hashes.as<uint64_t>();
         Bracket br(e, K_OTHER, 0);
         const uint64_t hash_and = (e->flags & FQD_FLAG_WEAK_HASH) ? 0x00000000FFFFFFC0ull : ~0ull;
         hipLaunchKernelGGL(hash_keys_kernel, dim3(grid_for(e, n)), dim3(kBlock), 0, e->stream,
@@ -1271,8 +1291,8 @@ static int insert_keys_impl(fqd_engine* e, const uint64_t* keys, uint64_t n, uin
     const KeyStore ks = key_store(e);
     BulkPlan plan;
     if (bulk_applies(e, n) && (rc = bulk_plan(e, n, plan))) return rc;
-    if (plan.ok) { if ((rc = launch_bulk_insert(e, ks, e->hashes.as<uint64_t>(), 1, n, first, keep, plan, false))) return rc; }
-    else if ((rc = launch_insert(e, ks, e->hashes.as<uint64_t>(), 1, n, first, keep))) return rc;
+    if (plan.ok) { if ((rc = launch_bulk_insert(e, ks, hashes, 1, n, first, keep, plan, false))) return rc; }
+    else if ((rc = launch_insert(e, ks, hashes, 1, n, first, keep))) return rc;
     e->n_records += n; e->keys_used += words;
     return FQD_OK;
 }

@@ -1431,7 +1431,8 @@ __global__ __launch_bounds__(kBlock)
 void encode_chunks_kernel(SegView s0, uint64_t n, uint32_t W0, uint32_t n_parts, uint32_t chunk_tiles, uint32_t n_chunks, uint32_t used_chunks, uint64_t sub_cap,
                           uint64_t* __restrict__ out_keys, uint32_t* __restrict__ origin, uint64_t* __restrict__ counts,
                           unsigned long long* __restrict__ totals, uint32_t* __restrict__ next_chunk,
-                          uint64_t* __restrict__ err, uint32_t rw_magic, uint64_t hash_and)
+                          uint64_t* __restrict__ err, uint32_t rw_magic, uint64_t hash_and,
+                          uint64_t* __restrict__ out_hash /* nullable: the key's placement hash to the same slot of a second array (it travels with the key) */)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t wave_cnt[kGroupParts][kBlock / 64];
@@ -1460,6 +1461,7 @@ void encode_chunks_kernel(SegView s0, uint64_t n, uint32_t W0, uint32_t n_parts,
             const uint64_t i = r0 + t;
             const uint32_t l0 = s0.ulen;
             uint32_t owner = 0xFFFFFFFFu;
+            uint64_t my_hash = 0;
             if (t < nr) {
                 uint64_t h = hash_begin(l0, 0);
                 const uint32_t b0 = in0 + t * s0.ustride;
@@ -1467,6 +1469,7 @@ void encode_chunks_kernel(SegView s0, uint64_t n, uint32_t W0, uint32_t n_parts,
                 auto sink = [&](uint64_t w) { *out++ = w; h = hash_word(h, w); };
                 const uint32_t diff = pack_mate(lds + (b0 >> 2), b0 & 3u, l0, sink);
                 h = hash_end(h) & hash_and;
+                my_hash = h;
                 owner = owner_of(h, n_parts);
                 if (diff) {
                     const uint64_t e = locate_bad_base(s0.bases + i * uint64_t(s0.ustride), l0, nullptr, 0, i);
@@ -1485,7 +1488,7 @@ void encode_chunks_kernel(SegView s0, uint64_t n, uint32_t W0, uint32_t n_parts,
                 for (uint32_t w = 0; w < wave; ++w) local += wave_cnt[owner][w];
                 const uint32_t slot = local < sub_cap ? uint32_t((uint64_t(owner) * n_chunks + chunk) * sub_cap + local) : 0xFFFFFFFFu;
                 dst_of[t] = slot;
-                if (slot != 0xFFFFFFFFu) origin[slot] = uint32_t(i);
+                if (slot != 0xFFFFFFFFu) { origin[slot] = uint32_t(i); if (out_hash) out_hash[slot] = my_hash; }
             }
             __syncthreads();
             if (t < n_parts) { uint32_t c = 0; for (uint32_t w = 0; w < R / 64u; ++w) c += wave_cnt[t][w]; running[t] += c; }
@@ -1512,7 +1515,8 @@ __global__ __launch_bounds__(kBlock)
 void encode_chunks_pe_kernel(SegView s0, SegView s1, uint64_t n, uint32_t W_0, uint32_t W_1, uint32_t n_parts, uint32_t chunk_tiles, uint32_t n_chunks,
                              uint32_t used_chunks, uint64_t sub_cap, uint64_t* __restrict__ out_keys, uint32_t* __restrict__ origin, uint64_t* __restrict__ counts,
                              unsigned long long* __restrict__ totals, uint32_t* __restrict__ next_chunk,
-                             uint64_t* __restrict__ err, uint32_t tile_bytes0, uint32_t rw_magic, uint64_t hash_and)
+                             uint64_t* __restrict__ err, uint32_t tile_bytes0, uint32_t rw_magic, uint64_t hash_and,
+                             uint64_t* __restrict__ out_hash)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t wave_cnt[kGroupParts][kBlock / 64];
@@ -1559,7 +1563,8 @@ void encode_chunks_pe_kernel(SegView s0, SegView s1, uint64_t n, uint32_t W_0, u
             }
             const uint64_t other = __shfl_xor(h, 1, 64);
             uint32_t owner = 0xFFFFFFFFu;
-            if (live && !mate) owner = owner_of(hash_pair(h, other) & hash_and, n_parts);
+            const uint64_t pair_hash = hash_pair(h, other) & hash_and;
+            if (live && !mate) owner = owner_of(pair_hash, n_parts);
             owner = __shfl(owner, int(lane & ~1u), 64);              // both mates know their pair's owner
             if (live && diff) {
                 uint32_t byte = 0;
@@ -1580,7 +1585,7 @@ void encode_chunks_pe_kernel(SegView s0, SegView s1, uint64_t n, uint32_t W_0, u
                 for (uint32_t w = 0; w < wave; ++w) local += wave_cnt[owner][w];
                 const uint32_t slot = local < sub_cap ? uint32_t((uint64_t(owner) * n_chunks + chunk) * sub_cap + local) : 0xFFFFFFFFu;
                 dst_of[pair] = slot;
-                if (slot != 0xFFFFFFFFu) origin[slot] = uint32_t(i);
+                if (slot != 0xFFFFFFFFu) { origin[slot] = uint32_t(i); if (out_hash) out_hash[slot] = pair_hash; }
             }
             __syncthreads();
             if (t < n_parts) { uint32_t c = 0; for (uint32_t w = 0; w < R / 64u; ++w) c += wave_cnt[t][w]; running[t] += c; }
@@ -1642,6 +1647,17 @@ void padded_slots_kernel(SegView s0, SegView s1, uint32_t paired, uint64_t n, ui
         if (l0 > max0 || l1 > max1) ++bad;
     }
     if (bad) atomicAdd(too_long, static_cast<unsigned long long>(bad));
+}
+
+// Hashes that arrived WITH their keys (fqd_insert_slabs_hashed): only the slots of a slab that hold no key need a word,
+// the one every insert path passes over.
+__global__ __launch_bounds__(kBlock)
+void mask_unused_hashes_kernel(uint64_t* __restrict__ hashes, uint64_t n, uint64_t slab_cap, const uint64_t* __restrict__ slab_count)
+{
+    for (uint64_t i = blockIdx.x * uint64_t(kBlock) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kBlock) {
+        const uint64_t slab = i / slab_cap;
+        if (i - slab * slab_cap >= slab_count[slab]) hashes[i] = kSkipHash;
+    }
 }
 
 // Placement hashes of uniform keys that arrived without them (the sharded exchange sends keys only):

@@ -79,6 +79,8 @@ struct Round {                           // buffers and events of one round in f
     uint32_t* origin = nullptr;          // input position per slot of `grouped`
     uint8_t*  keep_recv = nullptr;       // owner side: flags of what was inserted
     uint8_t*  keep_back = nullptr;       // source side: flags per slot of `grouped`
+    uint64_t* grouped_hash = nullptr;    // FQD_SHARD_SEND_HASH: the placement hash of every key slot of `grouped` (slabs only, no spill region)
+    uint64_t* recv_hash = nullptr;       //   and, owner side, the hashes of the slabs as they arrived
     uint64_t* d_counts = nullptr;        // CountLayout
     uint64_t* h_counts = nullptr;        // pinned mirror
     uint64_t* d_ins_counts = nullptr;    // owner side, round laid out again: valid keys per sub-slab
@@ -113,6 +115,7 @@ struct fqd_shard {
     std::vector<Local> lr;
     uint32_t S = 1, K = 0;
     bool padded = false; uint32_t own_len0 = 0, own_len1 = 0;
+    bool send_hash = false;              // every key's hash travels with it: the owners do not hash arrived keys again
     Geometry g;
     uint64_t cap = 0;                    // g.cap()
     CountLayout cl{1, 1};
@@ -208,6 +211,9 @@ int exchange_forward(fqd_shard* s, uint64_t k)
             if (!a && !b) continue;
             xs.push_back({src, dst, a ? at_words(a->grouped, fqd_plan::slab_slot(uint32_t(dst), s->cap) * s->K) : nullptr,
                           b ? at_words_rw(b->slot, fqd_plan::slab_slot(uint32_t(src), s->cap) * s->K) : nullptr, slab_words * 8});
+            if (s->send_hash)
+                xs.push_back({src, dst, a ? at_words(a->grouped_hash, fqd_plan::slab_slot(uint32_t(dst), s->cap)) : nullptr,
+                              b ? at_words_rw(b->recv_hash, fqd_plan::slab_slot(uint32_t(src), s->cap)) : nullptr, s->cap * 8});
             xs.push_back({src, dst, a ? at_words(a->d_counts, cl.oc() + uint64_t(dst) * cl.G) : nullptr,
                           b ? at_words_rw(b->d_counts, cl.ic() + uint64_t(src) * cl.G) : nullptr, cl.G * 8});
             xs.push_back({src, dst, a ? at_words(a->d_counts, cl.ot() + uint64_t(dst)) : nullptr,
@@ -352,7 +358,10 @@ int finish_receive(fqd_shard* s, uint64_t k)
                 SH_HIP(s, hipMemcpyAsync(r.d_ins_counts, r.h_ins_counts, n_sub * 8, hipMemcpyHostToDevice, l.es));
                 counts = r.d_ins_counts;
             }
-            SH_ENG(s, l, fqd_insert_slabs(l.e, r.slot, uint32_t(n_sub), g.sub_cap, counts, s->own_len0, s->own_len1, r.keep_recv));
+            // the hashes that came with the keys serve as long as every slab lies the way the one-pass encoder filled it; a slab
+            // that came again, or came filled from its first slot on, is hashed here (same function, same values)
+            if (s->send_hash && !fixed) SH_ENG(s, l, fqd_insert_slabs_hashed(l.e, r.slot, r.recv_hash, uint32_t(n_sub), g.sub_cap, counts, s->own_len0, s->own_len1, r.keep_recv));
+            else                        SH_ENG(s, l, fqd_insert_slabs(l.e, r.slot, uint32_t(n_sub), g.sub_cap, counts, s->own_len0, s->own_len1, r.keep_recv));
         } else {
             // this owner received a spill: every source's slab, then its spill as further sub-slabs, in (source, position) order
             SH_HIP(s, hipStreamWaitEvent(l.es, r.ev_spill, 0));
@@ -436,6 +445,8 @@ void free_all(fqd_shard* s)
             if (r.origin) (void)hipFree(r.origin);
             if (r.keep_recv) (void)hipFree(r.keep_recv);
             if (r.keep_back) (void)hipFree(r.keep_back);
+            if (r.grouped_hash) (void)hipFree(r.grouped_hash);
+            if (r.recv_hash) (void)hipFree(r.recv_hash);
             if (r.d_counts) (void)hipFree(r.d_counts);
             if (r.d_ins_counts) (void)hipFree(r.d_ins_counts);
             if (r.h_counts) (void)hipHostFree(r.h_counts);
@@ -486,6 +497,7 @@ int fqd_shard_create(fqd_engine* const* engines, const fqd_shard_config* cfg, fq
     fqd_shard* s = new fqd_shard();
     s->cfg = *cfg;
     s->padded = (cfg->flags & FQD_SHARD_PADDED) != 0;
+    s->send_hash = (cfg->flags & FQD_SHARD_SEND_HASH) != 0 && !s->padded;
     s->K = s->padded ? fqd_padded_key_words(cfg->len0, cfg->len1) : fqd_key_words(cfg->len0, cfg->len1);
     s->S = cfg->len1 ? 2u : 1u;
     s->own_len0 = s->padded ? s->K : cfg->len0;                   // what the owners' engines are told their keys are
@@ -522,6 +534,8 @@ int fqd_shard_create(fqd_engine* const* engines, const fqd_shard_config* cfg, fq
                 (err = hipMalloc(reinterpret_cast<void**>(&r.origin), slots * 4)) != hipSuccess ||
                 (err = hipMalloc(reinterpret_cast<void**>(&r.keep_recv), ins_subs * s->g.sub_cap + s->cap)) != hipSuccess ||
                 (err = hipMalloc(reinterpret_cast<void**>(&r.keep_back), slots + s->cap)) != hipSuccess ||
+                (s->send_hash && (err = hipMalloc(reinterpret_cast<void**>(&r.grouped_hash), W * s->cap * 8)) != hipSuccess) ||
+                (s->send_hash && (err = hipMalloc(reinterpret_cast<void**>(&r.recv_hash), W * s->cap * 8)) != hipSuccess) ||
                 (err = hipMalloc(reinterpret_cast<void**>(&r.d_counts), s->cl.words() * 8)) != hipSuccess ||
                 (err = hipMalloc(reinterpret_cast<void**>(&r.d_ins_counts), ins_subs * 8)) != hipSuccess ||
                 (err = hipHostMalloc(reinterpret_cast<void**>(&r.h_counts), s->cl.words() * 8, hipHostMallocDefault)) != hipSuccess ||
@@ -604,8 +618,8 @@ int fqd_shard_round(fqd_shard* s, const fqd_reads* seg, const uint64_t* n, uint8
         } else {
             // one pass where it applies (it says which way it went in the word behind the totals); a sub-slab that overflows is
             // noticed from the counts and the round grouped again (finish_receive)
-            SH_ENG(s, l, fqd_encode_slabs(l.e, seg + a * s->S, n[a], uint32_t(W), s->g.chunk_reads, s->g.chunks, s->g.sub_cap, r.grouped,
-                                          r.d_counts + cl.oc(), r.d_counts + cl.ot(), r.origin, 0u));
+            SH_ENG(s, l, fqd_encode_slabs_hashed(l.e, seg + a * s->S, n[a], uint32_t(W), s->g.chunk_reads, s->g.chunks, s->g.sub_cap, r.grouped,
+                                                 s->send_hash ? r.grouped_hash : nullptr, r.d_counts + cl.oc(), r.d_counts + cl.ot(), r.origin, 0u));
         }
         SH_HIP(s, hipMemcpyAsync(r.h_counts, r.d_counts, size_t(cl.ic()) * 8, hipMemcpyDeviceToHost, l.es));
         SH_HIP(s, hipMemcpyAsync(r.h_bad, fqd_internal_state(l.e), 8, hipMemcpyDeviceToHost, l.es));     // first bad byte so far, this round's encoder included

@@ -218,6 +218,14 @@ class Engine:
         self._check(self._L.fqd_encode_slabs(self._h, self._desc(segs), n, n_parts, chunk_reads, n_chunks, sub_cap, self._p(out_keys),
                                              self._p(chunk_counts), self._p(totals), self._p(origin), 1 if exact else 0))
 
+    def encode_slabs_hashed(self, segs: Sequence[Reads], n: int, n_parts: int, chunk_reads: int, n_chunks: int, sub_cap: int, out_keys, out_hashes,
+                            chunk_counts, totals, origin, exact: bool = False):
+        self._check(self._L.fqd_encode_slabs_hashed(self._h, self._desc(segs), n, n_parts, chunk_reads, n_chunks, sub_cap, self._p(out_keys), self._p(out_hashes),
+                                                    self._p(chunk_counts), self._p(totals), self._p(origin), 1 if exact else 0))
+
+    def insert_slabs_hashed(self, keys, hashes, n_slabs: int, slab_cap: int, slab_count, len0: int, len1: int, keep):
+        self._check(self._L.fqd_insert_slabs_hashed(self._h, self._p(keys), self._p(hashes), n_slabs, slab_cap, self._p(slab_count), len0, len1, self._p(keep)))
+
     def insert_slabs(self, keys, n_slabs: int, slab_cap: int, slab_count, len0: int, len1: int, keep):
         self._check(self._L.fqd_insert_slabs(self._h, self._p(keys), n_slabs, slab_cap, self._p(slab_count), len0, len1, self._p(keep)))
 

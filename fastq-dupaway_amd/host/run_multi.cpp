@@ -210,6 +210,9 @@ void HashDupRemover::run_ordered_multi(int S, const std::string* in, const std::
                     }
                     widen = false;
                 }
+                // FQD_SHARD_SEND_HASH=1: every key's placement hash travels with it (12.5 % more bytes on the links, no re-hash
+                // pass at the owners); the library ignores it for padded keys
+                if (const char* v = std::getenv("FQD_SHARD_SEND_HASH")) if (std::atoi(v) != 0) cfg.flags |= FQD_SHARD_SEND_HASH;
                 cfg.round_reads = round_reads; cfg.len0 = len0; cfg.len1 = S == 2 ? len1 : 0;
                 if (const char* v = std::getenv("FQD_SHARD_SLAB")) cfg.slab_records = std::strtoull(v, nullptr, 10);    // tests: force slab overflows
                 if (tuning_.use_rccl) { if (fqd_shard_unique_id(id) != FQD_OK) throw std::runtime_error(std::string("GPU exchange: ") + fqd_shard_last_error(nullptr)); cfg.unique_id = id; }

@@ -24,8 +24,9 @@ class ShardGroup:
 
     def __init__(self, engines: Sequence[Engine], world: int, first_rank: int, round_reads: int, len0: int, len1: int = 0,
                  transport: str = "rccl", uid: Optional[bytes] = None, slack_permille: int = 0, slab_records: int = 0,
-                 padded: bool = False):
-        """padded: len0/len1 are the longest reads allowed and batches may hold reads of any lengths up to them."""
+                 padded: bool = False, send_hash: bool = False):
+        """padded: len0/len1 are the longest reads allowed and batches may hold reads of any lengths up to them.
+        send_hash: every key's placement hash travels with it (FQD_SHARD_SEND_HASH; ignored with padded)."""
         self._L = load_library()
         self.engines = list(engines)
         self.world, self.first_rank, self.S = world, first_rank, (2 if len1 else 1)
@@ -33,7 +34,7 @@ class ShardGroup:
         cfg = _lib.ShardConfig(world=world, n_local=len(self.engines), first_rank=first_rank,
                                transport=_lib.SHARD_RCCL if transport == "rccl" else _lib.SHARD_COPY,
                                round_reads=round_reads, len0=len0, len1=len1, slack_permille=slack_permille,
-                               flags=_lib.SHARD_PADDED if padded else 0, slab_records=slab_records,
+                               flags=(_lib.SHARD_PADDED if padded else 0) | (_lib.SHARD_SEND_HASH if send_hash else 0), slab_records=slab_records,
                                unique_id=C.cast(self._uid, C.c_void_p) if self._uid is not None else None)
         handles = (C.c_void_p * len(self.engines))(*[e._h for e in self.engines])
         h = C.c_void_p()

@@ -226,6 +226,18 @@ int  fqd_encode_slabs(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t 
                       uint64_t sub_cap, uint64_t* out_keys, uint64_t* chunk_counts, uint64_t* totals, uint32_t* origin, uint32_t flags);
 int  fqd_insert_slabs(fqd_engine* e, const uint64_t* keys, uint32_t n_slabs, uint64_t slab_cap, const uint64_t* slab_count,
                       uint32_t len0, uint32_t len1, uint8_t* keep);
+/* The same two with every key's 8-byte placement hash beside it, so that the owner does not have to read all 64 bytes
+ * of every arrived key once more just to hash it (1.75 ms per 100 M reads of a 14 ms sharded step, measured on one rank;
+ * it costs the links 12.5 % more bytes): fqd_encode_slabs_hashed also writes hash[slot] for every key slot it fills
+ * (one-pass grouping only: after FQD_SLABS_EXACT, or whenever totals[n_parts] reads 1, out_hashes holds nothing and the
+ * owner uses fqd_insert_slabs); fqd_insert_slabs_hashed takes the hashes as they arrived (device, n_slabs * slab_cap
+ * words, overwritten where a slot holds no key) — keys of known mate lengths only: an owner of opaque (padded) keys
+ * hashes the padded words, which the source never saw. */
+int  fqd_encode_slabs_hashed(fqd_engine* e, const fqd_reads* seg, uint64_t n, uint32_t n_parts, uint64_t chunk_reads, uint32_t n_chunks,
+                             uint64_t sub_cap, uint64_t* out_keys, uint64_t* out_hashes, uint64_t* chunk_counts, uint64_t* totals,
+                             uint32_t* origin, uint32_t flags);
+int  fqd_insert_slabs_hashed(fqd_engine* e, const uint64_t* keys, uint64_t* hashes, uint32_t n_slabs, uint64_t slab_cap,
+                             const uint64_t* slab_count, uint32_t len0, uint32_t len1, uint8_t* keep);
 
 /* ---- one dedup job over the GPUs of a node (BASELINE north_star: "reads are partitioned across the 8
  * GPUs of one node by hash prefix with an RCCL all-to-all over xGMI so each GPU owns a disjoint bucket range") ----
@@ -244,6 +256,8 @@ typedef struct fqd_shard fqd_shard;
 #define FQD_SHARD_RCCL 0    /* ncclSend/ncclRecv in one group per exchange: a direct all-to-all over xGMI */
 #define FQD_SHARD_COPY 1    /* peer copies; every rank must live in this process (always used when ranks share a GPU) */
 #define FQD_SHARD_PADDED 1u /* fqd_shard_config.flags: reads of several lengths, exchanged as padded keys (fqd_encode_padded) */
+#define FQD_SHARD_SEND_HASH 2u /* fqd_shard_config.flags: every key's placement hash travels with it (72 instead of 64 bytes per
+                                  150-base read on the links; the owners skip their re-hash pass).  Ignored with FQD_SHARD_PADDED. */
 
 typedef struct fqd_shard_config {
     int32_t  world;            /* ranks of the job                                                        */
@@ -254,7 +268,7 @@ typedef struct fqd_shard_config {
     uint32_t len0, len1;       /* the job's fixed read lengths (len1 = 0: single-end); with FQD_SHARD_PADDED the
                                   longest reads allowed: batches of any lengths up to them, ragged or uniform */
     uint32_t slack_permille;   /* slab capacity over a fair share, 0 = 30                                  */
-    uint32_t flags;            /* FQD_SHARD_PADDED                                                         */
+    uint32_t flags;            /* FQD_SHARD_PADDED, FQD_SHARD_SEND_HASH                                    */
     uint64_t slab_records;     /* 0 = fqd_shard_slab_capacity(...); tests force overflows with a small one */
     const uint8_t* unique_id;  /* RCCL: FQD_SHARD_ID_BYTES from fqd_shard_unique_id, the same in every process */
 } fqd_shard_config;

@@ -1,0 +1,113 @@
+// The GPU reader of ORDINARY gzip files (fastq-dupaway_amd/csrc/fqd_gunzip_core.hpp) run on the CPU, unit by unit as the
+// kernels of fqd_gunzip.hip run it: block starts guessed per unit, every unit decoded into 16-bit symbols from its guess,
+// the chain of unit ends and starts checked, windows made unit after unit, symbols turned into bytes.  What comes out is
+// written for tests/test_gunzip_core.py to compare with what zlib makes of the same file.  Test infrastructure only.
+//   gunzip_core_check <in.gz> <out> <unit_bytes> [max_ratio]     prints: status units bytes_out deflate_bytes
+//   status: ok | chain (a unit does not start where the one before it ended) | bad (damaged data) | full (a unit's room) | header
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <memory>
+#include <vector>
+
+#include "../../fastq-dupaway_amd/csrc/fqd_gunzip_core.hpp"
+
+using namespace fqd::gunz;
+
+struct ArraySink {
+    uint16_t* p; uint64_t cap, n = 0;
+    bool room(uint32_t need) const { return n + need <= cap; }
+    void put(uint16_t s) { p[n++] = s; }
+    uint16_t back(uint32_t d) const { return p[n - d]; }
+    uint64_t count() const { return n; }
+};
+
+// The member's header (RFC 1952): where the deflate stream starts; 0: not a header this reader takes.
+static size_t deflate_start(const std::vector<uint8_t>& in, size_t n)
+{
+    if (n < 18 || in[0] != 31 || in[1] != 139 || in[2] != 8) return 0;
+    const uint8_t flg = in[3];
+    size_t at = 10;
+    if (flg & 4) { if (at + 2 > n) return 0; at += 2 + (in[at] | (size_t(in[at + 1]) << 8)); }
+    if (flg & 8) { while (at < n && in[at]) ++at; ++at; }
+    if (flg & 16) { while (at < n && in[at]) ++at; ++at; }
+    if (flg & 2) at += 2;
+    return at < n ? at : 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 4) return 2;
+    std::ifstream f(argv[1], std::ios::binary);
+    std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    const size_t n = file.size();
+    const uint64_t unit_bytes = std::strtoull(argv[3], nullptr, 10);
+    const uint64_t ratio = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 16;
+    std::FILE* out = std::fopen(argv[2], "wb");
+    const size_t ds = deflate_start(file, n);
+    if (!ds || unit_bytes < 64) { std::printf("header 0 0 0\n"); std::fclose(out); return 0; }
+    // the deflate stream and everything behind it (the trailer, further members) in a buffer of its own: aligned words, 16
+    // readable bytes behind — and at an odd byte offset within the words, as it lies in a file
+    const size_t len = n - ds;
+    std::vector<uint64_t> words((len + 3) / 8 + 4, 0);
+    uint8_t* base = reinterpret_cast<uint8_t*>(words.data()) + 3;
+    std::memcpy(base, file.data() + ds, len);
+    BitIn in; in.words = words.data(); in.lead = 24; in.nbits = uint64_t(len) * 8;
+
+    const uint64_t n_units = (len + unit_bytes - 1) / unit_bytes;
+    auto tables = std::make_unique<Tables>();
+    uint8_t lens[320];
+    // 1. guessed starts
+    std::vector<uint64_t> start(n_units, UINT64_MAX);
+    start[0] = 0;
+    for (uint64_t u = 1; u < n_units; ++u) {
+        const uint64_t lo = u * unit_bytes * 8, hi = std::min<uint64_t>((u + 1) * unit_bytes * 8, in.nbits);
+        for (uint64_t p = lo; p < hi; ++p) if (plausible_block_start(in, p, lens)) { start[u] = p; break; }
+    }
+    // 2. every unit with a start, decoded on its own
+    struct Unit { uint64_t start, end; uint32_t status; std::vector<uint16_t> sym; };
+    std::vector<Unit> units;
+    for (uint64_t u = 0; u < n_units; ++u) {
+        if (start[u] == UINT64_MAX) continue;
+        Unit x; x.start = start[u];
+        uint64_t next = u + 1;
+        while (next < n_units && start[next] == UINT64_MAX) ++next;          // a unit without a start belongs to the one before it
+        const uint64_t stop_bit = next < n_units ? next * unit_bytes * 8 : UINT64_MAX;
+        const uint64_t span = (next - u) * unit_bytes;
+        x.sym.resize(span * ratio + 1024);
+        ArraySink sink{x.sym.data(), x.sym.size()};
+        State st; st.pos = st.start_bit = x.start;
+        while (st.status == kOk) decode_some(in, *tables, lens, st, stop_bit, sink, 1000);      // in stretches, as the GPU does
+        x.end = st.pos; x.status = st.status;
+        x.sym.resize(sink.n);
+        units.push_back(std::move(x));
+        if (st.status == kFinal) break;                                      // what follows is the trailer
+    }
+    // 3. the chain
+    const char* verdict = "ok";
+    for (size_t k = 0; k < units.size(); ++k) {
+        const Unit& x = units[k];
+        if (x.status == kOutputFull) { verdict = "full"; break; }
+        if (x.status == kBadData || x.status == kInputEnd) { verdict = "bad"; break; }
+        if (k + 1 < units.size() ? (x.status != kBoundary || x.end != units[k + 1].start) : x.status != kFinal) { verdict = "chain"; break; }
+    }
+    unsigned long long bytes = 0;
+    if (!std::strcmp(verdict, "ok")) {
+        // 4 + 5. windows unit after unit, then the bytes
+        std::vector<uint8_t> win(kWindow, 0), next(kWindow, 0), text;
+        for (const Unit& x : units) {
+            text.resize(x.sym.size());
+            for (size_t i = 0; i < x.sym.size(); ++i) text[i] = x.sym[i] < 256 ? uint8_t(x.sym[i]) : win[x.sym[i] - 256];
+            std::fwrite(text.data(), 1, text.size(), out);
+            bytes += text.size();
+            for (uint32_t k = 0; k < kWindow; ++k) next[k] = window_byte(win.data(), x.sym.data(), x.sym.size(), k);
+            win.swap(next);
+        }
+    }
+    std::fclose(out);
+    const unsigned long long deflate_bytes = units.empty() ? 0 : (units.back().end + 7) / 8;
+    std::printf("%s %zu %llu %llu\n", verdict, units.size(), bytes, deflate_bytes);
+    return 0;
+}

@@ -603,10 +603,12 @@ def test_multi_gpu_cli_single_end_matches_oracle(exe, oracle, tmp_path, devices,
     src.write_bytes(uniform_fastq(rnd, 60000, 100, 9000, lambda k: b"r%07d" % k))
     exp, got = tmp_path / "exp.fq", tmp_path / "got.fq"
     tot, dup = oracle.filter_single(src, exp, FASTQ)
-    r = run(exe, "-i", src, "-o", got, "--fast", "-v", env={"FQD_DEVICES": devices, "FQD_EXCHANGE": exchange, "FQD_BLOCK_MB": "1", "FQD_SHARD_SLAB": slab})
-    assert r.returncode == 0, r.stderr
-    assert filecmp.cmp(got, exp, shallow=False)
-    assert r.stdout == f"{tot} reads processed, out of which {dup} duplicates were removed.\n"
+    for send_hash in ("0", "1"):                                 # the owners hash arrived keys again / the hashes travel with the keys
+        r = run(exe, "-i", src, "-o", got, "--fast", "-v", env={"FQD_DEVICES": devices, "FQD_EXCHANGE": exchange, "FQD_BLOCK_MB": "1", "FQD_SHARD_SLAB": slab,
+                                                                 "FQD_SHARD_SEND_HASH": send_hash})
+        assert r.returncode == 0, r.stderr
+        assert filecmp.cmp(got, exp, shallow=False)
+        assert r.stdout == f"{tot} reads processed, out of which {dup} duplicates were removed.\n"
     assert dup > 10000
 
 
@@ -619,10 +621,11 @@ def test_multi_gpu_cli_paired_matches_oracle(exe, oracle, tmp_path, devices):
     f2.write_bytes(uniform_fastq(rnd, 40000, 60, 40, lambda k: b"p%06d/2" % k))
     e1, e2, g1, g2 = (tmp_path / x for x in ("e1.fq", "e2.fq", "g1.fq", "g2.fq"))
     tot, dup, _ = oracle.filter_paired(f1, f2, e1, e2, FASTQ)
-    r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "-v", env={"FQD_DEVICES": devices, "FQD_BLOCK_MB": "1"})
-    assert r.returncode == 0, r.stderr
-    assert filecmp.cmp(g1, e1, shallow=False) and filecmp.cmp(g2, e2, shallow=False)
-    assert r.stdout == f"{tot} read pairs processed, out of which {dup} duplicates were removed.\n"
+    for send_hash in ("0", "1"):
+        r = run(exe, "-i", f1, "-u", f2, "-o", g1, "-p", g2, "--fast", "-v", env={"FQD_DEVICES": devices, "FQD_BLOCK_MB": "1", "FQD_SHARD_SEND_HASH": send_hash})
+        assert r.returncode == 0, r.stderr
+        assert filecmp.cmp(g1, e1, shallow=False) and filecmp.cmp(g2, e2, shallow=False)
+        assert r.stdout == f"{tot} read pairs processed, out of which {dup} duplicates were removed.\n"
     assert dup > 1000
 
 

@@ -11,7 +11,7 @@ LL = 150
 
 
 def _run(oracle, world, rounds, n_per, paired=False, transport="copy", slab_records=0, dup_permille=300, skew=0.0,
-         uneven=False, lens=(LL, LL), seed=5):
+         uneven=False, lens=(LL, LL), seed=5, send_hash=False, weak_hash=False):
     from fastq_dupaway_amd import Engine, Reads
     from fastq_dupaway_amd.shard import ShardGroup, unique_id
     S = 2 if paired else 1
@@ -35,10 +35,10 @@ def _run(oracle, world, rounds, n_per, paired=False, transport="copy", slab_reco
                     rows = bases[k][r][m][: n_per * lens[m]].view(n_per, lens[m])
                     rows[hit] = bases[0][0][m][: lens[m]].clone()
     keeps = [[torch.full((n_per,), 7, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(rounds)]
-    engines = [Engine(segments=S) for _ in range(world)]
+    engines = [Engine(segments=S, weak_hash=weak_hash) for _ in range(world)]
     uid = unique_id() if transport == "rccl" else None
     with ShardGroup(engines, world=world, first_rank=0, round_reads=n_per, len0=lens[0], len1=lens[1] if paired else 0,
-                    transport=transport, uid=uid, slab_records=slab_records) as g:
+                    transport=transport, uid=uid, slab_records=slab_records, send_hash=send_hash) as g:
         for k in range(rounds):
             segs = [[Reads(bases[k][r][m], uniform_len=lens[m], uniform_stride=lens[m]) for m in range(S)] for r in range(world)]
             g.round(segs, ns[k], keeps[k])
@@ -66,6 +66,29 @@ def test_shard_group_virtual_ranks(oracle, world, paired):
     stats = _run(oracle, world, rounds=3, n_per=20000, paired=paired, uneven=True)
     assert all(s["overflow_rounds"] == 0 for s in stats)
     assert all(s["rounds"] == 3 and s["ranks_in_comm"] == world for s in stats)
+
+
+@pytest.mark.parametrize("world,paired,slab,skew,n_per", [(1, False, 0, 0.0, 20000), (2, True, 0, 0.0, 20000), (4, False, 0, 0.0, 20000), (8, True, 0, 0.0, 20000),
+                                                          (3, False, 16, 0.0, 20000), (4, True, 0, 0.3, 30000), (2, False, 0, 0.0, 2_200_000)])
+def test_shard_group_hashes_travel_with_the_keys(oracle, world, paired, slab, skew, n_per):
+    """FQD_SHARD_SEND_HASH: the source's encoder writes every key's placement hash beside it, the hash slab travels with the key
+    slab and the owner inserts without hashing the arrived keys again (fqd_encode_slabs_hashed / fqd_insert_slabs_hashed) — same
+    flags as the oracle's, also where slabs spill or come again (those rounds are hashed by their owner as before), on the
+    atomic and the bulk insert path, and with a weak placement hash (tag collisions verified as ever)."""
+    stats = _run(oracle, world, rounds=3 if n_per < 100000 else 2, n_per=n_per, paired=paired, uneven=n_per < 100000, slab_records=slab, skew=skew,
+                 send_hash=True, dup_permille=300 if n_per < 100000 else 200)
+    plain = _run(oracle, world, rounds=1, n_per=5000, paired=paired)
+    assert stats[0]["bytes_sent"] > 0 and plain[0]["bytes_sent"] > 0
+    if slab == 0 and skew == 0.0:
+        assert all(s["overflow_rounds"] == 0 for s in stats)
+        # 8 bytes a key slot more on the wire
+        per_round = stats[0]["bytes_sent"] / stats[0]["rounds"]
+        K = (16 if paired else 8) * 8
+        assert per_round >= world * stats[0]["slab_records"] * (K + 8)
+
+
+def test_shard_group_hashes_travel_weak_hash(oracle):
+    _run(oracle, 3, rounds=3, n_per=20000, send_hash=True, weak_hash=True)
 
 
 def test_shard_group_mates_of_unequal_length(oracle):

@@ -1,8 +1,10 @@
 // mix_probe — what does this chip's HBM sustain for the staged encoder's TRAFFIC SHAPE, with no work attached?
-// The encoder reads 150 B and writes 72 B per read (64-byte key + 8-byte hash): 22.2 GB per 100 M reads in 3.9-4.2 ms =
-// 5.3-5.7 TB/s.  The guide's 6.29 TB/s "copy ceiling" is a 1:1 copy.  This measures bare grid-stride kernels that move
+// The encoder reads 150 B and writes 72 B per read (64-byte key + 8-byte hash): 22.2 GB per 100 M reads in 3.7-4.2 ms =
+// 5.3-6.0 TB/s.  The guide's 6.29 TB/s "copy ceiling" is a 1:1 copy.  This measures bare grid-stride kernels that move
 // the same bytes in the same proportion — R 16-byte loads per W 16-byte stores per lane and step, non-temporal both —
 // so that the encoder can be priced against ITS OWN ceiling.
+// (The first run of this probe, gpurun_out/r4/mix_probe.jsonl, reported 7.3-7.5 TB/s for the 2:1 mix: its stores used
+// only some of the loaded values and the compiler had removed the other loads.  Fixed; see below.)
 //   R:W = 1:0 read only · 1:1 copy · 2:1 the encoder's mix (150:72 = 2.08:1) · 0:1 write only
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/mix_probe tools/mix_probe.hip ; run: tools/mix_probe [GB read, default 15]
 #include <hip/hip_runtime.h>
@@ -27,16 +29,20 @@ __global__ __launch_bounds__(256) void mix(const u32x4* __restrict__ src, u32x4*
             const u32x4* p = &src[(s * R + r) * lanes + me];
             v[r] = NT ? __builtin_nontemporal_load(p) : *p;
         }
+        // every store carries a value that depends on EVERY load of the step: the first version of this probe stored
+        // v[w % R], the compiler dropped the loads nobody used, and its "2:1 mix" was a 1:1 copy of half the bytes
+        u32x4 all = {0, 0, 0, 0};
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc ^= v[r];
+        for (int r = 0; r < R; ++r) all ^= v[r];
+        acc ^= all;
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             u32x4* q = &dst[(s * W + w) * lanes + me];
-            const u32x4 x = R > 0 ? v[w % (R > 0 ? R : 1)] : u32x4{uint32_t(s), uint32_t(w), 0, 0};
+            const u32x4 x = R > 0 ? all + u32x4{uint32_t(w), 0, 0, 0} : u32x4{uint32_t(s), uint32_t(w), 0, 0};
             if (NT) __builtin_nontemporal_store(x, q); else *q = x;
         }
     }
-    if (W == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = acc.x;
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[0] = acc.x;
 }
 
 template <int R, int W, bool NT>

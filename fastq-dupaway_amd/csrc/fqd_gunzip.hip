@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <unistd.h>
 
 #include "../../include/fqdupaway.h"
 #include "fqd_gunzip_core.hpp"
@@ -84,20 +85,27 @@ struct RingSink {
     uint16_t* ring;                      // LDS, kRing symbols
     const uint16_t* out;                 // HBM: the unit's symbols moved out so far ([0, flushed))
     uint64_t cap, n, flushed;
+    uint32_t lane;
     __device__ __forceinline__ bool room(uint32_t need) const { return n + need <= cap; }
-    __device__ __forceinline__ void put(uint16_t s) { ring[n & (kRing - 1u)] = s; ++n; }
-    __device__ __forceinline__ uint16_t back(uint32_t d) const
+    __device__ __forceinline__ void put(uint16_t s) { ring[n & (kRing - 1u)] = s; ++n; }       // (every lane the same symbol to the same place)
+    // the ring still holds place i unless i + kRing has been put; n never gets further than flushed + kStretch + 258 + 7
+    __device__ __forceinline__ uint16_t at(uint64_t i) const { return i + kRing > flushed + kStretch + 512u ? ring[i & (kRing - 1u)] : out[i]; }
+    // a match: the places it reads all hold their symbols before it starts (k mod d), so the lanes copy 64 symbols a turn
+    __device__ __forceinline__ void copy(uint32_t d, uint32_t len)
     {
-        const uint64_t i = n - d;
-        // the ring still holds i unless i + kRing has been put; n never gets further than flushed + kStretch + 258 + 7
-        return i + kRing > flushed + kStretch + 512u ? ring[i & (kRing - 1u)] : out[i];
+        const int64_t from = int64_t(n) - int64_t(d);
+        for (uint32_t k = lane; k < len; k += kWave) {
+            const int64_t i = from + int64_t(k < d ? k : k % d);
+            ring[(n + k) & (kRing - 1u)] = i < 0 ? uint16_t(256 + int64_t(kWindow) + i) : at(uint64_t(i));
+        }
+        n += len;
     }
     __device__ __forceinline__ uint64_t count() const { return n; }
 };
 
 __global__ __launch_bounds__(kWave)
 void gz_decode_kernel(BitIn in, const UnitIn* __restrict__ units, uint32_t n_units, uint16_t* __restrict__ sym, UnitOut* __restrict__ result,
-                      uint32_t* __restrict__ next_unit)
+                      uint32_t* __restrict__ next_unit, unsigned long long* __restrict__ debug /* 8 words, FQD_GUNZIP_TRACE */)
 {
     __shared__ Tables tables;
     __shared__ __attribute__((aligned(16))) uint16_t ring[kRing];
@@ -116,13 +124,18 @@ void gz_decode_kernel(BitIn in, const UnitIn* __restrict__ units, uint32_t n_uni
         uint16_t* out = sym + ui.sym_at;
         State st;
         st.pos = st.start_bit = ui.start_bit;
-        RingSink sink{ring, out, ui.sym_cap, 0, 0};
+        RingSink sink{ring, out, ui.sym_cap, 0, 0, lane};
         uint64_t flushed = 0;
-        for (;;) {
+        for (uint64_t stretch = 0;; ++stretch) {
+            // EVERY lane runs the decoder, on the same bits to the same end: the control flow of 6700 instructions stays uniform
+            // (a first version ran it under `if (lane == 0)` and never came back from the GPU, while the very same code, ring and
+            // all, runs to its end on the CPU); what the lanes write — tables, ring — they all write alike
+            sink.flushed = flushed;
+            decode_some(in, tables, lens, st, ui.stop_bit, sink, kStretch);
+            if (stretch > (ui.sym_cap / kStretch) + 16u && st.status == kOk) st.status = kBadData;          // (cannot happen: every stretch adds symbols)
             if (lane == 0) {
-                sink.flushed = flushed;
-                decode_some(in, tables, lens, st, ui.stop_bit, sink, kStretch);
                 sh_n = sink.n; sh_status = st.status;
+                if (debug) { debug[0] = stretch; debug[1] = sink.n; debug[2] = st.pos; debug[3] = st.status; debug[4] = st.in_block; debug[5] = u; }
             }
             __syncthreads();
             const uint64_t n = sh_n;
@@ -211,12 +224,21 @@ void gz_crc_kernel(const uint8_t* __restrict__ text, uint64_t total, uint64_t n_
         // a short last slice: its bytes are moved to the END of the 64 KiB frame (leading zero bytes do not change a raw register started from 0)
         const uint64_t len = end - sl * kSlice, pad = kSlice - len;
         uint32_t r = 0;
-        for (uint32_t k = 0; k < kCrcChunk; ++k) {
-            const uint64_t frame = uint64_t(t) * kCrcChunk + k;                 // position in the frame
-            const uint8_t b = frame >= pad ? text[sl * kSlice + (frame - pad)] : uint8_t(0);
-            r = table[(r ^ b) & 0xFFu] ^ (r >> 8);
+        if (pad == 0 && (reinterpret_cast<uintptr_t>(text + lo) & 15u) == 0) {       // a whole slice: 16 bytes a load
+            const uint4* p16 = reinterpret_cast<const uint4*>(text + lo);
+            for (uint32_t k = 0; k < kCrcChunk / 16u; ++k) {
+                const uint4 v = p16[k];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 16; ++j) r = table[(r ^ (w[j >> 2] >> (8 * (j & 3)))) & 0xFFu] ^ (r >> 8);
+            }
+        } else {
+            for (uint32_t k = 0; k < kCrcChunk; ++k) {
+                const uint64_t frame = uint64_t(t) * kCrcChunk + k;             // position in the frame
+                const uint8_t b = frame >= pad ? text[sl * kSlice + (frame - pad)] : uint8_t(0);
+                r = table[(r ^ b) & 0xFFu] ^ (r >> 8);
+            }
         }
-        (void)lo;
         reg[t] = r;
         __syncthreads();
         for (uint32_t k = 0; k < 8u; ++k) {
@@ -278,13 +300,18 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
     int n_cu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, fqd_internal_device(e)) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
 
+    static const bool trace = std::getenv("FQD_GUNZIP_TRACE") != nullptr;      // stages to stderr as they are reached
+#define GZ_TRACE(...) do { if (trace) { std::fprintf(stderr, "[gunzip] " __VA_ARGS__); std::fputc('\n', stderr); std::fflush(stderr); } } while (0)
     BitIn in;
     const uintptr_t addr = reinterpret_cast<uintptr_t>(deflate);
     in.words = reinterpret_cast<const uint64_t*>(addr & ~uintptr_t(7));
     in.lead = uint64_t(addr & 7u) * 8u;
     in.nbits = avail_bytes * 8u;
 
-    // units: small enough that there are several per wave slot of the chip, large enough to hold a block start more often than not
+    // units: small enough that there are several per wave slot of the chip, large enough to hold a block start more often than
+    // not (zlib ends a block every 16 K codes: some 20-50 KB packed).  (One decoder per LANE instead of per wave — tables in HBM,
+    // 16 KiB units, tens of thousands of lanes waiting on memory at once — was measured: 2.6 GB/s of text against 4.6; lanes of
+    // a wave that copy matches of different lengths wait for the longest.)
     uint64_t unit_bytes = std::min<uint64_t>(512u << 10, std::max<uint64_t>(64u << 10, (avail_bytes / 8192u + 4095u) & ~uint64_t(4095)));
     if (const char* v = std::getenv("FQD_GUNZIP_UNIT_KB")) { const long kb = std::atol(v); if (kb > 0) unit_bytes = uint64_t(kb) << 10; }
     uint64_t ratio = 8;                                                      // symbols of room per compressed byte (FASTQ packs 3-6 fold)
@@ -297,6 +324,7 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
     hipLaunchKernelGGL(gz_find_starts_kernel, dim3(uint32_t(std::min<uint64_t>(n_nominal, uint64_t(n_cu) * 16u))), dim3(kWave), 0, stream,
                        in, unit_bytes * 8u, n_nominal, d_start.as<uint64_t>());
     GZ_TRY(e, hipGetLastError());
+    GZ_TRACE("%llu bytes, %llu units of %llu bytes: looking for block starts", (unsigned long long)avail_bytes, (unsigned long long)n_nominal, (unsigned long long)unit_bytes);
     std::vector<uint64_t> start(n_nominal);
     GZ_TRY(e, hipMemcpyAsync(start.data(), d_start.p, n_nominal * 8, hipMemcpyDeviceToHost, stream));
     GZ_TRY(e, hipStreamSynchronize(stream));
@@ -313,6 +341,7 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
         units.push_back(x);
     }
 
+    GZ_TRACE("%zu units have a start", units.size());
     // ---- 2-5 in batches of units whose symbols fit the scratch
     uint64_t scratch_syms = uint64_t(4) << 30;                               // 8 GiB of symbols
     if (const char* v = std::getenv("FQD_GUNZIP_SCRATCH_MB")) { const long mb = std::atol(v); if (mb > 0) scratch_syms = (uint64_t(mb) << 20) / 2; }
@@ -324,11 +353,17 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
         for (const UnitIn& x : units) all += x.sym_cap;
         scratch_syms = std::min(scratch_syms, all);
     }
-    DevMem d_sym, d_units, d_result, d_text_at, d_windows, d_counter;
+    DevMem d_sym, d_units, d_result, d_text_at, d_windows, d_counter, d_debug;
+    unsigned long long* h_debug = nullptr;
+    if (trace) {                                                              // host-visible, so that a kernel that never ends can still be read
+        GZ_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&h_debug), 64, hipHostMallocMapped));
+        std::memset(h_debug, 0xFF, 64);
+        d_debug.p = nullptr;
+    }
     GZ_TRY(e, d_sym.get(scratch_syms * 2 + 64));
     GZ_TRY(e, d_counter.get(64));
     std::vector<uint8_t> carry(kWindow, 0);                                   // the window before the next batch's first unit
-    uint64_t total = 0, expect_start = 0;
+    uint64_t total = 0, expect_start = 0, repairs = 0;
     bool final_seen = false, good = true;
     std::vector<UnitOut> result;
     std::vector<uint64_t> text_at;
@@ -345,17 +380,37 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
         GZ_TRY(e, hipMemcpyAsync(d_units.p, units.data() + at, nb * sizeof(UnitIn), hipMemcpyHostToDevice, stream));
         GZ_TRY(e, hipMemsetAsync(d_counter.p, 0, 64, stream));
         hipLaunchKernelGGL(gz_decode_kernel, dim3(std::min<uint32_t>(nb, uint32_t(n_cu) * 10u)), dim3(kWave), 0, stream,
-                           in, d_units.as<const UnitIn>(), nb, d_sym.as<uint16_t>(), d_result.as<UnitOut>(), d_counter.as<uint32_t>());
+                           in, d_units.as<const UnitIn>(), nb, d_sym.as<uint16_t>(), d_result.as<UnitOut>(), d_counter.as<uint32_t>(),
+                           h_debug);
         GZ_TRY(e, hipGetLastError());
+        GZ_TRACE("batch of %u units queued for decoding (%llu symbols of room)", nb, (unsigned long long)used);
+        if (trace) for (int tick = 0; tick < 20 && hipStreamQuery(stream) == hipErrorNotReady; ++tick) {
+            usleep(200000);
+            GZ_TRACE("  ... stretch %llu symbols %llu pos %llu status %llu in_block %llu unit %llu", h_debug[0], h_debug[1], h_debug[2], h_debug[3], h_debug[4], h_debug[5]);
+        }
         result.resize(nb);
         GZ_TRY(e, hipMemcpyAsync(result.data(), d_result.p, nb * sizeof(UnitOut), hipMemcpyDeviceToHost, stream));
         GZ_TRY(e, hipStreamSynchronize(stream));
+        GZ_TRACE("decoded: first unit status %u, %llu symbols, end bit %llu", result[0].status, (unsigned long long)result[0].n_sym, (unsigned long long)result[0].end_bit);
         // ---- 3. the chain
         text_at.resize(nb);
         uint32_t live = 0;
         for (uint32_t k = 0; k < nb && good && !final_seen; ++k) {
-            const UnitIn& x = units[at + k]; const UnitOut& r = result[k];
-            if (x.start_bit != expect_start) { good = false; break; }
+            UnitIn& x = units[at + k]; UnitOut& r = result[k];
+            if (x.start_bit != expect_start) {
+                // a guess that did not hold (a header-like stretch of bits inside a block: a few per gigabyte): the unit before ended
+                // at the true boundary, so this one is decoded again from there — one small launch — and the chain goes on
+                if (++repairs > 64u + units.size() / 16u) { good = false; break; }       // (damage, not bad luck)
+                x.start_bit = expect_start;
+                GZ_TRY(e, hipMemcpyAsync(d_units.as<UnitIn>() + k, &x, sizeof(UnitIn), hipMemcpyHostToDevice, stream));
+                GZ_TRY(e, hipMemsetAsync(d_counter.p, 0, 64, stream));
+                hipLaunchKernelGGL(gz_decode_kernel, dim3(1), dim3(kWave), 0, stream, in, d_units.as<const UnitIn>() + k, 1u, d_sym.as<uint16_t>(),
+                                   d_result.as<UnitOut>() + k, d_counter.as<uint32_t>(), static_cast<unsigned long long*>(nullptr));
+                GZ_TRY(e, hipGetLastError());
+                GZ_TRY(e, hipMemcpyAsync(&r, d_result.as<UnitOut>() + k, sizeof(UnitOut), hipMemcpyDeviceToHost, stream));
+                GZ_TRY(e, hipStreamSynchronize(stream));
+                GZ_TRACE("unit %zu decoded again from bit %llu: status %u, %llu symbols", at + k, (unsigned long long)expect_start, r.status, (unsigned long long)r.n_sym);
+            }
             if (r.status != kBoundary && r.status != kFinal) { good = false; break; }
             if (total + r.n_sym > text_cap) { good = false; break; }
             text_at[k] = total; total += r.n_sym;
@@ -375,6 +430,7 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
         GZ_TRY(e, hipGetLastError());
         GZ_TRY(e, hipMemcpyAsync(carry.data(), d_windows.as<uint8_t>() + uint64_t(live) * kWindow, kWindow, hipMemcpyDeviceToHost, stream));
         GZ_TRY(e, hipStreamSynchronize(stream));
+        GZ_TRACE("windows and bytes of %u units done, %llu bytes of text so far", live, (unsigned long long)total);
         at = hi;
     }
     if (!good || !final_seen) return FQD_OK;                                  // *ok stays 0: the caller reads the file the host way
@@ -395,6 +451,7 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
         hipLaunchKernelGGL(gz_crc_kernel, dim3(uint32_t(std::min<uint64_t>(n_slices, uint64_t(n_cu) * 8u))), dim3(kCrcThreads), 0, stream,
                            static_cast<const uint8_t*>(text), total, n_slices, d_shift.as<const uint32_t>(), d_raw.as<uint32_t>());
         GZ_TRY(e, hipGetLastError());
+        GZ_TRACE("CRC of %llu slices queued", (unsigned long long)n_slices);
         std::vector<uint32_t> raw(n_slices);
         GZ_TRY(e, hipMemcpyAsync(raw.data(), d_raw.p, n_slices * 4, hipMemcpyDeviceToHost, stream));
         GZ_TRY(e, hipStreamSynchronize(stream));

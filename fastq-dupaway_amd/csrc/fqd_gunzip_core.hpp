@@ -28,8 +28,10 @@
 
 #if defined(__HIPCC__)
 #define FQD_HD __host__ __device__ __forceinline__
+#define FQD_HD_CALL __host__ __device__ __attribute__((noinline))     /* the long ones: called, not inlined — a kernel that inlines the whole decoder is 6700 instructions of one control-flow graph */
 #else
 #define FQD_HD inline
+#define FQD_HD_CALL inline
 #endif
 
 namespace fqd {
@@ -42,7 +44,7 @@ constexpr uint32_t kNoStart = 0xFFFFFFFFu;
 enum Status : uint32_t { kOk = 0, kBoundary = 1 /* stopped where the next unit begins */, kFinal = 2 /* through the final block */,
                          kBadData = 3, kOutputFull = 4, kInputEnd = 5 };
 
-// Bits of the stream, least significant first, read as aligned 64-bit words (the buffer has 16 readable bytes behind it).
+// Bits of the stream, least significant first, read as aligned 64-bit words (the buffer has 32 readable bytes behind it: the decoder loads a word ahead).
 struct BitIn {
     const uint64_t* words = nullptr;     // 8-byte aligned
     uint64_t lead = 0;                   // bits of words[0] before the stream's first bit
@@ -101,7 +103,7 @@ FQD_HD uint32_t reverse15(uint32_t v)                        // the low 15 bits,
 
 // Builds one code from its lengths.  false: over-subscribed, or incomplete where zlib does not let that pass.
 // which: 0 literal/length (table lit, kLitBits), 1 distance (table dist, kDistBits).
-FQD_HD bool build_code(const uint8_t* lens, uint32_t n, bool may_be_single, uint32_t* table, uint32_t index_bits, Code& c, bool is_dist)
+FQD_HD_CALL bool build_code(const uint8_t* lens, uint32_t n, bool may_be_single, uint32_t* table, uint32_t index_bits, Code& c, bool is_dist)
 {
     uint32_t count[16];
     for (uint32_t l = 0; l < 16u; ++l) count[l] = 0;
@@ -147,7 +149,7 @@ FQD_HD uint32_t slow_decode(const Code& c, uint64_t w, uint32_t& len)
 // The code lengths of a dynamic block whose three header bits have been read: pos -> first code of the block, lens[0..nlen)
 // literal/length, lens[nlen..nlen+ndist) distance.  false: no such header (counts out of range, a code-length code that is
 // not complete, lengths that overrun, no end-of-block code).  lens: 320 bytes.
-FQD_HD bool read_code_lengths(const BitIn& in, uint64_t& pos, uint8_t* lens, uint32_t& nlen, uint32_t& ndist)
+FQD_HD_CALL bool read_code_lengths(const BitIn& in, uint64_t& pos, uint8_t* lens, uint32_t& nlen, uint32_t& ndist)
 {
     uint64_t w = in.peek(pos);
     nlen = uint32_t(w & 31u) + 257u; ndist = uint32_t((w >> 5) & 31u) + 1u;
@@ -182,6 +184,7 @@ FQD_HD bool read_code_lengths(const BitIn& in, uint64_t& pos, uint8_t* lens, uin
     const uint32_t total = nlen + ndist;
     uint32_t i = 0;
     while (i < total) {
+        if (pos > in.nbits) return false;                                  // (garbage read as a header: no read beyond the 16 bytes behind the stream)
         w = in.peek(pos);
         uint32_t code = 0, l = 0, sym = 0xFFu;
         for (l = 1; l <= 7u; ++l) {                                       // a bit at a time, first bit the most significant of the code
@@ -217,7 +220,7 @@ FQD_HD bool parse_dynamic_header(const BitIn& in, uint64_t& pos, Tables& t, uint
     return build_code(lens, nlen, true, t.lit, kLitBits, t.lc, false) && build_code(lens + nlen, ndist, true, t.dist, kDistBits, t.dc, true);
 }
 
-FQD_HD void fixed_codes(Tables& t, uint8_t* lens)
+FQD_HD_CALL void fixed_codes(Tables& t, uint8_t* lens)
 {
     for (uint32_t s = 0; s < 288u; ++s) lens[s] = uint8_t(s < 144u ? 8u : s < 256u ? 9u : s < 280u ? 7u : 8u);
     (void)build_code(lens, 288u, false, t.lit, kLitBits, t.lc, false);
@@ -230,7 +233,7 @@ FQD_HD void fixed_codes(Tables& t, uint8_t* lens)
 // and the second wants 320 bytes of scratch: the three header bits, the counts, and a complete code-length code ...
 FQD_HD bool block_start_first_look(const BitIn& in, uint64_t pos)
 {
-    if (pos + 17 + 12 > in.nbits) return false;
+    if (pos + 300 > in.nbits) return false;                               // (a dynamic block's header alone is longer: 17 bits, >= 4 x 3, >= 257 lengths)
     uint64_t w = in.peek(pos);
     if ((w & 7u) != 4u) return false;                                     // BFINAL = 0, BTYPE = 2 (bits: 0, then 0 1)
     if (((w >> 3) & 31u) > 29u || ((w >> 8) & 31u) > 29u) return false;   // HLIT <= 29 (286 codes), HDIST <= 29
@@ -260,7 +263,9 @@ FQD_HD bool plausible_block_start(const BitIn& in, uint64_t pos, uint8_t* lens)
 // The sink a decoder writes through (the GPU's is an LDS ring flushed by the whole wave, the CPU harness's an array):
 //   bool room(uint32_t n)      at least n more symbols fit (258 are asked for before every code)
 //   void put(uint16_t s)
-//   uint16_t back(uint32_t d)  the symbol d places back (1 = the last one put); d <= count()
+//   void copy(uint32_t d, uint32_t len)   a match: len symbols, symbol k = the one at place count() - d + (k mod d) before the
+//                              copy, or, where that place is negative, the window symbol 256 + kWindow + place (the GPU's
+//                              sink lets every lane of the wave copy its share: the places read all exist beforehand)
 //   uint64_t count()
 // A decoder's state between calls (the GPU decodes a stretch, lets the wave flush, and goes on).
 struct State {
@@ -280,7 +285,10 @@ template <class Sink>
 FQD_HD void decode_some(const BitIn& in, Tables& t, uint8_t* lens, State& st, uint64_t stop_bit, Sink& out, uint64_t budget)
 {
     const uint64_t until = out.count() + budget;
+    // every turn of the loops below produces a symbol, ends a block or ends the unit; `fuel` holds them to that whatever the data
+    uint64_t fuel = 2u * budget + 4096u;
     while (st.status == kOk && out.count() < until) {
+        if (fuel-- == 0u) { st.status = kBadData; return; }
         if (st.in_block == 0u) {
             if (st.pos + 3 > in.nbits) { st.status = kInputEnd; return; }
             const uint64_t w = in.peek(st.pos);
@@ -305,6 +313,7 @@ FQD_HD void decode_some(const BitIn& in, Tables& t, uint8_t* lens, State& st, ui
         }
         if (st.in_block == 2u) {
             while (st.stored_left && out.count() < until) {
+                if (fuel-- == 0u) { st.status = kBadData; return; }
                 if (!out.room(8)) { st.status = kOutputFull; return; }
                 uint64_t w = in.peek(st.pos);
                 const uint32_t n = st.stored_left < 7u ? st.stored_left : 7u;      // (peek gives 57 bits)
@@ -314,33 +323,56 @@ FQD_HD void decode_some(const BitIn& in, Tables& t, uint8_t* lens, State& st, ui
             if (st.stored_left == 0u) { st.in_block = 0u; if (st.last) { st.status = kFinal; return; } }
             continue;
         }
-        // ---- a compressed block: the bits in a register, refilled from the stream when fewer than 48 are left ---------------
+        // ---- a compressed block ------------------------------------------------------------------------------------------------
+        // The bits in a register (`bb`, the low `bc` of them valid), topped up 32 at a time; the 64-bit word they come from is
+        // loaded ONE WORD AHEAD of its use: on the GPU a load that the next code has to wait for costs a trip to L2 or HBM —
+        // some thousand clocks against the hundred or two a code takes — and the first version of this loop (57 fresh bits
+        // from memory whenever fewer than 48 were left, i.e. every code or two) ran at 2300 clocks per code.
         uint64_t pos = st.pos;
-        uint64_t bb = in.peek(pos);
-        uint32_t bc = 57;                                                 // valid bits in bb
+        const uint64_t p0 = pos + in.lead;
+        uint64_t wi = p0 >> 6;                                            // word being drained
+        uint64_t cur = in.words[wi], ahead = in.words[wi + 1];
+        uint32_t half = uint32_t((p0 >> 5) & 1u);                         // next half of `cur` to take
+        uint64_t bb; uint32_t bc;
+        {
+            const uint32_t s5 = uint32_t(p0 & 31u);                       // bits of the current half already consumed
+            bb = (half ? cur >> 32 : cur & 0xFFFFFFFFull) >> s5; bc = 32u - s5;
+            if (half) { cur = ahead; ++wi; ahead = in.words[wi + 1]; }
+            half ^= 1u;
+        }
+        auto refill = [&]() {                                             // bc <= 32 -> bc + 32
+            bb |= (half ? cur >> 32 : cur & 0xFFFFFFFFull) << bc; bc += 32u;
+            if (half) { cur = ahead; ++wi; ahead = in.words[wi + 1]; }
+            half ^= 1u;
+        };
         bool end_of_block = false;
+        uint32_t bad = kOk;
         while (out.count() < until) {
-            if (bc < 48u) { bb = in.peek(pos); bc = 57; }
-            if (!out.room(258)) { st.pos = pos; st.status = kOutputFull; return; }
-            uint32_t e = t.lit[bb & ((1u << kLitBits) - 1u)];
+            if (fuel-- == 0u) { bad = kBadData; break; }
+            if (bc <= 32u) {
+                if (pos > in.nbits) { bad = kInputEnd; break; }           // (damaged or cut data: no read beyond the 16 bytes behind the stream)
+                refill();
+            }
+            if (!out.room(258)) { bad = kOutputFull; break; }
+            uint32_t e = t.lit[bb & ((1u << kLitBits) - 1u)];             // >= 33 bits are there: a code and its extra bits take 20 at most
             if ((e & 15u) == 0u) {
                 uint32_t l;
-                const uint32_t s = slow_decode(t.lc, bb, l);
-                if (l == 0u || s > 285u) { st.pos = pos; st.status = kBadData; return; }
-                e = lit_entry(s, l);
+                const uint32_t sy = slow_decode(t.lc, bb, l);
+                if (l == 0u || sy > 285u) { bad = kBadData; break; }
+                e = lit_entry(sy, l);
             }
             const uint32_t kind = (e >> 4) & 3u, cl = e & 15u;
             if (kind == 0u) { out.put(uint16_t(e >> 16)); bb >>= cl; bc -= cl; pos += cl; continue; }
             if (kind == 2u) { pos += cl; end_of_block = true; break; }
-            // a length: its code and extra bits, then the distance's (15 + 5 + 15 + 13 = 48 bits at most)
             const uint32_t ex = (e >> 8) & 31u;
             const uint32_t length = (e >> 16) + uint32_t((bb >> cl) & ((1u << ex) - 1u));
             bb >>= cl + ex; bc -= cl + ex; pos += cl + ex;
+            if (bc <= 32u) refill();                                      // the distance: 15 + 13 bits at most
             uint32_t f = t.dist[bb & ((1u << kDistBits) - 1u)];
             if ((f & 15u) == 0u) {
                 uint32_t l;
                 const uint32_t ds = slow_decode(t.dc, bb, l);
-                if (l == 0u || ds > 29u) { st.pos = pos; st.status = kBadData; return; }
+                if (l == 0u || ds > 29u) { bad = kBadData; break; }
                 f = dist_entry(ds, l);
             }
             const uint32_t dl = f & 15u, dx = (f >> 8) & 31u;
@@ -349,15 +381,13 @@ FQD_HD void decode_some(const BitIn& in, Tables& t, uint8_t* lens, State& st, ui
             const uint64_t have = out.count();
             if (d > have) {
                 const uint32_t before = uint32_t(d - have);               // the match starts this far before the unit's first byte
-                if (before > kWindow) { st.pos = pos; st.status = kBadData; return; }
+                if (before > kWindow) { bad = kBadData; break; }
                 if (before > st.deepest) st.deepest = before;
             }
-            for (uint32_t k = 0; k < length; ++k) {
-                const uint64_t n = have + k;
-                out.put(d > n ? uint16_t(256u + (kWindow - uint32_t(d - n))) : out.back(d));
-            }
+            out.copy(d, length);
         }
         st.pos = pos;
+        if (bad != kOk) { st.status = bad; return; }
         if (pos > in.nbits) { st.status = kInputEnd; return; }
         if (end_of_block) { st.in_block = 0u; if (st.last) { st.status = kFinal; return; } }
     }

@@ -273,6 +273,13 @@ class Engine:
                                              self._p(crc), n_members, self._p(text), C.byref(bad)))
         return int(bad.value)
 
+    def gunzip(self, deflate, avail: int, text):
+        """An ordinary gzip member's deflate stream (device bytes from its first byte on) inflated into text (device); returns
+        (ok, text_bytes, deflate_bytes, crc32)."""
+        tb, db, crc, ok = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0), C.c_int32(0)
+        self._check(self._L.fqd_gunzip(self._h, self._p(deflate), avail, self._p(text), text.numel(), C.byref(tb), C.byref(db), C.byref(crc), C.byref(ok)))
+        return bool(ok.value), int(tb.value), int(db.value), int(crc.value)
+
     def count_lines(self, text, n: int) -> int:
         lines = C.c_uint64(0)
         self._check(self._L.fqd_count_lines(self._h, self._p(text), n, C.byref(lines)))

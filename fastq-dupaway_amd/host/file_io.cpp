@@ -335,7 +335,14 @@ size_t InputFile::read(char* dst, size_t n, unsigned threads)
             const unsigned want = static_cast<unsigned>(std::min<size_t>(n - got, 1u << 30));
             const int k = gzread(g_, dst + got, want);
             if (k < 0) throw std::runtime_error("gzip input is corrupt or truncated");
-            if (k == 0) eof_ = true;
+            if (k == 0) {
+                // zlib hands out what a stream that ends too early held and says so only now (Z_BUF_ERROR at end of file): the
+                // reference's decompressor throws on such a file (file_utils.cpp:59-66), a clean end of input this is not
+                int en = Z_OK;
+                (void)gzerror(g_, &en);
+                if (en == Z_BUF_ERROR || en == Z_DATA_ERROR) throw std::runtime_error("gzip input is corrupt or truncated");
+                eof_ = true;
+            }
             got += static_cast<size_t>(k);
         } else {
             const ssize_t k = regular_ ? ::pread(fd_, dst + got, n - got, static_cast<off_t>(offset_)) : ::read(fd_, dst + got, n - got);

@@ -253,6 +253,69 @@ bool fetch_plain(const std::string& name, size_t block_bytes, int device, FileOn
     return at == size;
 }
 
+// An ORDINARY gzip file (one member, one long deflate stream: what gzip, pigz and sequencers write) to HBM as it lies on disk
+// and inflated THERE (fqd_gunzip: block starts guessed per unit, units decoded into symbols, windows, bytes).  Opt-in,
+// FQD_GUNZIP_ORDINARY_DEVICE=1: the kernels reach 4.6 GB/s of text on one MI355X, the several-thread host reader
+// (host/pgzip.hpp) 5.4 GB/s on the GPU box's share of cores — the device way takes the cores out of the job, not time.
+// false: not such a file, or anything irregular (a guess that did not hold, damage, CRC or length other than the trailer's,
+// further members): nothing is reported, the caller reads the file the host way.
+bool fetch_gzip_ordinary(const std::string& name, size_t block_bytes, int device, FileOnDevice& f, uint64_t& text_bytes)
+{
+    static const bool wanted = [] { const char* v = std::getenv("FQD_GUNZIP_ORDINARY_DEVICE"); return v && std::atoi(v) != 0; }();
+    uint64_t size = 0;
+    if (!wanted || !has_gz_extension(name) || !is_regular_file(name, size) || size < 28) return false;
+    InputFile file(name, true);
+    HIP_OK(hipSetDevice(device));
+    hipStream_t up = nullptr;
+    HIP_OK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    struct Guard { hipStream_t s; ~Guard() { (void)hipStreamDestroy(s); } } g{up};
+    Pinned<char> block[2];
+    block[0].reserve(block_bytes); block[1].reserve(block_bytes);
+    Device<char> comp;
+    comp.reserve(size + 64);
+    HIP_OK(hipMemsetAsync(comp.p + size, 0, 64, up));
+    uint64_t at = 0;
+    size_t header = 0;
+    unsigned char tail[8] = {0};
+    for (int k = 0;; k ^= 1) {                                   // the copy of one block overlaps the read of the next
+        const size_t got = file.read(block[k].p, block_bytes, host_threads());
+        HIP_OK(hipStreamSynchronize(up));                          // the other block's copy
+        if (got == 0) break;
+        if (at + got > size) return false;                         // the file grew under us
+        if (at == 0) {
+            // the member's header (RFC 1952): magic, method 8, the optional fields; a BGZF file never comes here (fetch_bgzf took it)
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(block[k].p);
+            if (got < 18 || p[0] != 31 || p[1] != 139 || p[2] != 8 || (p[3] & 0xE0)) return false;
+            size_t h = 10;
+            if (p[3] & 4) { if (h + 2 > got) return false; h += 2 + (p[h] | (size_t(p[h + 1]) << 8)); }
+            if (p[3] & 8) { while (h < got && p[h]) ++h; ++h; }
+            if (p[3] & 16) { while (h < got && p[h]) ++h; ++h; }
+            if (p[3] & 2) h += 2;
+            if (h + 10 > got) return false;
+            header = h;
+        }
+        // the last eight bytes of the file, wherever the blocks cut it
+        for (size_t i = 0; i < got; ++i) if (at + i + 8 >= size) tail[at + i + 8 - size] = static_cast<unsigned char>(block[k].p[i]);
+        HIP_OK(hipMemcpyAsync(comp.p + at, block[k].p, got, hipMemcpyHostToDevice, up));
+        at += got;
+    }
+    if (at != size || header == 0) return false;
+    const uint32_t want_crc = tail[0] | (uint32_t(tail[1]) << 8) | (uint32_t(tail[2]) << 16) | (uint32_t(tail[3]) << 24);
+    const uint32_t isize = tail[4] | (uint32_t(tail[5]) << 8) | (uint32_t(tail[6]) << 16) | (uint32_t(tail[7]) << 24);
+    // room for the text: ISIZE is the length modulo 2^32; a file of several gigabytes packed has wrapped it, so room is the
+    // smallest length with that remainder that is at least 2.5 times the packed size (FASTQ packs 3-6 fold)
+    uint64_t room = isize;
+    while (room < size * 5 / 2) room += 1ull << 32;
+    f.text.room_for(room + 64, up);
+    EngineHandle eng(1, device, up);                              // a small engine of this thread's own: the stream and the error slot of the call
+    uint64_t tb = 0, db = 0; uint32_t crc = 0; int32_t ok = 0;
+    const int rc = fqd_gunzip(eng.e, reinterpret_cast<const uint8_t*>(comp.p) + header, size - header, reinterpret_cast<uint8_t*>(f.text.p), room, &tb, &db, &crc, &ok);
+    if (rc != FQD_OK) throw DeviceError(std::string("GPU engine: ") + fqd_last_error(eng.e));
+    if (!ok || header + db + 8 != size || crc != want_crc || uint32_t(tb) != isize) return false;
+    text_bytes = tb;
+    return true;
+}
+
 } // namespace detail
 
 // An ordered run (single-end, or paired files read side by side) with a codec at either end — BGZF inputs, or `.gz`
@@ -293,6 +356,7 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
     try {
         CompressedOnDevice packed[2];
         bool fetched[2] = {false, false};
+        bool text_ready[2] = {false, false};                       // a `.gz` input whose TEXT is in HBM already (fetch_gzip_ordinary)
         std::exception_ptr fetch_error[2];
         uint64_t plain_bytes[2] = {0, 0};
         // the engine — its key store and table sized from the files' sizes — is made on a helper thread under the reads
@@ -308,6 +372,10 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
                 try {
                     fetched[s] = has_gz_extension(in[s]) ? fetch_bgzf(in[s], fetch_bytes, tuning_.device, packed[s], &dev[s])
                                                          : fetch_plain(in[s], fetch_bytes, tuning_.device, dev[s], plain_bytes[s]);
+                    if (!fetched[s] && has_gz_extension(in[s])) {              // not BGZF: an ordinary gzip file, inflated on the GPU too if asked for
+                        packed[s] = CompressedOnDevice(); dev[s].forget();
+                        fetched[s] = text_ready[s] = fetch_gzip_ordinary(in[s], fetch_bytes, tuning_.device, dev[s], plain_bytes[s]);
+                    }
                 } catch (const DeviceOutOfMemory&) { fetched[s] = false; }
                 catch (const DeviceError&) { fetched[s] = false; fetch_error[s] = std::current_exception(); }
                 catch (const std::exception&) { fetched[s] = false; }      // the host reader will say what is wrong with the file
@@ -324,8 +392,8 @@ bool HashDupRemover::run_ordered_resident(int S, const std::string* in, const st
         {
             StageClock::Scope t("ordered/resident: inflate + record scan on the GPU");
             for (int s = 0; s < S; ++s) {
-                const bool ok = has_gz_extension(in[s]) ? finish_on_device(eng->e, stream, format_, packed[s], dev[s])
-                                                        : records_on_device(eng->e, stream, format_, plain_bytes[s], dev[s]);
+                const bool ok = has_gz_extension(in[s]) && !text_ready[s] ? finish_on_device(eng->e, stream, format_, packed[s], dev[s])
+                                                                          : records_on_device(eng->e, stream, format_, plain_bytes[s], dev[s]);
                 if (!ok) return false;
             }
         }
@@ -473,7 +541,13 @@ void HashDupRemover::run_unordered_resident(const std::string* in, const std::st
         auto fetch_or_load = [&](int s) {
             if (inflate_on_device()) {
                 try {
-                    if (has_gz_extension(in[s])) on_device[s] = fetch_bgzf(in[s], fetch_bytes, tuning_.device, packed[s], &dev[s]);
+                    if (has_gz_extension(in[s])) {
+                        on_device[s] = fetch_bgzf(in[s], fetch_bytes, tuning_.device, packed[s], &dev[s]);
+                        if (!on_device[s]) {                                   // not BGZF: an ordinary gzip file, inflated on the GPU too if asked for
+                            packed[s] = CompressedOnDevice(); dev[s].forget();
+                            plain_on_device[s] = fetch_gzip_ordinary(in[s], fetch_bytes, tuning_.device, dev[s], plain_bytes[s]);
+                        }
+                    }
                     else plain_on_device[s] = fetch_plain(in[s], fetch_bytes, tuning_.device, dev[s], plain_bytes[s]);
                 }
                 catch (const DeviceOutOfMemory&) { err[s] = std::current_exception(); return; }   // rethrown below: the two-pass run takes over

@@ -419,6 +419,20 @@ int  fqd_bgzf_deflate(fqd_engine* e, const uint8_t* src, uint64_t n, uint32_t li
 int  fqd_bgzf_inflate(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* comp_len,
                       const uint64_t* out_off, const uint32_t* out_len, const uint32_t* crc, uint64_t n_members,
                       uint8_t* text, uint64_t* n_bad);
+/* An ORDINARY gzip member (one long deflate stream without member sizes: what gzip, pigz and sequencer software write; the
+ * reference reads it through the same gzip decompressor, file_utils.cpp:59-66) inflated in HBM.  `deflate` (device; any
+ * alignment; 32 readable bytes behind the last one) points at the member's raw deflate stream — the caller has walked the
+ * 10-byte-plus header — and avail_bytes says how many bytes of the file lie from there on (the trailer and whatever
+ * follows included).  The stream is cut into units whose block starts are GUESSED, every unit is decoded on its own into
+ * 16-bit symbols that stand for a byte or for "a byte of the 32 KiB before this unit", the chain of unit ends and starts is
+ * checked, and the symbols become text (csrc/fqd_gunzip_core.hpp).  *ok = 1: text[0 .. *text_bytes) is the member's text,
+ * *deflate_bytes the length of its deflate stream (the 8-byte trailer follows: CRC-32 and ISIZE, for the caller to hold
+ * against *crc32 and *text_bytes), *crc32 the CRC-32 of the text.  *ok = 0: a guess that did not hold, damaged data, a unit
+ * that outgrew its room or a text longer than text_cap — nothing is reported beyond that: the caller reads the file the
+ * host way, which produces the reference-visible diagnostic.  Waits for the stream. */
+int  fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint8_t* text, uint64_t text_cap,
+                uint64_t* text_bytes, uint64_t* deflate_bytes, uint32_t* crc32, int32_t* ok);
+
 /* The same for one BATCH of members of a file that is still being read: queued on the engine's stream, nothing waited
  * for; bad members are ADDED to the two uint64 at bad_counters (device; zeroed by the caller, read when it likes), so
  * the inflate of what has arrived runs under the read of what has not. */

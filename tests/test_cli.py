@@ -583,6 +583,65 @@ def test_ordered_runs_on_bgzf_inputs_stay_on_the_device(exe, oracle, tmp_path, c
         assert rc != 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["single", "paired", "unordered"])
+@pytest.mark.parametrize("case", ["good", "header_fields", "flipped_bit", "truncated", "two_members", "bad_base"])
+def test_ordinary_gzip_inputs_inflated_on_the_device(exe, oracle, tmp_path, case, mode):
+    """FQD_GUNZIP_ORDINARY_DEVICE=1: an ordinary `.gz` (one long deflate stream, what gzip / pigz / sequencers write; reference
+    file_utils.cpp:59-66 reads it through the same decompressor) goes to HBM as it lies on disk and is inflated THERE
+    (fqd_gunzip).  Good files: the oracle's bytes and lines, and the device really did it (its stage shows in the timing).
+    Anything irregular — damage, a cut file, several members, an unknown base — is left to the host reader: exactly what the
+    run without the switch gives, message, exit code and partial output alike."""
+    from gunzip_cases import header_with_fields, member
+    rnd = random.Random(23)
+    n = 30000
+    seqs = random_reads(rnd, n, 4000, 60, 100)
+    r1 = [(b"M01:7:FC:1:%d:%d 1:N:0" % (1100 + k % 7, 1000 + k), seqs[k]) for k in range(n)]
+    r2 = [(b"M01:7:FC:1:%d:%d 2:N:0" % (1100 + k % 7, 1000 + k), seqs[(k * 13) % n]) for k in range(n)]
+    if case == "bad_base":
+        i, q = r1[20000]; r1[20000] = (i, q[:5] + b"x" + q[6:])
+    if mode == "unordered":
+        rnd.shuffle(r2)
+    t = [fastq(r1), fastq(r2)]
+    z = [member(x, 6, header=header_with_fields() if case == "header_fields" else b"") for x in t]
+    if case == "flipped_bit":
+        b = bytearray(z[0]); b[len(b) // 2] ^= 4; z[0] = bytes(b)
+    if case == "truncated":
+        z[0] = z[0][: len(z[0]) * 2 // 3]
+    if case == "two_members":
+        half = t[0].index(b"\n@", len(t[0]) // 2) + 1
+        z[0] = member(t[0][:half], 6) + member(t[0][half:], 1)
+    S = 1 if mode == "single" else 2
+    ins = [tmp_path / f"r{s + 1}.fq.gz" for s in range(S)]
+    for s in range(S):
+        ins[s].write_bytes(z[s])
+    runs = {}
+    for device in ("1", "0"):
+        outs = [tmp_path / f"g{s + 1}_{device}.fq.gz" for s in range(S)]
+        args = ["-i", ins[0], "-o", outs[0]] + (["-u", ins[1], "-p", outs[1]] if S == 2 else []) + (["--unordered"] if mode == "unordered" else [])
+        r = run(exe, *args, "--fast", "-v", env={"FQD_HOST_TIMING": "1", "FQD_GUNZIP_ORDINARY_DEVICE": device, "FQD_GUNZIP_UNIT_KB": "64"}, cwd=tmp_path)
+        said = "\n".join(l for l in r.stderr.splitlines() if "[host timing]" not in l)
+        content = [gzip.open(p, "rb").read() if p.exists() else None for p in outs] if r.returncode == 0 else [p.exists() for p in outs]
+        runs[device] = (r.returncode, r.stdout, said, content)
+        if device == "1" and case in ("good", "header_fields") and mode != "unordered":
+            assert "ordered/resident: survivors out of HBM" in r.stderr, r.stderr       # the resident run took the files: nothing was left to the host reader
+    assert runs["1"] == runs["0"]
+    rc, out, said, got = runs["1"]
+    if case in ("good", "header_fields", "two_members"):
+        ps = [tmp_path / f"p{s + 1}.fq" for s in range(S)]
+        es = [tmp_path / f"e{s + 1}.fq" for s in range(S)]
+        for s in range(S):
+            ps[s].write_bytes(t[s])
+        if S == 2:
+            tot, dup, un = oracle.filter_paired(ps[0], ps[1], es[0], es[1], FASTQ, unordered=mode == "unordered")
+        else:
+            tot, dup = oracle.filter_single(ps[0], es[0], FASTQ)
+        assert rc == 0 and str(tot) in out and tot > 20000
+        assert got == [e.read_bytes() for e in es]
+    else:
+        assert rc != 0
+
+
 # ---------------------------------------------------------------- GPU: several engines in one run (FQD_DEVICES)
 
 def uniform_fastq(rnd, n, L, pool, ident):

@@ -87,6 +87,12 @@ def test_plain_gzip_and_plain_files_read_the_same(io, tmp_path):
         f.write(data[:250_000])
     (l3, h3), _ = io("r", tmp_path / "std.fq.gz", 1 << 16, 4)
     assert (int(l3), int(h3)) == (250_000, fnv(data[:250_000]))
+    # the same member cut short: zlib hands out what it could inflate and reports the early end only with the read after —
+    # which used to pass for a clean end of file (the reference's decompressor throws: file_utils.cpp:59-66)
+    raw = (tmp_path / "std.fq.gz").read_bytes()
+    (tmp_path / "cut_std.fq.gz").write_bytes(raw[: len(raw) * 2 // 3])
+    _, err = io("r", tmp_path / "cut_std.fq.gz", 1 << 16, 4, ok=False)
+    assert "corrupt or truncated" in err
 
 
 def test_damaged_bgzf_is_reported(io, tmp_path):

@@ -8,12 +8,12 @@
 //   gz_find_starts_kernel   one wave per unit of the compressed bytes: 64 bit offsets at a time are given a first look
 //                           (three header bits, counts, a complete code-length code: registers only); the few that pass
 //                           get the second look (all code lengths, both codes complete) one after the other;
-//   gz_decode_kernel        one wave per unit with a start: lane 0 decodes serially (the tables of the block in LDS, the
-//                           bits in a register) into a ring of 16-bit symbols in LDS, from which matches are copied;
-//                           the whole wave moves the ring's new symbols out to HBM, 16 bytes a lane;
-//   gz_windows_kernel       one workgroup, unit after unit: the 32 KiB of text that end with the unit, from its symbols and
-//                           the window before it;
-//   gz_resolve_kernel       every symbol becomes a byte: one workgroup per unit, eight symbols a lane and step;
+//   gz_decode_planes_kernel one wave per unit and plane: the wave decoder of the BGZF reader (fqd_inflate_wave.hpp), run twice per
+//                           unit over two made-up windows — what comes out the same in both planes is a byte of the stream,
+//                           what differs says which byte of the unknown window it is;
+//   gz_window_maps_kernel,  the 32 KiB of text that end with a unit: which place of the window before every place copies (all units at
+//   gz_windows_chain_kernel once), then the windows themselves unit after unit, the running window in LDS;
+//   gz_resolve_kernel       every place of every unit becomes a byte: one workgroup per unit, sixteen places a lane and step;
 //   gz_crc_kernel           CRC-32 of every 64 KiB of the text; the host folds them (one 32 x 32 bit matrix per fold).
 // Anything irregular — a chain of unit ends and starts that does not close, damaged data, a unit that outgrows its room,
 // CRC or length that differ from the trailer — is only REPORTED (ok = 0): the caller reads the file the host way, whose
@@ -23,12 +23,14 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <vector>
 #include <unistd.h>
 
 #include "../../include/fqdupaway.h"
 #include "fqd_gunzip_core.hpp"
+#include "fqd_inflate_wave.hpp"
 
 #define FQD_HIDDEN __attribute__((visibility("hidden")))
 FQD_HIDDEN hipStream_t fqd_internal_stream(fqd_engine* e);
@@ -44,126 +46,222 @@ using namespace fqd::gunz;
         return fqd_internal_fail(e, FQD_ERR_HIP, hipGetErrorString(err_)); } } while (0)
 
 constexpr uint32_t kWave = 64;
-constexpr uint32_t kRing = 4096;                  // symbols of a decoder's LDS ring (8 KiB): what it put last, matches copy out of it
-constexpr uint32_t kStretch = kRing / 2 - 512;    // symbols lane 0 decodes before the wave moves them out (a code adds up to 258 more)
 
 // ---- 1. where units start --------------------------------------------------------------------------------------------------
+// Every bit offset of a unit is sifted, 64 a turn, with what 13 bits can tell (final-block bit, block type, code counts: one
+// offset in nine passes) out of two words the wave slides along the stream; what passes WAITS until 64 offsets do and is then
+// given the first look proper (a complete code-length code: one in a hundred) by 64 lanes side by side; what passes that
+// waits for the second look (some 300 code lengths read, two codes checked: 15 000 instructions), again 64 side by side.
+// The first offset of the unit that passes everything is its start.  (First version: every look for every offset as it came,
+// the second one lane at a time — 25 of 168 ms per gigabyte of text; the looks in stages: 5.)
 __global__ __launch_bounds__(kWave)
 void gz_find_starts_kernel(BitIn in, uint64_t unit_bits, uint64_t n_units, uint64_t* __restrict__ start)
 {
-    __shared__ uint8_t lens[320];
-    __shared__ uint32_t found;
+    __shared__ uint8_t lens[kWave][320];
+    __shared__ uint64_t sifted[2 * kWave], looked[2 * kWave];
     const uint32_t lane = threadIdx.x;
+    const uint64_t last_word = ((in.nbits + in.lead) >> 6) + 3u;              // 32 readable bytes lie behind the stream: no word beyond them is asked for
+    auto word = [&](uint64_t i) { return in.words[i <= last_word ? i : last_word]; };
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         if (u == 0) { if (lane == 0) start[0] = 0; continue; }
         const uint64_t lo = u * unit_bits, hi = lo + unit_bits < in.nbits ? lo + unit_bits : in.nbits;
         uint64_t at = ~0ull;
-        for (uint64_t p0 = lo; p0 < hi && at == ~0ull; p0 += kWave) {
+        uint32_t n_sifted = 0, n_looked = 0;
+        // takes the first n (<= 64) of a queue, keeps the rest; `test` runs on every lane that has an entry
+        auto drain = [&](uint64_t* q, uint32_t& have, uint32_t n, auto&& test) -> unsigned long long {
+            __syncthreads();
+            const uint64_t mine = lane < n ? q[lane] : 0ull;
+            const bool yes = lane < n && test(mine);
+            const unsigned long long hit = __ballot(yes);
+            const uint64_t keep = (lane < have - n) ? q[n + lane] : 0ull;      // (have - n <= 64)
+            __syncthreads();
+            if (lane < have - n) q[lane] = keep;
+            have -= n;
+            __syncthreads();
+            return hit;
+        };
+        auto first_looks = [&](uint32_t n) {                                  // sifted -> looked, order kept
+            const uint64_t mine = lane < n ? sifted[lane] : 0ull;             // (read before drain moves the queue)
+            const unsigned long long hit = drain(sifted, n_sifted, n, [&](uint64_t p) { return block_start_first_look(in, p); });
+            if ((hit >> lane) & 1ull) looked[n_looked + uint32_t(__popcll(hit & ((1ull << lane) - 1ull)))] = mine;
+            n_looked += uint32_t(__popcll(hit));
+        };
+        auto second_looks = [&](uint32_t n) {                                 // true: one of the first n looked-at offsets is a block start
+            const uint64_t mine = lane < n ? looked[lane] : 0ull;
+            const unsigned long long hit = drain(looked, n_looked, n, [&](uint64_t p) { return block_start_second_look(in, p, lens[lane]); });
+            if (hit) at = __shfl(mine, int(__ffsll(static_cast<long long>(hit))) - 1, 64);
+            return hit != 0ull;
+        };
+        uint64_t wi = (lo + in.lead) >> 6;
+        uint64_t A = word(wi), B = word(wi + 1), C = word(wi + 2);           // a turn is 64 offsets = one word: [A B] hold a lane's 13 bits, C is a turn ahead
+        bool found = false;
+        for (uint64_t p0 = lo; p0 < hi && !found; p0 += kWave) {
             const uint64_t p = p0 + lane;
-            unsigned long long cand = __ballot(p < hi && block_start_first_look(in, p));
-            while (cand) {                                                // the few that pass, lowest offset first
-                const uint32_t l = uint32_t(__ffsll(static_cast<long long>(cand))) - 1u;
-                if (lane == 0) found = block_start_second_look(in, p0 + l, lens) ? 1u : 0u;
-                __syncthreads();
-                const bool yes = found != 0u;
-                __syncthreads();
-                if (yes) { at = p0 + l; break; }
-                cand &= cand - 1ull;
+            const uint64_t ahead = word(wi + 3);
+            const uint32_t s = uint32_t((p0 + in.lead) & 63u) + lane;        // the lane's offset from the first bit of A: 0 .. 126
+            const uint64_t x = s < 64u ? A : B, y = s < 64u ? B : C;
+            const uint32_t r = s & 63u;
+            const uint32_t w13 = uint32_t(r ? (x >> r) | (y << (64u - r)) : x) & 0x1FFFu;
+            const bool pass = p < hi && p + 300 <= in.nbits && block_start_header_bits(w13);
+            A = B; B = C; C = ahead; ++wi;
+            const unsigned long long cand = __ballot(pass);
+            if (pass) sifted[n_sifted + uint32_t(__popcll(cand & ((1ull << lane) - 1ull)))] = p;
+            n_sifted += uint32_t(__popcll(cand));
+            if (n_sifted >= kWave) {
+                first_looks(kWave);
+                if (n_looked >= kWave) found = second_looks(kWave);
             }
+        }
+        if (!found) {
+            if (n_sifted) first_looks(n_sifted);
+            while (!found && n_looked) found = second_looks(n_looked < kWave ? n_looked : kWave);
         }
         if (lane == 0) start[u] = at;
     }
 }
 
-// ---- 2. a unit decoded into symbols ------------------------------------------------------------------------------------------
-struct UnitIn  { uint64_t start_bit, stop_bit, sym_at, sym_cap; };           // where to start, the next unit's nominal start, room in the symbol scratch
-struct UnitOut { uint64_t end_bit, n_sym; uint32_t status, deepest; };
+// ---- 2. a unit decoded — twice, as BYTES -------------------------------------------------------------------------------------
+// The wave decoder of the BGZF reader (fqd_inflate_wave.hpp: the lanes decode a block's bits side by side from guessed code
+// boundaries, matches are resolved 64 at a time) writes bytes and copies bytes; what a unit needs are SYMBOLS — "a byte", or
+// "the byte at place w of the 32 KiB before me", which nobody knows yet.  It gets them without a line of that decoder
+// changed: the unit is decoded twice, each time with a MADE-UP window in front of its room,
+//     plane P: window[w] = w & 255          plane Q: window[w] = (w & 255) ^ (1 + (w >> 8))
+// Copies are the identity on bytes, so a byte that was copied (however often) from place w of the window comes out as P[w] in
+// one plane and Q[w] in the other — two values that differ for every w and give w back — and a literal of the stream comes
+// out the same in both.  P == Q: the byte; otherwise w = P | ((P ^ Q) - 1) << 8.  Twice the decoding at 50 times the speed of
+// the one-lane decoder this kernel replaced (csrc/fqd_gunzip_core.hpp, kept as the CPU reference form: 4.6 GB/s of text).
+struct UnitIn  { uint64_t start_bit, stop_bit, at, cap; };                   // where to start, the next unit's nominal start, the unit's place in a plane, room behind the window
+struct UnitOut { uint64_t end_bit, n; uint32_t status, how; };               // how: 1 a boundary, 2 the final block's end
 
-// Lane 0's sink: the ring in LDS; what has left the ring is read back from HBM (matches deeper than the ring keeps: rare in
-// FASTQ, where a match reaches a record or two back).
-struct RingSink {
-    uint16_t* ring;                      // LDS, kRing symbols
-    const uint16_t* out;                 // HBM: the unit's symbols moved out so far ([0, flushed))
-    uint64_t cap, n, flushed;
+struct WaveCtx {                                                             // the wave as fqd_inflate_wave.hpp sees it (as in fqd_inflate.hip)
+    static constexpr uint32_t kLanes = kWave;
     uint32_t lane;
-    __device__ __forceinline__ bool room(uint32_t need) const { return n + need <= cap; }
-    __device__ __forceinline__ void put(uint16_t s) { ring[n & (kRing - 1u)] = s; ++n; }       // (every lane the same symbol to the same place)
-    // the ring still holds place i unless i + kRing has been put; n never gets further than flushed + kStretch + 258 + 7
-    __device__ __forceinline__ uint16_t at(uint64_t i) const { return i + kRing > flushed + kStretch + 512u ? ring[i & (kRing - 1u)] : out[i]; }
-    // a match: the places it reads all hold their symbols before it starts (k mod d), so the lanes copy 64 symbols a turn
-    __device__ __forceinline__ void copy(uint32_t d, uint32_t len)
-    {
-        const int64_t from = int64_t(n) - int64_t(d);
-        for (uint32_t k = lane; k < len; k += kWave) {
-            const int64_t i = from + int64_t(k < d ? k : k % d);
-            ring[(n + k) & (kRing - 1u)] = i < 0 ? uint16_t(256 + int64_t(kWindow) + i) : at(uint64_t(i));
-        }
-        n += len;
-    }
-    __device__ __forceinline__ uint64_t count() const { return n; }
+    template <class F> __device__ __forceinline__ void lanes(F f) { f(lane); __syncthreads(); }
+    template <class F> __device__ __forceinline__ void lanes_open(F f) { f(lane); }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    template <class F> __device__ __forceinline__ uint64_t ballot(F f) { return __ballot(f(lane) ? 1 : 0); }
+    __device__ __forceinline__ uint32_t same(uint32_t v) const { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+    __device__ __forceinline__ void add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
+    __device__ __forceinline__ void mark(int) {}
 };
 
-__global__ __launch_bounds__(kWave)
-void gz_decode_kernel(BitIn in, const UnitIn* __restrict__ units, uint32_t n_units, uint16_t* __restrict__ sym, UnitOut* __restrict__ result,
-                      uint32_t* __restrict__ next_unit, unsigned long long* __restrict__ debug /* 8 words, FQD_GUNZIP_TRACE */)
+__device__ __forceinline__ uint32_t made_up(uint32_t plane, uint32_t w) { return plane ? ((w & 255u) ^ (1u + (w >> 8))) : (w & 255u); }
+
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void gz_decode_planes_kernel(const uint8_t* __restrict__ deflate, uint64_t avail_bytes, const UnitIn* __restrict__ units, uint32_t n_units,
+                             uint8_t* __restrict__ plane_p, uint8_t* __restrict__ plane_q, fqd::winf::Token* __restrict__ tokens,
+                             UnitOut* __restrict__ result /* [2 * n_units]: unit u, plane p at 2u + p */, uint32_t* __restrict__ next_item)
 {
-    __shared__ Tables tables;
-    __shared__ __attribute__((aligned(16))) uint16_t ring[kRing];
-    __shared__ uint8_t lens[320];
-    __shared__ uint32_t my_unit;
-    __shared__ uint64_t sh_n;
-    __shared__ uint32_t sh_status;
-    const uint32_t lane = threadIdx.x;
+    __shared__ fqd::winf::Shared<kWave> sh;
+    __shared__ uint32_t my_item;
+    __shared__ uint32_t info[3];
+    WaveCtx ctx{threadIdx.x};
+    fqd::winf::Token* tok = tokens + size_t(blockIdx.x) * fqd::winf::kTokenRoom;
     for (;;) {
-        if (lane == 0) my_unit = atomicAdd(next_unit, 1u);
+        if (threadIdx.x == 0) my_item = atomicAdd(next_item, 1u);
         __syncthreads();
-        const uint32_t u = my_unit;
+        const uint32_t item = my_item;
         __syncthreads();
-        if (u >= n_units) break;
+        if (item >= 2u * n_units) break;
+        const uint32_t u = item >> 1, plane = item & 1u;
         const UnitIn ui = units[u];
-        uint16_t* out = sym + ui.sym_at;
-        State st;
-        st.pos = st.start_bit = ui.start_bit;
-        RingSink sink{ring, out, ui.sym_cap, 0, 0, lane};
-        uint64_t flushed = 0;
-        for (uint64_t stretch = 0;; ++stretch) {
-            // EVERY lane runs the decoder, on the same bits to the same end: the control flow of 6700 instructions stays uniform
-            // (a first version ran it under `if (lane == 0)` and never came back from the GPU, while the very same code, ring and
-            // all, runs to its end on the CPU); what the lanes write — tables, ring — they all write alike
-            sink.flushed = flushed;
-            decode_some(in, tables, lens, st, ui.stop_bit, sink, kStretch);
-            if (stretch > (ui.sym_cap / kStretch) + 16u && st.status == kOk) st.status = kBadData;          // (cannot happen: every stretch adds symbols)
-            if (lane == 0) {
-                sh_n = sink.n; sh_status = st.status;
-                if (debug) { debug[0] = stretch; debug[1] = sink.n; debug[2] = st.pos; debug[3] = st.status; debug[4] = st.in_block; debug[5] = u; }
+        uint8_t* out = (plane ? plane_q : plane_p) + ui.at;
+        // the made-up window: 32 KiB, sixteen bytes a lane and store
+        for (uint32_t w0 = threadIdx.x * 16u; w0 < kWindow; w0 += kWave * 16u) {
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t w = w0 + 4u * k;
+                v[k] = made_up(plane, w) | (made_up(plane, w + 1u) << 8) | (made_up(plane, w + 2u) << 16) | (made_up(plane, w + 3u) << 24);
             }
-            __syncthreads();
-            const uint64_t n = sh_n;
-            const uint32_t status = sh_status;
-            // whole groups of eight symbols leave the ring, 16 bytes a lane (the unit's room starts 16-byte aligned); the last few wait
-            const uint64_t upto = status == kOk ? n & ~7ull : n;
-            for (uint64_t g = (flushed >> 3) + lane; g < (upto >> 3); g += kWave)
-                reinterpret_cast<uint4*>(out)[g] = reinterpret_cast<const uint4*>(ring)[g & (kRing / 8u - 1u)];
-            if (status != kOk) for (uint64_t i = (upto & ~7ull) + lane; i < upto; i += kWave) out[i] = ring[i & (kRing - 1u)];
-            flushed = upto & ~7ull;
-            __syncthreads();                                              // (the stores are visible to lane 0's later loads: one workgroup)
-            if (status != kOk) break;
+            reinterpret_cast<uint4*>(out + w0)[0] = uint4{v[0], v[1], v[2], v[3]};
         }
-        if (lane == 0) result[u] = UnitOut{st.pos, sink.n, st.status, st.deepest};
+        __syncthreads();
+        const uint64_t byte0 = ui.start_bit >> 3;
+        const uint64_t left = avail_bytes - byte0;
+        const uint32_t comp_len = uint32_t(left < (1ull << 28) ? left : (1ull << 28));
+        const uint64_t rel = ui.stop_bit == ~0ull ? 0xFFFFFFFFull : ui.stop_bit - byte0 * 8u;
+        const uint32_t st = fqd::winf::inflate_stretch(ctx, sh, deflate + byte0, comp_len, uint32_t(ui.start_bit & 7u), uint32_t(rel < 0xFFFFFFFFull ? rel : 0xFFFFFFFFull),
+                                                       out, kWindow, uint32_t(kWindow + ui.cap), tok, info);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            UnitOut r;
+            r.status = st;
+            r.end_bit = st == fqd::winf::kOk ? byte0 * 8u + info[0] : 0;
+            r.n = st == fqd::winf::kOk ? info[1] - kWindow : 0;
+            r.how = st == fqd::winf::kOk ? info[2] : 0;
+            result[item] = r;
+        }
+        __syncthreads();
     }
 }
 
-// ---- 4. windows, unit after unit -----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024)
-void gz_windows_kernel(const UnitIn* __restrict__ units, const UnitOut* __restrict__ result, uint32_t n_units, const uint16_t* __restrict__ sym,
-                       uint8_t* __restrict__ windows /* (n_units + 1) x kWindow; [0] is given */)
+// The symbol at place i of a unit, from its two planes.
+__device__ __forceinline__ uint32_t symbol_of(const uint8_t* __restrict__ p, const uint8_t* __restrict__ q, uint64_t i)
 {
+    const uint32_t a = p[i], b = q[i];
+    return a == b ? a : 256u + (a | (((a ^ b) - 1u) << 8));
+}
+
+// ---- 4. windows ------------------------------------------------------------------------------------------------------------------
+// The 32 KiB of text that end with unit u, from its own last places and — where those were copied out of the window before it,
+// or the unit is shorter than 32 KiB — from the window of unit u - 1.  Nearly every unit has such places (the instrument and
+// flow-cell part of a FASTQ ID line is copied from record to record through the whole file), so the windows are a chain; but
+// what a unit's window takes from the one before — WHICH place for every place — depends on the unit alone:
+//   gz_window_maps_kernel   all units at once: map[u][k] = a byte, or 256 + the place of the window before that place k copies
+//   gz_windows_chain_kernel one workgroup, the running window in LDS: next[k] = map byte, or prev[place]; the maps of the next
+//                           unit are on their way while this one is looked up
+// (One workgroup reading symbols and windows from HBM unit after unit took 25 us a unit: 120 of the first version's 168 ms per
+// gigabyte of text.)
+__global__ __launch_bounds__(256)
+void gz_window_maps_kernel(const UnitIn* __restrict__ units, const UnitOut* __restrict__ result, uint32_t n_units,
+                           const uint8_t* __restrict__ plane_p, const uint8_t* __restrict__ plane_q, uint16_t* __restrict__ maps /* n_units x kWindow */)
+{
+    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint8_t* p = plane_p + units[u].at + kWindow;
+        const uint8_t* q = plane_q + units[u].at + kWindow;
+        const uint64_t n = result[2u * u].n;
+        uint16_t* m = maps + uint64_t(u) * kWindow;
+        for (uint32_t k = threadIdx.x; k < kWindow; k += 256u)
+            // place k of the new window is text place n - kWindow + k of the unit, or, before the unit, place k + n of the old window
+            m[k] = (n >= kWindow || k + n >= kWindow) ? uint16_t(symbol_of(p, q, n - kWindow + k)) : uint16_t(256u + k + uint32_t(n));
+    }
+}
+__global__ __launch_bounds__(1024)
+void gz_windows_chain_kernel(const uint16_t* __restrict__ maps, uint32_t n_units, uint8_t* __restrict__ windows /* (n_units + 1) x kWindow; [0] is given */)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t win[];          // two windows: the one before, the one being made
+    constexpr uint32_t kPer = kWindow / 1024u / 8u;                        // 4 x eight places a lane
+    const uint32_t t = threadIdx.x;
+    for (uint32_t k = t * 16u; k < kWindow; k += 1024u * 16u) reinterpret_cast<uint4*>(win)[k / 16u] = reinterpret_cast<const uint4*>(windows)[k / 16u];
+    uint4 m[kPer], ahead[kPer];
+    if (n_units) for (uint32_t i = 0; i < kPer; ++i) ahead[i] = reinterpret_cast<const uint4*>(maps)[i * 1024u + t];
+    __syncthreads();
     for (uint32_t u = 0; u < n_units; ++u) {
-        const uint8_t* prev = windows + uint64_t(u) * kWindow;
-        uint8_t* next = windows + uint64_t(u + 1u) * kWindow;
-        const uint16_t* s = sym + units[u].sym_at;
-        const uint64_t n = result[u].n_sym;
-        for (uint32_t k = threadIdx.x; k < kWindow; k += 1024u) next[k] = window_byte(prev, s, n, k);
+        const uint8_t* prev = win + (u & 1u) * kWindow;
+        uint8_t* next = win + ((u + 1u) & 1u) * kWindow;
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; ++i) m[i] = ahead[i];
+        if (u + 1u < n_units) {
+            const uint4* nm = reinterpret_cast<const uint4*>(maps + uint64_t(u + 1u) * kWindow);
+#pragma unroll
+            for (uint32_t i = 0; i < kPer; ++i) ahead[i] = nm[i * 1024u + t];
+        }
+        uint8_t* gnext = windows + uint64_t(u + 1u) * kWindow;
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; ++i) {
+            const uint32_t w[4] = {m[i].x, m[i].y, m[i].z, m[i].w};
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t sy = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                const uint32_t byte = sy < 256u ? sy : prev[sy - 256u];
+                if (k < 4) lo |= byte << (8 * k); else hi |= byte << (8 * (k - 4));
+            }
+            const uint32_t at = (i * 1024u + t) * 8u;
+            reinterpret_cast<uint2*>(next)[at / 8u] = uint2{lo, hi};
+            reinterpret_cast<uint2*>(gnext)[at / 8u] = uint2{lo, hi};
+        }
         __syncthreads();
     }
 }
@@ -171,27 +269,33 @@ void gz_windows_kernel(const UnitIn* __restrict__ units, const UnitOut* __restri
 // ---- 5. bytes ----------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void gz_resolve_kernel(const UnitIn* __restrict__ units, const UnitOut* __restrict__ result, const uint64_t* __restrict__ text_at, uint32_t n_units,
-                       const uint16_t* __restrict__ sym, const uint8_t* __restrict__ windows, uint8_t* __restrict__ text)
+                       const uint8_t* __restrict__ plane_p, const uint8_t* __restrict__ plane_q, const uint8_t* __restrict__ windows, uint8_t* __restrict__ text)
 {
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const uint16_t* s = sym + units[u].sym_at;                        // 16-byte aligned
+        const uint8_t* p = plane_p + units[u].at + kWindow;                   // 16-byte aligned
+        const uint8_t* q = plane_q + units[u].at + kWindow;
         const uint8_t* win = windows + uint64_t(u) * kWindow;
         uint8_t* dst = text + text_at[u];
-        const uint64_t n = result[u].n_sym;
-        const bool plain = result[u].deepest == 0u;
-        for (uint64_t g = threadIdx.x; g < (n >> 3); g += 256u) {
-            const uint4 v = reinterpret_cast<const uint4*>(s)[g];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            uint8_t b[8];
+        const uint64_t n = result[2u * u].n;
+        for (uint64_t g = threadIdx.x; g < (n >> 4); g += 256u) {
+            const uint4 a = reinterpret_cast<const uint4*>(p)[g], b = reinterpret_cast<const uint4*>(q)[g];
+            uint32_t wa[4] = {a.x, a.y, a.z, a.w};
+            const uint32_t wb[4] = {b.x, b.y, b.z, b.w};
+            if ((wa[0] ^ wb[0]) | (wa[1] ^ wb[1]) | (wa[2] ^ wb[2]) | (wa[3] ^ wb[3])) {       // some byte came out of the window
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t x = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-                b[k] = (plain || x < 256u) ? uint8_t(x) : win[x - 256u];
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t x = (wa[k >> 2] >> (8 * (k & 3))) & 0xFFu, y = (wb[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                    if (x != y) wa[k >> 2] = (wa[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | (uint32_t(win[x | (((x ^ y) - 1u) << 8)]) << (8 * (k & 3)));
+                }
             }
+            uint8_t* d = dst + 16u * g;                                       // (dst has whatever alignment the units before left it)
+            if ((reinterpret_cast<uintptr_t>(d) & 3u) == 0) { uint32_t* d4 = reinterpret_cast<uint32_t*>(d); d4[0] = wa[0]; d4[1] = wa[1]; d4[2] = wa[2]; d4[3] = wa[3]; }
+            else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) dst[8u * g + k] = b[k];          // (dst has whatever alignment the units before left it)
+                for (int k = 0; k < 16; ++k) d[k] = uint8_t(wa[k >> 2] >> (8 * (k & 3)));
+            }
         }
-        for (uint64_t i = (n & ~7ull) + threadIdx.x; i < n; i += 256u) { const uint32_t x = s[i]; dst[i] = x < 256u ? uint8_t(x) : win[x - 256u]; }
+        for (uint64_t i = (n & ~15ull) + threadIdx.x; i < n; i += 256u) { const uint32_t s = symbol_of(p, q, i); dst[i] = s < 256u ? uint8_t(s) : win[s - 256u]; }
     }
 }
 
@@ -301,7 +405,9 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, fqd_internal_device(e)) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
 
     static const bool trace = std::getenv("FQD_GUNZIP_TRACE") != nullptr;      // stages to stderr as they are reached
-#define GZ_TRACE(...) do { if (trace) { std::fprintf(stderr, "[gunzip] " __VA_ARGS__); std::fputc('\n', stderr); std::fflush(stderr); } } while (0)
+    const auto t_begin = std::chrono::steady_clock::now();
+#define GZ_TRACE(...) do { if (trace) { (void)hipStreamSynchronize(stream); std::fprintf(stderr, "[gunzip %7.2f ms] ", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); \
+    std::fprintf(stderr, __VA_ARGS__); std::fputc('\n', stderr); std::fflush(stderr); } } while (0)
     BitIn in;
     const uintptr_t addr = reinterpret_cast<uintptr_t>(deflate);
     in.words = reinterpret_cast<const uint64_t*>(addr & ~uintptr_t(7));
@@ -309,9 +415,9 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
     in.nbits = avail_bytes * 8u;
 
     // units: small enough that there are several per wave slot of the chip, large enough to hold a block start more often than
-    // not (zlib ends a block every 16 K codes: some 20-50 KB packed).  (One decoder per LANE instead of per wave — tables in HBM,
-    // 16 KiB units, tens of thousands of lanes waiting on memory at once — was measured: 2.6 GB/s of text against 4.6; lanes of
-    // a wave that copy matches of different lengths wait for the longest.)
+    // not (zlib ends a block every 16 K codes: some 20-50 KB packed).  (Measured and replaced on the way here, DESIGN §3b: one
+    // serial decoder per wave writing 16-bit symbols, all lanes running it alike — 4.6 GB/s of text; the same, one decoder per
+    // LANE with its tables in HBM — 2.6 GB/s: lanes of a wave that copy matches of different lengths wait for the longest.)
     uint64_t unit_bytes = std::min<uint64_t>(512u << 10, std::max<uint64_t>(64u << 10, (avail_bytes / 8192u + 4095u) & ~uint64_t(4095)));
     if (const char* v = std::getenv("FQD_GUNZIP_UNIT_KB")) { const long kb = std::atol(v); if (kb > 0) unit_bytes = uint64_t(kb) << 10; }
     uint64_t ratio = 8;                                                      // symbols of room per compressed byte (FASTQ packs 3-6 fold)
@@ -336,97 +442,95 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
         UnitIn x;
         x.start_bit = start[u];
         x.stop_bit = next < n_nominal ? next * unit_bytes * 8u : ~0ull;
-        x.sym_cap = ((next - u) * unit_bytes * ratio + 1024u) & ~uint64_t(7);
-        x.sym_at = 0;
+        x.cap = ((next - u) * unit_bytes * ratio + 1024u + 15u) & ~uint64_t(15);
+        x.at = 0;
         units.push_back(x);
     }
 
     GZ_TRACE("%zu units have a start", units.size());
-    // ---- 2-5 in batches of units whose symbols fit the scratch
-    uint64_t scratch_syms = uint64_t(4) << 30;                               // 8 GiB of symbols
-    if (const char* v = std::getenv("FQD_GUNZIP_SCRATCH_MB")) { const long mb = std::atol(v); if (mb > 0) scratch_syms = (uint64_t(mb) << 20) / 2; }
-    uint64_t largest = 0;
-    for (const UnitIn& x : units) largest = std::max(largest, x.sym_cap);
-    scratch_syms = std::max(scratch_syms, largest);
+    // ---- 2-5 in batches of units whose two planes fit the scratch
+    uint64_t plane_bytes = uint64_t(4) << 30;                                // per plane
+    if (const char* v = std::getenv("FQD_GUNZIP_SCRATCH_MB")) { const long mb = std::atol(v); if (mb > 0) plane_bytes = (uint64_t(mb) << 20) / 2; }
+    auto room_of = [](const UnitIn& x) { return uint64_t(kWindow) + x.cap + 64u; };          // made-up window, text, slack (a multiple of 16)
     {
-        uint64_t all = 0;
-        for (const UnitIn& x : units) all += x.sym_cap;
-        scratch_syms = std::min(scratch_syms, all);
+        uint64_t largest = 0, all = 0;
+        for (const UnitIn& x : units) { largest = std::max(largest, room_of(x)); all += room_of(x); }
+        plane_bytes = std::min(std::max(plane_bytes, largest), all);
     }
-    DevMem d_sym, d_units, d_result, d_text_at, d_windows, d_counter, d_debug;
-    unsigned long long* h_debug = nullptr;
-    if (trace) {                                                              // host-visible, so that a kernel that never ends can still be read
-        GZ_TRY(e, hipHostMalloc(reinterpret_cast<void**>(&h_debug), 64, hipHostMallocMapped));
-        std::memset(h_debug, 0xFF, 64);
-        d_debug.p = nullptr;
-    }
-    GZ_TRY(e, d_sym.get(scratch_syms * 2 + 64));
+    DevMem d_p, d_q, d_units, d_result, d_text_at, d_windows, d_counter, d_tokens, d_maps;
+    GZ_TRY(e, d_p.get(plane_bytes + 64));
+    GZ_TRY(e, d_q.get(plane_bytes + 64));
     GZ_TRY(e, d_counter.get(64));
+    const uint32_t decoders = uint32_t(std::min<uint64_t>(2u * units.size(), uint64_t(n_cu) * 16u));    // 10 KB of LDS, <= 128 VGPRs: sixteen waves a CU
+    GZ_TRY(e, d_tokens.get(size_t(decoders) * fqd::winf::kTokenRoom * sizeof(fqd::winf::Token)));
+    GZ_TRACE("scratch allocated: 2 planes of %llu bytes, %u decoders' tokens", (unsigned long long)plane_bytes, decoders);
     std::vector<uint8_t> carry(kWindow, 0);                                   // the window before the next batch's first unit
     uint64_t total = 0, expect_start = 0, repairs = 0;
     bool final_seen = false, good = true;
     std::vector<UnitOut> result;
     std::vector<uint64_t> text_at;
     size_t at = 0;
+    auto decode = [&](uint32_t first, uint32_t count) -> int {              // units [first, first + count) of the batch, both planes
+        GZ_TRY(e, hipMemsetAsync(d_counter.p, 0, 64, stream));
+        hipLaunchKernelGGL(gz_decode_planes_kernel, dim3(std::min<uint32_t>(2u * count, decoders)), dim3(kWave), 0, stream,
+                           deflate, avail_bytes, d_units.as<const UnitIn>() + first, count, d_p.as<uint8_t>(), d_q.as<uint8_t>(),
+                           d_tokens.as<fqd::winf::Token>(), d_result.as<UnitOut>() + 2u * first, d_counter.as<uint32_t>());
+        GZ_TRY(e, hipGetLastError());
+        GZ_TRY(e, hipMemcpyAsync(result.data() + 2u * first, d_result.as<UnitOut>() + 2u * first, 2u * count * sizeof(UnitOut), hipMemcpyDeviceToHost, stream));
+        GZ_TRY(e, hipStreamSynchronize(stream));
+        return FQD_OK;
+    };
     while (at < units.size() && good && !final_seen) {
         size_t hi = at; uint64_t used = 0;
-        while (hi < units.size() && used + units[hi].sym_cap <= scratch_syms) { units[hi].sym_at = used; used += units[hi].sym_cap; ++hi; }
+        while (hi < units.size() && used + room_of(units[hi]) <= plane_bytes) { units[hi].at = used; used += room_of(units[hi]); ++hi; }
         const uint32_t nb = uint32_t(hi - at);
         if (nb == 0) { good = false; break; }
         GZ_TRY(e, d_units.get(nb * sizeof(UnitIn)));
-        GZ_TRY(e, d_result.get(nb * sizeof(UnitOut)));
+        GZ_TRY(e, d_result.get(2u * nb * sizeof(UnitOut)));
         GZ_TRY(e, d_text_at.get(nb * 8));
         GZ_TRY(e, d_windows.get(uint64_t(nb + 1u) * kWindow));
         GZ_TRY(e, hipMemcpyAsync(d_units.p, units.data() + at, nb * sizeof(UnitIn), hipMemcpyHostToDevice, stream));
-        GZ_TRY(e, hipMemsetAsync(d_counter.p, 0, 64, stream));
-        hipLaunchKernelGGL(gz_decode_kernel, dim3(std::min<uint32_t>(nb, uint32_t(n_cu) * 10u)), dim3(kWave), 0, stream,
-                           in, d_units.as<const UnitIn>(), nb, d_sym.as<uint16_t>(), d_result.as<UnitOut>(), d_counter.as<uint32_t>(),
-                           h_debug);
-        GZ_TRY(e, hipGetLastError());
-        GZ_TRACE("batch of %u units queued for decoding (%llu symbols of room)", nb, (unsigned long long)used);
-        if (trace) for (int tick = 0; tick < 20 && hipStreamQuery(stream) == hipErrorNotReady; ++tick) {
-            usleep(200000);
-            GZ_TRACE("  ... stretch %llu symbols %llu pos %llu status %llu in_block %llu unit %llu", h_debug[0], h_debug[1], h_debug[2], h_debug[3], h_debug[4], h_debug[5]);
-        }
-        result.resize(nb);
-        GZ_TRY(e, hipMemcpyAsync(result.data(), d_result.p, nb * sizeof(UnitOut), hipMemcpyDeviceToHost, stream));
-        GZ_TRY(e, hipStreamSynchronize(stream));
-        GZ_TRACE("decoded: first unit status %u, %llu symbols, end bit %llu", result[0].status, (unsigned long long)result[0].n_sym, (unsigned long long)result[0].end_bit);
+        result.resize(2u * nb);
+        GZ_TRACE("batch of %u units queued for decoding (%llu bytes a plane)", nb, (unsigned long long)used);
+        int rc = decode(0, nb);
+        if (rc) return rc;
+        GZ_TRACE("decoded: first unit status %u, %llu bytes, end bit %llu", result[0].status, (unsigned long long)result[0].n, (unsigned long long)result[0].end_bit);
         // ---- 3. the chain
         text_at.resize(nb);
         uint32_t live = 0;
         for (uint32_t k = 0; k < nb && good && !final_seen; ++k) {
-            UnitIn& x = units[at + k]; UnitOut& r = result[k];
+            UnitIn& x = units[at + k];
             if (x.start_bit != expect_start) {
                 // a guess that did not hold (a header-like stretch of bits inside a block: a few per gigabyte): the unit before ended
                 // at the true boundary, so this one is decoded again from there — one small launch — and the chain goes on
                 if (++repairs > 64u + units.size() / 16u) { good = false; break; }       // (damage, not bad luck)
                 x.start_bit = expect_start;
                 GZ_TRY(e, hipMemcpyAsync(d_units.as<UnitIn>() + k, &x, sizeof(UnitIn), hipMemcpyHostToDevice, stream));
-                GZ_TRY(e, hipMemsetAsync(d_counter.p, 0, 64, stream));
-                hipLaunchKernelGGL(gz_decode_kernel, dim3(1), dim3(kWave), 0, stream, in, d_units.as<const UnitIn>() + k, 1u, d_sym.as<uint16_t>(),
-                                   d_result.as<UnitOut>() + k, d_counter.as<uint32_t>(), static_cast<unsigned long long*>(nullptr));
-                GZ_TRY(e, hipGetLastError());
-                GZ_TRY(e, hipMemcpyAsync(&r, d_result.as<UnitOut>() + k, sizeof(UnitOut), hipMemcpyDeviceToHost, stream));
-                GZ_TRY(e, hipStreamSynchronize(stream));
-                GZ_TRACE("unit %zu decoded again from bit %llu: status %u, %llu symbols", at + k, (unsigned long long)expect_start, r.status, (unsigned long long)r.n_sym);
+                if ((rc = decode(k, 1u))) return rc;
+                GZ_TRACE("unit %zu decoded again from bit %llu: status %u, %llu bytes", at + k, (unsigned long long)expect_start, result[2u * k].status, (unsigned long long)result[2u * k].n);
             }
-            if (r.status != kBoundary && r.status != kFinal) { good = false; break; }
-            if (total + r.n_sym > text_cap) { good = false; break; }
-            text_at[k] = total; total += r.n_sym;
+            const UnitOut& r = result[2u * k]; const UnitOut& r2 = result[2u * k + 1u];
+            if (r.status != fqd::winf::kOk || r2.status != fqd::winf::kOk || r.end_bit != r2.end_bit || r.n != r2.n || r.how != r2.how) { good = false; break; }
+            if (total + r.n > text_cap) { good = false; break; }
+            text_at[k] = total; total += r.n;
             expect_start = r.end_bit;
             live = k + 1;
-            if (r.status == kFinal) final_seen = true;
+            if (r.how == 2u) final_seen = true;
         }
         if (!good) break;
         // ---- 4, 5
         GZ_TRY(e, hipMemcpyAsync(d_text_at.p, text_at.data(), live * 8, hipMemcpyHostToDevice, stream));
         GZ_TRY(e, hipMemcpyAsync(d_windows.p, carry.data(), kWindow, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(gz_windows_kernel, dim3(1), dim3(1024), 0, stream, d_units.as<const UnitIn>(), d_result.as<const UnitOut>(), live,
-                           d_sym.as<const uint16_t>(), d_windows.as<uint8_t>());
+        GZ_TRY(e, d_maps.get(size_t(live) * kWindow * 2));
+        hipLaunchKernelGGL(gz_window_maps_kernel, dim3(std::min<uint32_t>(live, uint32_t(n_cu) * 8u)), dim3(256), 0, stream, d_units.as<const UnitIn>(),
+                           d_result.as<const UnitOut>(), live, d_p.as<const uint8_t>(), d_q.as<const uint8_t>(), d_maps.as<uint16_t>());
+        GZ_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(gz_windows_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(2u * kWindow)));
+        hipLaunchKernelGGL(gz_windows_chain_kernel, dim3(1), dim3(1024), 2u * kWindow, stream, d_maps.as<const uint16_t>(), live, d_windows.as<uint8_t>());
+        GZ_TRY(e, hipGetLastError());
+        GZ_TRACE("windows of %u units made", live);
         hipLaunchKernelGGL(gz_resolve_kernel, dim3(std::min<uint32_t>(live, uint32_t(n_cu) * 8u)), dim3(256), 0, stream,
                            d_units.as<const UnitIn>(), d_result.as<const UnitOut>(), d_text_at.as<const uint64_t>(), live,
-                           d_sym.as<const uint16_t>(), d_windows.as<const uint8_t>(), text);
+                           d_p.as<const uint8_t>(), d_q.as<const uint8_t>(), d_windows.as<const uint8_t>(), text);
         GZ_TRY(e, hipGetLastError());
         GZ_TRY(e, hipMemcpyAsync(carry.data(), d_windows.as<uint8_t>() + uint64_t(live) * kWindow, kWindow, hipMemcpyDeviceToHost, stream));
         GZ_TRY(e, hipStreamSynchronize(stream));
@@ -463,6 +567,7 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
         }
         crc = reg ^ advance_zero_bytes(0xFFFFFFFFu, total) ^ 0xFFFFFFFFu;     // the same register started from all ones, then inverted: zlib's CRC-32
     }
+    GZ_TRACE("CRC folded: done");
     *text_bytes = total;
     *deflate_bytes = (expect_start + 7) / 8;
     *crc32 = crc;

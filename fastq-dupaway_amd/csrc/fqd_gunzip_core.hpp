@@ -231,20 +231,36 @@ FQD_HD_CALL void fixed_codes(Tables& t, uint8_t* lens)
 // Is there a dynamic, non-final block header at stream bit `pos` whose codes are complete?  (What a unit's start is guessed by.)
 // In two steps, because of 64 offsets tried side by side nearly all fail the first — a few instructions, nothing but registers —
 // and the second wants 320 bytes of scratch: the three header bits, the counts, and a complete code-length code ...
+// `bits(d)`: at least 57 bits of the stream from bit pos + d on (d = 0, 17, 65: the kernel answers out of five words it holds
+// in registers and slides along, so that a turn of its loop waits for no load).
+// (The very first part of it, on 13 bits: the kernel sifts every offset with this alone and looks further at what passes.)
+FQD_HD bool block_start_header_bits(uint32_t w13)
+{
+    return (w13 & 7u) == 4u && ((w13 >> 3) & 31u) <= 29u && ((w13 >> 8) & 31u) <= 29u;     // BFINAL 0, BTYPE 2, HLIT <= 29 (286 codes), HDIST <= 29
+}
+template <class Bits>
+FQD_HD bool block_start_first_look_bits(Bits&& bits)
+{
+    uint64_t w = bits(0u);
+    if (!block_start_header_bits(uint32_t(w) & 0x1FFFu)) return false;
+    const uint32_t ncode = uint32_t((w >> 13) & 15u) + 4u;
+    // the code-length code is complete iff its lengths l > 0 add up to one in units of 2^-l (more: over-subscribed, less:
+    // incomplete) — a sum, no table of counts: on the GPU an array indexed by data lives in scratch memory
+    uint32_t kraft = 0;
+    w = bits(17u);
+    const uint64_t w2 = bits(17u + 48u);
+    for (uint32_t i = 0; i < 19u; ++i) {                                  // (all nineteen, the ones beyond ncode not counted: no loop whose length is data)
+        if (i == 16u) w = w2;
+        const uint32_t l = uint32_t(w & 7u);
+        kraft += (i < ncode && l) ? 128u >> l : 0u;
+        w >>= 3;
+    }
+    return kraft == 128u;
+}
 FQD_HD bool block_start_first_look(const BitIn& in, uint64_t pos)
 {
     if (pos + 300 > in.nbits) return false;                               // (a dynamic block's header alone is longer: 17 bits, >= 4 x 3, >= 257 lengths)
-    uint64_t w = in.peek(pos);
-    if ((w & 7u) != 4u) return false;                                     // BFINAL = 0, BTYPE = 2 (bits: 0, then 0 1)
-    if (((w >> 3) & 31u) > 29u || ((w >> 8) & 31u) > 29u) return false;   // HLIT <= 29 (286 codes), HDIST <= 29
-    const uint32_t ncode = uint32_t((w >> 13) & 15u) + 4u;
-    uint32_t count[8];
-    for (uint32_t l = 0; l < 8u; ++l) count[l] = 0;
-    w = in.peek(pos + 17);
-    for (uint32_t i = 0; i < ncode; ++i) { if (i == 16u) w = in.peek(pos + 17 + 48); ++count[w & 7u]; w >>= 3; }
-    int32_t left = 1;
-    for (uint32_t l = 1; l <= 7u; ++l) { left = (left << 1) - int32_t(count[l]); if (left < 0) return false; }
-    return left == 0;
+    return block_start_first_look_bits([&](uint32_t d) { return in.peek(pos + d); });
 }
 // ... then the lengths themselves and both codes.
 FQD_HD bool block_start_second_look(const BitIn& in, uint64_t pos, uint8_t* lens)

@@ -564,14 +564,22 @@ FQD_HD bool resolve_matches(Ctx& ctx, S& sh, uint8_t* out, const Token* tok, uin
     return fine;
 }
 
-// The whole member.  `tok` is room for kTokenRoom tokens (any memory this wave has to itself); kOk iff exactly
-// out_len bytes came out.
-template <class Ctx, class S>
-FQD_HD uint32_t inflate_member(Ctx& ctx, S& sh, const uint8_t* comp, uint32_t comp_len, uint8_t* out, uint32_t out_len, Token* tok)
+// The whole member (kUnit = false): `tok` is room for kTokenRoom tokens (any memory this wave has to itself); kOk iff
+// exactly out_len bytes came out.
+// A STRETCH of a longer deflate stream (kUnit = true; csrc/fqd_gunzip.hip: a unit of an ordinary gzip file): decoding starts
+// at bit `first_bit` of comp — a block boundary — and ends at the first boundary at or after `stop_bit` where a dynamic,
+// non-final block begins (what a unit's start is guessed by), or with the end of the final block; the text goes to
+// out[out_start ...) (out_len: all the room there is, out_start included), and matches may reach back into out[0, out_start):
+// the 32 KiB before the stretch, whatever the caller put there.  kOk: info[0] = the bit the stretch ended at, info[1] = where
+// its text ended in out, info[2] = 1 (a boundary) or 2 (the final block's end).
+constexpr uint32_t kStopHere = 100;
+template <bool kUnit, class Ctx, class S>
+FQD_HD uint32_t inflate_impl(Ctx& ctx, S& sh, const uint8_t* comp, uint32_t comp_len, uint32_t first_bit, uint32_t stop_bit,
+                             uint8_t* out, uint32_t out_start, uint32_t out_len, Token* tok, uint32_t* info)
 {
     constexpr uint32_t L = Ctx::kLanes;
     const uint32_t total_bits = comp_len * 8u;
-    uint32_t bitpos = 0, outpos = 0;
+    uint32_t bitpos = first_bit, outpos = out_start;
     for (;;) {
         // ---- block header: lane 0 reads it, everybody learns what it said ------------------------------------------
         ctx.lanes([&](uint32_t lane) {
@@ -580,7 +588,8 @@ FQD_HD uint32_t inflate_member(Ctx& ctx, S& sh, const uint8_t* comp, uint32_t co
             uint32_t status = kOk;
             const uint32_t last = in.take(1), type = in.take(2);
             uint32_t a = 0, b = 0, c = 0;
-            if (type == 0u) {
+            if (kUnit && bitpos != first_bit && !last && type == 2u && bitpos >= stop_bit) status = kStopHere;
+            else if (type == 0u) {
                 in.seek((in.pos() + 7u) & ~7u); in.ensure();
                 a = in.take(16); in.ensure();
                 const uint32_t nn = in.take(16);
@@ -596,6 +605,7 @@ FQD_HD uint32_t inflate_member(Ctx& ctx, S& sh, const uint8_t* comp, uint32_t co
         });
         ctx.mark(0);
         uint32_t status = ctx.same(sh.same[1]);
+        if (kUnit && status == kStopHere) { info[0] = bitpos; info[1] = outpos; info[2] = 1u; return kOk; }
         if (status != kOk) return status;
         const uint32_t last = ctx.same(sh.same[2]), type = ctx.same(sh.same[3]);
         bitpos = ctx.same(sh.same[6]);
@@ -726,7 +736,19 @@ FQD_HD uint32_t inflate_member(Ctx& ctx, S& sh, const uint8_t* comp, uint32_t co
         }
         if (last) break;
     }
+    if (kUnit) { info[0] = bitpos; info[1] = outpos; info[2] = 2u; return kOk; }
     return outpos == out_len ? uint32_t(kOk) : uint32_t(kShortOutput);
+}
+template <class Ctx, class S>
+FQD_HD uint32_t inflate_member(Ctx& ctx, S& sh, const uint8_t* comp, uint32_t comp_len, uint8_t* out, uint32_t out_len, Token* tok)
+{
+    return inflate_impl<false>(ctx, sh, comp, comp_len, 0u, 0xFFFFFFFFu, out, 0u, out_len, tok, nullptr);
+}
+template <class Ctx, class S>
+FQD_HD uint32_t inflate_stretch(Ctx& ctx, S& sh, const uint8_t* comp, uint32_t comp_len, uint32_t first_bit, uint32_t stop_bit,
+                                uint8_t* out, uint32_t out_start, uint32_t out_len, Token* tok, uint32_t* info)
+{
+    return inflate_impl<true>(ctx, sh, comp, comp_len, first_bit, stop_bit, out, out_start, out_len, tok, info);
 }
 
 } // namespace winf

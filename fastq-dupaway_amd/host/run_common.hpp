@@ -338,7 +338,7 @@ bool inflate_on_device();                                     // FQD_GUNZIP_DEVI
 bool deflate_on_device();                                     // FQD_GZ_DEVICE / FQD_GZ_LEVEL
 bool fetch_bgzf(const std::string& name, size_t block_bytes, int device, CompressedOnDevice& c, FileOnDevice* into = nullptr);
 bool fetch_plain(const std::string& name, size_t block_bytes, int device, FileOnDevice& f, uint64_t& text_bytes);
-bool fetch_gzip_ordinary(const std::string& name, size_t block_bytes, int device, FileOnDevice& f, uint64_t& text_bytes);   // FQD_GUNZIP_ORDINARY_DEVICE=1
+bool fetch_gzip_ordinary(const std::string& name, size_t block_bytes, int device, FileOnDevice& f, uint64_t& text_bytes);   // FQD_GUNZIP_ORDINARY_DEVICE=0: off
 bool records_on_device(fqd_engine* e, hipStream_t stream, Format format, uint64_t text_bytes, FileOnDevice& f);
 bool finish_on_device(fqd_engine* e, hipStream_t stream, Format format, CompressedOnDevice& c, FileOnDevice& f);
 void guess_capacity(int S, const std::string* in, uint64_t& reads, uint64_t& bases);

@@ -253,15 +253,16 @@ bool fetch_plain(const std::string& name, size_t block_bytes, int device, FileOn
     return at == size;
 }
 
-// An ORDINARY gzip file (one member, one long deflate stream: what gzip, pigz and sequencers write) to HBM as it lies on disk
-// and inflated THERE (fqd_gunzip: block starts guessed per unit, units decoded into symbols, windows, bytes).  Opt-in,
-// FQD_GUNZIP_ORDINARY_DEVICE=1: the kernels reach 4.6 GB/s of text on one MI355X, the several-thread host reader
-// (host/pgzip.hpp) 5.4 GB/s on the GPU box's share of cores — the device way takes the cores out of the job, not time.
-// false: not such a file, or anything irregular (a guess that did not hold, damage, CRC or length other than the trailer's,
-// further members): nothing is reported, the caller reads the file the host way.
+// An ORDINARY gzip file (one member, one long deflate stream: what gzip, pigz and sequencers write; the reference reads it
+// through the same decompressor as any .gz, file_utils.cpp:59-66) to HBM as it lies on disk and inflated THERE (fqd_gunzip:
+// block starts guessed per unit, every unit decoded twice over made-up windows, windows chained, bytes): 20 GB/s of text on one
+// MI355X against 5.4 for the several-thread host reader (host/pgzip.hpp), which stays the way for pipes, small files and
+// whatever is irregular.  FQD_GUNZIP_ORDINARY_DEVICE=0 turns it off.
+// false: not such a file, or anything irregular (a guess that did not hold and could not be repaired, damage, CRC or length
+// other than the trailer's, further members): nothing is reported, the caller reads the file the host way.
 bool fetch_gzip_ordinary(const std::string& name, size_t block_bytes, int device, FileOnDevice& f, uint64_t& text_bytes)
 {
-    static const bool wanted = [] { const char* v = std::getenv("FQD_GUNZIP_ORDINARY_DEVICE"); return v && std::atoi(v) != 0; }();
+    static const bool wanted = [] { const char* v = std::getenv("FQD_GUNZIP_ORDINARY_DEVICE"); return !v || std::atoi(v) != 0; }();
     uint64_t size = 0;
     if (!wanted || !has_gz_extension(name) || !is_regular_file(name, size) || size < 28) return false;
     InputFile file(name, true);
@@ -302,10 +303,9 @@ bool fetch_gzip_ordinary(const std::string& name, size_t block_bytes, int device
     if (at != size || header == 0) return false;
     const uint32_t want_crc = tail[0] | (uint32_t(tail[1]) << 8) | (uint32_t(tail[2]) << 16) | (uint32_t(tail[3]) << 24);
     const uint32_t isize = tail[4] | (uint32_t(tail[5]) << 8) | (uint32_t(tail[6]) << 16) | (uint32_t(tail[7]) << 24);
-    // room for the text: ISIZE is the length modulo 2^32; a file of several gigabytes packed has wrapped it, so room is the
-    // smallest length with that remainder that is at least 2.5 times the packed size (FASTQ packs 3-6 fold)
-    uint64_t room = isize;
-    while (room < size * 5 / 2) room += 1ull << 32;
+    // room for the text: ISIZE is its length modulo 2^32 only, so room is what FASTQ at its most packable needs (binned
+    // qualities: sevenfold) and at least what ISIZE says; a text that outgrows it sends the file to the host reader
+    const uint64_t room = std::max<uint64_t>(uint64_t(isize), size * 8u) + (64u << 10);
     f.text.room_for(room + 64, up);
     EngineHandle eng(1, device, up);                              // a small engine of this thread's own: the stream and the error slot of the call
     uint64_t tb = 0, db = 0; uint32_t crc = 0; int32_t ok = 0;

@@ -2,7 +2,9 @@
 // kernels of fqd_gunzip.hip run it: block starts guessed per unit, every unit decoded into 16-bit symbols from its guess,
 // the chain of unit ends and starts checked, windows made unit after unit, symbols turned into bytes.  What comes out is
 // written for tests/test_gunzip_core.py to compare with what zlib makes of the same file.  Test infrastructure only.
-//   gunzip_core_check <in.gz> <out> <unit_bytes> [max_ratio]     prints: status units bytes_out deflate_bytes
+//   gunzip_core_check <in.gz> <out> <unit_bytes> [max_ratio] [serial|planes]     prints: status units bytes_out deflate_bytes
+//   serial: fqd_gunzip_core.hpp's one decoder per unit writing symbols; planes (what the kernels do): the wave decoder of
+//   fqd_inflate_wave.hpp (its lanes a loop here) run TWICE per unit over two made-up windows, whose outputs together ARE the symbols
 //   status: ok | chain (a unit does not start where the one before it ended) | bad (damaged data) | full (a unit's room) | header
 #include <cstdio>
 #include <cstdlib>
@@ -13,8 +15,21 @@
 #include <vector>
 
 #include "../../fastq-dupaway_amd/csrc/fqd_gunzip_core.hpp"
+#include "../../fastq-dupaway_amd/csrc/fqd_inflate_wave.hpp"
 
 using namespace fqd::gunz;
+
+template <uint32_t L>
+struct LoopCtx {
+    static constexpr uint32_t kLanes = L;
+    template <class F> void lanes(F f) { for (uint32_t l = 0; l < L; ++l) f(l); }
+    template <class F> void lanes_open(F f) { for (uint32_t l = 0; l < L; ++l) f(l); }
+    void sync() {}
+    template <class F> uint64_t ballot(F f) { uint64_t m = 0; for (uint32_t l = 0; l < L; ++l) m |= uint64_t(f(l) ? 1u : 0u) << l; return m; }
+    uint32_t same(uint32_t v) const { return v; }
+    void add(uint32_t* p, uint32_t v) { *p += v; }
+    void mark(int) {}
+};
 
 struct ArraySink {
     uint16_t* p; uint64_t cap, n = 0;
@@ -74,7 +89,45 @@ int main(int argc, char** argv)
     // 2. every unit with a start, decoded on its own
     struct Unit { uint64_t start, end, stop_bit, span; uint32_t status; std::vector<uint16_t> sym; };
     std::vector<Unit> units;
+    const bool planes = argc > 5 && !std::strcmp(argv[5], "planes");
+    auto wsh = std::make_unique<fqd::winf::Shared<64>>();
+    std::vector<fqd::winf::Token> wtok(fqd::winf::kTokenRoom);
     auto decode = [&](Unit& x) {
+        if (planes) {
+            // the unit twice through the byte decoder, the 32 KiB before it made up: plane_P[w] = w & 255, plane_Q[w] = (w & 255) ^ (1 + (w >> 8)).
+            // A byte that comes out the same in both is a literal of the stream; one that differs was copied from place w of the window.
+            const uint64_t cap = x.span * ratio + 1024;
+            std::vector<uint8_t> pl[2];
+            uint32_t info[2][3] = {{0, 0, 0}, {0, 0, 0}}, st[2] = {0, 0};
+            const uint64_t byte0 = x.start >> 3;
+            const uint32_t first_bit = uint32_t(x.start & 7u);
+            const uint64_t rel_stop = x.stop_bit == UINT64_MAX ? 0xFFFFFFFFull : x.stop_bit - byte0 * 8;
+            const uint32_t comp_len = uint32_t(std::min<uint64_t>(len - byte0, 1u << 28));
+            std::vector<uint32_t> cw(comp_len / 4 + 4, 0);                   // the unit's bytes on, at the alignment they have in the file
+            uint8_t* cp = reinterpret_cast<uint8_t*>(cw.data()) + (byte0 & 3u);
+            std::memcpy(cp, base + byte0, comp_len);
+            LoopCtx<64> ctx;
+            for (int p = 0; p < 2; ++p) {
+                pl[p].assign(kWindow + cap + 16, 0xEE);
+                for (uint32_t w = 0; w < kWindow; ++w) pl[p][w] = p ? uint8_t((w & 255u) ^ (1u + (w >> 8))) : uint8_t(w & 255u);
+                st[p] = fqd::winf::inflate_stretch(ctx, *wsh, cp, comp_len, first_bit, uint32_t(std::min<uint64_t>(rel_stop, 0xFFFFFFFFull)),
+                                                   pl[p].data(), kWindow, uint32_t(kWindow + cap), wtok.data(), info[p]);
+            }
+            if (st[0] != fqd::winf::kOk || st[1] != fqd::winf::kOk || info[0][0] != info[1][0] || info[0][1] != info[1][1]) {
+                x.status = st[0] == fqd::winf::kOutputOverrun || st[1] == fqd::winf::kOutputOverrun ? uint32_t(kOutputFull) : uint32_t(kBadData);
+                x.end = 0; x.sym.clear();
+                return;
+            }
+            x.end = byte0 * 8 + info[0][0];
+            x.status = info[0][2] == 2u ? uint32_t(kFinal) : uint32_t(kBoundary);
+            const uint64_t n = info[0][1] - kWindow;
+            x.sym.resize(n);
+            for (uint64_t i = 0; i < n; ++i) {
+                const uint32_t a = pl[0][kWindow + i], b = pl[1][kWindow + i];
+                x.sym[i] = a == b ? uint16_t(a) : uint16_t(256u + (a | (((a ^ b) - 1u) << 8)));
+            }
+            return;
+        }
         x.sym.assign(x.span * ratio + 1024, 0);
         ArraySink sink{x.sym.data(), x.sym.size()};
         State st; st.pos = st.start_bit = x.start;

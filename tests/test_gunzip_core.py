@@ -15,28 +15,34 @@ HERE = Path(__file__).resolve().parent
 SRC = HERE / "native" / "gunzip_core_check.cpp"
 EXE = HERE / "native" / "gunzip_core_check"
 CORE = HERE.parent / "fastq-dupaway_amd" / "csrc" / "fqd_gunzip_core.hpp"
+WAVE = HERE.parent / "fastq-dupaway_amd" / "csrc" / "fqd_inflate_wave.hpp"
 
 
 def harness():
-    if not EXE.exists() or EXE.stat().st_mtime < max(SRC.stat().st_mtime, CORE.stat().st_mtime):
+    if not EXE.exists() or EXE.stat().st_mtime < max(SRC.stat().st_mtime, CORE.stat().st_mtime, WAVE.stat().st_mtime):
         subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-Wno-unknown-pragmas", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                         "-o", str(EXE), str(SRC)], check=True, capture_output=True)
     return EXE
 
 
-def run(raw: bytes, tmp_path, unit: int, ratio: int = 16):
+def run(raw: bytes, tmp_path, unit: int, ratio: int = 16, how: str = "planes"):
     src, out = tmp_path / "in.gz", tmp_path / "out.bin"
     src.write_bytes(raw)
-    r = subprocess.run([str(harness()), str(src), str(out), str(unit), str(ratio)], check=True, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([str(harness()), str(src), str(out), str(unit), str(ratio), how], check=True, capture_output=True, text=True, timeout=600)
     verdict, units, size, deflate_bytes = r.stdout.split()
     return verdict, int(units), out.read_bytes(), int(deflate_bytes)
 
 
+@pytest.mark.parametrize("how", ["planes", "serial"])
 @pytest.mark.parametrize("unit", [1 << 20, 65536, 4096])
 @pytest.mark.parametrize("name,data,raw", list(cases()), ids=[c[0] for c in cases()])
-def test_ordinary_gzip_inflates_as_zlib_does(tmp_path, name, data, raw, unit):
+def test_ordinary_gzip_inflates_as_zlib_does(tmp_path, name, data, raw, unit, how):
+    """planes: what fqd_gunzip.hip runs — the wave decoder of the BGZF reader twice per unit over two made-up windows; serial: the
+    reference form of the same scheme, one plain decoder per unit writing 16-bit symbols (fqd_gunzip_core.hpp)."""
+    if how == "serial" and unit == 1 << 20:
+        pytest.skip("one size less for the reference form")
     ratio = 2000 if name == "long_runs" else 16
-    verdict, units, got, deflate_bytes = run(raw, tmp_path, unit, ratio)
+    verdict, units, got, deflate_bytes = run(raw, tmp_path, unit, ratio, how)
     assert verdict == "ok" and got == data
     # the stream ends where the trailer begins: header + deflate + 8 bytes = the member
     header = len(raw) - 8 - deflate_bytes

@@ -464,6 +464,9 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
     const uint32_t decoders = uint32_t(std::min<uint64_t>(2u * units.size(), uint64_t(n_cu) * 16u));    // 10 KB of LDS, <= 128 VGPRs: sixteen waves a CU
     GZ_TRY(e, d_tokens.get(size_t(decoders) * fqd::winf::kTokenRoom * sizeof(fqd::winf::Token)));
     GZ_TRACE("scratch allocated: 2 planes of %llu bytes, %u decoders' tokens", (unsigned long long)plane_bytes, decoders);
+    struct Member { uint64_t text_from, text_to, deflate_end; uint32_t crc, isize; };
+    std::vector<Member> members;
+    uint64_t member_from = 0;
     std::vector<uint8_t> carry(kWindow, 0);                                   // the window before the next batch's first unit
     uint64_t total = 0, expect_start = 0, repairs = 0;
     bool final_seen = false, good = true;
@@ -515,7 +518,34 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
             text_at[k] = total; total += r.n;
             expect_start = r.end_bit;
             live = k + 1;
-            if (r.how == 2u) final_seen = true;
+            if (r.how == 2u) {
+                // the member's final block ended here: its trailer follows at the next byte, and — `cat a.gz b.gz`, or a writer that
+                // starts a member every so often — perhaps another member, whose first block the next unit is then decoded from
+                // (its own guess lies further on: the repair above takes it back)
+                const uint64_t trailer = (r.end_bit + 7u) / 8u;
+                if (trailer + 8u > avail_bytes) { good = false; break; }
+                uint8_t head[8 + 1024];
+                const size_t got = size_t(std::min<uint64_t>(sizeof head, avail_bytes - trailer));
+                GZ_TRY(e, hipMemcpyAsync(head, deflate + trailer, got, hipMemcpyDeviceToHost, stream));
+                GZ_TRY(e, hipStreamSynchronize(stream));
+                Member m;
+                m.text_from = member_from; m.text_to = total; m.deflate_end = trailer;
+                m.crc = head[0] | (uint32_t(head[1]) << 8) | (uint32_t(head[2]) << 16) | (uint32_t(head[3]) << 24);
+                m.isize = head[4] | (uint32_t(head[5]) << 8) | (uint32_t(head[6]) << 16) | (uint32_t(head[7]) << 24);
+                members.push_back(m);
+                member_from = total;
+                if (trailer + 8u == avail_bytes) { final_seen = true; break; }
+                // the next member's header (RFC 1952)
+                const uint8_t* h = head + 8; const size_t hn = got - 8;
+                size_t at_h = 10;
+                if (hn < 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || (h[3] & 0xE0)) { good = false; break; }
+                if (h[3] & 4) { if (at_h + 2 > hn) { good = false; break; } at_h += 2 + (h[at_h] | (size_t(h[at_h + 1]) << 8)); }
+                if (h[3] & 8) { while (at_h < hn && h[at_h]) ++at_h; ++at_h; }
+                if (h[3] & 16) { while (at_h < hn && h[at_h]) ++at_h; ++at_h; }
+                if (h[3] & 2) at_h += 2;
+                if (at_h + 2 > hn) { good = false; break; }
+                expect_start = (trailer + 8u + at_h) * 8u;
+            }
         }
         if (!good) break;
         // ---- 4, 5
@@ -535,41 +565,57 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
         GZ_TRY(e, hipMemcpyAsync(carry.data(), d_windows.as<uint8_t>() + uint64_t(live) * kWindow, kWindow, hipMemcpyDeviceToHost, stream));
         GZ_TRY(e, hipStreamSynchronize(stream));
         GZ_TRACE("windows and bytes of %u units done, %llu bytes of text so far", live, (unsigned long long)total);
-        at = hi;
+        at = at + live < hi && final_seen ? hi : at + live;                  // (units of the batch behind a repair that were not reached are decoded with the next batch)
+        if (at == units.size() && !final_seen && expect_start / 8u + 2u < avail_bytes) {
+            // members go on behind the last unit that had a start: the rest of the file as one more unit, from where the chain stands
+            UnitIn x;
+            x.start_bit = expect_start; x.stop_bit = ~0ull; x.at = 0;
+            x.cap = ((avail_bytes - expect_start / 8u) * ratio + 1024u + 15u) & ~uint64_t(15);
+            if (room_of(x) > plane_bytes) { good = false; break; }
+            units.push_back(x);
+        }
     }
     if (!good || !final_seen) return FQD_OK;                                  // *ok stays 0: the caller reads the file the host way
 
-    // ---- CRC-32 of the text
+    // ---- CRC-32 and length of every member's text against its trailer
+    if (members.empty()) return FQD_OK;
     uint32_t crc = 0;
-    if (total) {
-        const uint64_t n_slices = (total + kSlice - 1) / kSlice;
+    {
         DevMem d_shift, d_raw;
         GZ_TRY(e, d_shift.get(8 * 32 * 4));
-        GZ_TRY(e, d_raw.get(n_slices * 4));
+        GZ_TRY(e, d_raw.get(((total + kSlice - 1) / kSlice + members.size()) * 4));
         uint32_t shift[8][32];
         Mat m = mat_one_zero_byte();
         for (int k = 0; k < 8; ++k) m = mat_square(m);                        // 256 zero bytes
         for (int k = 0; k < 8; ++k) { std::memcpy(shift[k], m.col, sizeof m.col); m = mat_square(m); }
         const Mat slice_mat = m;                                              // 65536 zero bytes
         GZ_TRY(e, hipMemcpyAsync(d_shift.p, shift, sizeof shift, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(gz_crc_kernel, dim3(uint32_t(std::min<uint64_t>(n_slices, uint64_t(n_cu) * 8u))), dim3(kCrcThreads), 0, stream,
-                           static_cast<const uint8_t*>(text), total, n_slices, d_shift.as<const uint32_t>(), d_raw.as<uint32_t>());
-        GZ_TRY(e, hipGetLastError());
-        GZ_TRACE("CRC of %llu slices queued", (unsigned long long)n_slices);
-        std::vector<uint32_t> raw(n_slices);
-        GZ_TRY(e, hipMemcpyAsync(raw.data(), d_raw.p, n_slices * 4, hipMemcpyDeviceToHost, stream));
-        GZ_TRY(e, hipStreamSynchronize(stream));
-        // raw register of the whole text started from 0: full slices fold with the 64 KiB matrix, the short last one with its own length
-        uint32_t reg = 0;
-        for (uint64_t s = 0; s < n_slices; ++s) {
-            const uint64_t len = s + 1 < n_slices ? kSlice : total - s * kSlice;
-            reg = (len == kSlice ? mat_apply(slice_mat, reg) : advance_zero_bytes(reg, len)) ^ raw[s];
+        std::vector<uint32_t> raw;
+        for (const Member& mb : members) {
+            const uint64_t len = mb.text_to - mb.text_from;
+            crc = 0;
+            if (len) {
+                const uint64_t n_slices = (len + kSlice - 1) / kSlice;
+                hipLaunchKernelGGL(gz_crc_kernel, dim3(uint32_t(std::min<uint64_t>(n_slices, uint64_t(n_cu) * 8u))), dim3(kCrcThreads), 0, stream,
+                                   static_cast<const uint8_t*>(text) + mb.text_from, len, n_slices, d_shift.as<const uint32_t>(), d_raw.as<uint32_t>());
+                GZ_TRY(e, hipGetLastError());
+                raw.resize(n_slices);
+                GZ_TRY(e, hipMemcpyAsync(raw.data(), d_raw.p, n_slices * 4, hipMemcpyDeviceToHost, stream));
+                GZ_TRY(e, hipStreamSynchronize(stream));
+                // raw register of the member's text started from 0: full slices fold with the 64 KiB matrix, the short last one with its own length
+                uint32_t reg = 0;
+                for (uint64_t sl = 0; sl < n_slices; ++sl) {
+                    const uint64_t l = sl + 1 < n_slices ? kSlice : len - sl * kSlice;
+                    reg = (l == kSlice ? mat_apply(slice_mat, reg) : advance_zero_bytes(reg, l)) ^ raw[sl];
+                }
+                crc = reg ^ advance_zero_bytes(0xFFFFFFFFu, len) ^ 0xFFFFFFFFu;   // the same register started from all ones, then inverted: zlib's CRC-32
+            }
+            if (crc != mb.crc || uint32_t(len) != mb.isize) { GZ_TRACE("a member's CRC-32 or length is not its trailer's"); return FQD_OK; }   // *ok stays 0
         }
-        crc = reg ^ advance_zero_bytes(0xFFFFFFFFu, total) ^ 0xFFFFFFFFu;     // the same register started from all ones, then inverted: zlib's CRC-32
     }
-    GZ_TRACE("CRC folded: done");
+    GZ_TRACE("%zu member(s): CRC-32 and length as the trailers say", members.size());
     *text_bytes = total;
-    *deflate_bytes = (expect_start + 7) / 8;
+    *deflate_bytes = members.back().deflate_end;
     *crc32 = crc;
     *ok = 1;
     return FQD_OK;

@@ -253,13 +253,13 @@ bool fetch_plain(const std::string& name, size_t block_bytes, int device, FileOn
     return at == size;
 }
 
-// An ORDINARY gzip file (one member, one long deflate stream: what gzip, pigz and sequencers write; the reference reads it
+// An ORDINARY gzip file (members that are one long deflate stream each: what gzip, pigz and sequencers write; the reference reads it
 // through the same decompressor as any .gz, file_utils.cpp:59-66) to HBM as it lies on disk and inflated THERE (fqd_gunzip:
 // block starts guessed per unit, every unit decoded twice over made-up windows, windows chained, bytes): 20 GB/s of text on one
 // MI355X against 5.4 for the several-thread host reader (host/pgzip.hpp), which stays the way for pipes, small files and
 // whatever is irregular.  FQD_GUNZIP_ORDINARY_DEVICE=0 turns it off.
 // false: not such a file, or anything irregular (a guess that did not hold and could not be repaired, damage, CRC or length
-// other than the trailer's, further members): nothing is reported, the caller reads the file the host way.
+// other than a trailer's, bytes behind the last member): nothing is reported, the caller reads the file the host way.
 bool fetch_gzip_ordinary(const std::string& name, size_t block_bytes, int device, FileOnDevice& f, uint64_t& text_bytes)
 {
     static const bool wanted = [] { const char* v = std::getenv("FQD_GUNZIP_ORDINARY_DEVICE"); return !v || std::atoi(v) != 0; }();
@@ -311,7 +311,8 @@ bool fetch_gzip_ordinary(const std::string& name, size_t block_bytes, int device
     uint64_t tb = 0, db = 0; uint32_t crc = 0; int32_t ok = 0;
     const int rc = fqd_gunzip(eng.e, reinterpret_cast<const uint8_t*>(comp.p) + header, size - header, reinterpret_cast<uint8_t*>(f.text.p), room, &tb, &db, &crc, &ok);
     if (rc != FQD_OK) throw DeviceError(std::string("GPU engine: ") + fqd_last_error(eng.e));
-    if (!ok || header + db + 8 != size || crc != want_crc || uint32_t(tb) != isize) return false;
+    (void)want_crc; (void)isize; (void)crc;                          // (every member's CRC-32 and ISIZE were held against its trailer by the call)
+    if (!ok || header + db + 8 != size) return false;
     text_bytes = tb;
     return true;
 }

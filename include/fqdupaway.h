@@ -419,17 +419,20 @@ int  fqd_bgzf_deflate(fqd_engine* e, const uint8_t* src, uint64_t n, uint32_t li
 int  fqd_bgzf_inflate(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_off, const uint32_t* comp_len,
                       const uint64_t* out_off, const uint32_t* out_len, const uint32_t* crc, uint64_t n_members,
                       uint8_t* text, uint64_t* n_bad);
-/* An ORDINARY gzip member (one long deflate stream without member sizes: what gzip, pigz and sequencer software write; the
- * reference reads it through the same gzip decompressor, file_utils.cpp:59-66) inflated in HBM.  `deflate` (device; any
- * alignment; 32 readable bytes behind the last one) points at the member's raw deflate stream — the caller has walked the
- * 10-byte-plus header — and avail_bytes says how many bytes of the file lie from there on (the trailer and whatever
- * follows included).  The stream is cut into units whose block starts are GUESSED, every unit is decoded on its own into
- * 16-bit symbols that stand for a byte or for "a byte of the 32 KiB before this unit", the chain of unit ends and starts is
- * checked, and the symbols become text (csrc/fqd_gunzip_core.hpp).  *ok = 1: text[0 .. *text_bytes) is the member's text,
- * *deflate_bytes the length of its deflate stream (the 8-byte trailer follows: CRC-32 and ISIZE, for the caller to hold
- * against *crc32 and *text_bytes), *crc32 the CRC-32 of the text.  *ok = 0: a guess that did not hold, damaged data, a unit
- * that outgrew its room or a text longer than text_cap — nothing is reported beyond that: the caller reads the file the
- * host way, which produces the reference-visible diagnostic.  Waits for the stream. */
+/* An ORDINARY gzip file (members that are one long deflate stream without member sizes: what gzip, pigz and sequencer software
+ * write; the reference reads it through the same gzip decompressor, file_utils.cpp:59-66) inflated in HBM.  `deflate` (device;
+ * any alignment; 32 readable bytes behind the last one) points at the FIRST member's raw deflate stream — the caller has walked
+ * its 10-byte-plus header — and avail_bytes says how many bytes of the file lie from there on (trailers and further members
+ * included).  The stream is cut into units whose block starts are GUESSED; every unit is decoded on its own — twice, by the wave
+ * decoder of the BGZF reader, over two made-up 32 KiB windows, so that what comes out says for every byte whether it is a byte of
+ * the stream or a copy of a place of the window before the unit — the chain of unit ends and starts is checked (a wrong guess:
+ * the unit is decoded again from the true boundary), the windows are made unit after unit, and the places become text
+ * (csrc/fqd_gunzip.hip).  Further members are walked where a final block ends; every member's CRC-32 and ISIZE are held against
+ * its trailer.  *ok = 1: text[0 .. *text_bytes) is the text of all members, *deflate_bytes the offset (from `deflate`) at which
+ * the LAST member's deflate stream ends (its 8-byte trailer is the end of the file's data), *crc32 that member's CRC-32.
+ * *ok = 0: a guess that could not be repaired, damaged data, a CRC or length that is not the trailer's, bytes behind the last
+ * member that are no member, a unit that outgrew its room or a text longer than text_cap — nothing is reported beyond that: the
+ * caller reads the file the host way, which produces the reference-visible diagnostic.  Waits for the stream. */
 int  fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint8_t* text, uint64_t text_cap,
                 uint64_t* text_bytes, uint64_t* deflate_bytes, uint32_t* crc32, int32_t* ok);
 

@@ -560,7 +560,8 @@ def test_ordered_runs_on_bgzf_inputs_stay_on_the_device(exe, oracle, tmp_path, c
                 return None
             return gzip.open(p, "rb").read() if str(p).endswith(".gz") else p.read_bytes()
         runs[resident] = (r.returncode, r.stdout, said, [content(p) for p in outs])
-        good = case in ("fastq_to_gz", "fastq_to_plain", "fasta", "small_windows", "plain_in_gz_out") or (case == "uneven_pairs" and not paired)
+        # (plain_gzip: file 1 is an ORDINARY gzip file — inflated on the GPU too, fqd_gunzip, since round 4)
+        good = case in ("fastq_to_gz", "fastq_to_plain", "fasta", "small_windows", "plain_in_gz_out", "plain_gzip") or (case == "uneven_pairs" and not paired)
         if r.returncode == 0:
             assert ("ordered/resident: survivors out of HBM" in r.stderr) == (resident == "1" and good), r.stderr
     assert runs["1"] == runs["0"]
@@ -590,8 +591,9 @@ def test_ordinary_gzip_inputs_inflated_on_the_device(exe, oracle, tmp_path, case
     """FQD_GUNZIP_ORDINARY_DEVICE=1: an ordinary `.gz` (one long deflate stream, what gzip / pigz / sequencers write; reference
     file_utils.cpp:59-66 reads it through the same decompressor) goes to HBM as it lies on disk and is inflated THERE
     (fqd_gunzip).  Good files: the oracle's bytes and lines, and the device really did it (its stage shows in the timing).
-    Anything irregular — damage, a cut file, several members, an unknown base — is left to the host reader: exactly what the
-    run without the switch gives, message, exit code and partial output alike."""
+    Several members (`cat a.gz b.gz`) are walked on the device too.  Anything irregular — damage, a cut file, an unknown base —
+    is left to the host reader: exactly what the run with FQD_GUNZIP_ORDINARY_DEVICE=0 gives, message, exit code and partial
+    output alike."""
     from gunzip_cases import header_with_fields, member
     rnd = random.Random(23)
     n = 30000
@@ -623,7 +625,7 @@ def test_ordinary_gzip_inputs_inflated_on_the_device(exe, oracle, tmp_path, case
         said = "\n".join(l for l in r.stderr.splitlines() if "[host timing]" not in l)
         content = [gzip.open(p, "rb").read() if p.exists() else None for p in outs] if r.returncode == 0 else [p.exists() for p in outs]
         runs[device] = (r.returncode, r.stdout, said, content)
-        if device == "1" and case in ("good", "header_fields") and mode != "unordered":
+        if device == "1" and case in ("good", "header_fields", "two_members") and mode != "unordered":
             assert "ordered/resident: survivors out of HBM" in r.stderr, r.stderr       # the resident run took the files: nothing was left to the host reader
     assert runs["1"] == runs["0"]
     rc, out, said, got = runs["1"]

@@ -60,6 +60,29 @@ def test_ordinary_gzip_inflates_as_zlib_does(eng, monkeypatch, name, data, raw):
         assert crc == want_crc == (zlib.crc32(data) & 0xFFFFFFFF) and isize == len(data) & 0xFFFFFFFF
 
 
+def test_several_members_are_walked(eng, monkeypatch):
+    """`cat a.gz b.gz c.gz`: where a final block ends the trailer is read and, behind it, the next member's header; every member's
+    CRC-32 and ISIZE are held against its own trailer; a member that starts behind the last guessed block start is still found."""
+    a, b, c = fastq_text(30000, 5), fastq_text(9000, 6), b"@t\nACGT\n+\nIIII\n"
+    from gunzip_cases import header_with_fields
+    raw = member(a, 6) + member(b, 1, header=header_with_fields()) + member(c, 9) + member(b"", 6) + member(b[:70000], 6)
+    data = a + b + c + b[:70000]
+    for unit_kb in (None, "64", "8"):
+        if unit_kb:
+            monkeypatch.setenv("FQD_GUNZIP_UNIT_KB", unit_kb)
+        ok, got, deflate_bytes, crc, h = device_gunzip(eng, raw, len(data) + 10)
+        assert ok and got == data
+        assert h + deflate_bytes + 8 == len(raw) and crc == zlib.crc32(b[:70000]) & 0xFFFFFFFF
+    dmg = bytearray(raw); dmg[len(member(a, 6)) + 2] ^= 1                      # the second member's method byte: no member
+    ok, _, _, _, _ = device_gunzip(eng, bytes(dmg), len(data) + 10)
+    assert not ok
+    wrong = bytearray(raw); wrong[len(member(a, 6)) - 8] ^= 1                  # the first member's CRC in its trailer
+    ok, _, _, _, _ = device_gunzip(eng, bytes(wrong), len(data) + 10)
+    assert not ok
+    ok, _, _, _, _ = device_gunzip(eng, raw + b"\0\0\0\0", len(data) + 10)       # bytes behind the last member that are no member
+    assert not ok
+
+
 def test_batches_of_units_carry_the_window_over(eng, monkeypatch):
     """A scratch far too small for all units at once: several batches, the 32 KiB window handed from one to the next."""
     data = fastq_text(60000, 7)

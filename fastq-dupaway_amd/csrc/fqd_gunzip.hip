@@ -442,14 +442,16 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
         UnitIn x;
         x.start_bit = start[u];
         x.stop_bit = next < n_nominal ? next * unit_bytes * 8u : ~0ull;
-        x.cap = ((next - u) * unit_bytes * ratio + 1024u + 15u) & ~uint64_t(15);
+        // room: `ratio` bytes of text per compressed byte of the unit's stretch — and of one unit more: a unit that is decoded again
+        // from the boundary the unit before it REALLY ended at (a member that ends early in that unit) starts that much earlier
+        x.cap = ((next - u + 1u) * unit_bytes * ratio + 1024u + 15u) & ~uint64_t(15);
         x.at = 0;
         units.push_back(x);
     }
 
     GZ_TRACE("%zu units have a start", units.size());
     // ---- 2-5 in batches of units whose two planes fit the scratch
-    uint64_t plane_bytes = uint64_t(4) << 30;                                // per plane
+    uint64_t plane_bytes = uint64_t(8) << 30;                                // per plane
     if (const char* v = std::getenv("FQD_GUNZIP_SCRATCH_MB")) { const long mb = std::atol(v); if (mb > 0) plane_bytes = (uint64_t(mb) << 20) / 2; }
     auto room_of = [](const UnitIn& x) { return uint64_t(kWindow) + x.cap + 64u; };          // made-up window, text, slack (a multiple of 16)
     {
@@ -513,8 +515,12 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
                 GZ_TRACE("unit %zu decoded again from bit %llu: status %u, %llu bytes", at + k, (unsigned long long)expect_start, result[2u * k].status, (unsigned long long)result[2u * k].n);
             }
             const UnitOut& r = result[2u * k]; const UnitOut& r2 = result[2u * k + 1u];
-            if (r.status != fqd::winf::kOk || r2.status != fqd::winf::kOk || r.end_bit != r2.end_bit || r.n != r2.n || r.how != r2.how) { good = false; break; }
-            if (total + r.n > text_cap) { good = false; break; }
+            if (r.status != fqd::winf::kOk || r2.status != fqd::winf::kOk || r.end_bit != r2.end_bit || r.n != r2.n || r.how != r2.how) {
+                GZ_TRACE("unit %zu (from bit %llu, room %llu): status %u / %u, %llu / %llu bytes: giving up", at + k, (unsigned long long)x.start_bit, (unsigned long long)x.cap,
+                         r.status, r2.status, (unsigned long long)r.n, (unsigned long long)r2.n);
+                good = false; break;
+            }
+            if (total + r.n > text_cap) { GZ_TRACE("the text outgrows the room given (%llu bytes)", (unsigned long long)text_cap); good = false; break; }
             text_at[k] = total; total += r.n;
             expect_start = r.end_bit;
             live = k + 1;

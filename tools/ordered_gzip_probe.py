@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=30_000_000)
     ap.add_argument("--dir", default="/dev/shm/fqd_og")
+    ap.add_argument("--quick", action="store_true", help="host reader: the default and zlib only")
     a = ap.parse_args()
     import numpy as np
     from fastq_dupaway_amd import _lib
@@ -46,10 +47,22 @@ def main():
     print(f"{plain.stat().st_size / 1e9:.2f} GB of FASTQ -> {gz.stat().st_size / 1e9:.2f} GB of ordinary gzip", flush=True)
     plain.unlink()
     said = {}
-    for pg in ("1", "1:12", "1:16", "1:4", "0"):
+    # first the default (round 4: the file to HBM as it lies on disk, inflated there by fqd_gunzip), twice, with its stages
+    for rep in range(2):
+        out = d / "out_dev.fq"
+        out.unlink(missing_ok=True)
+        t0 = time.perf_counter()
+        r = subprocess.run([str(_lib.CLI_PATH), "-i", str(gz), "-o", str(out), "--fast", "-v"], capture_output=True, text=True,
+                           env=dict(os.environ, FQD_HOST_TIMING="1", FQD_GUNZIP_TRACE="1" if rep else "0"))
+        dt = time.perf_counter() - t0
+        said["device"] = (r.returncode, r.stdout, out.stat().st_size)
+        print(f"inflated on the GPU: rc={r.returncode} {dt:.2f} s = {n / dt / 1e6:.2f} M reads/s | {r.stdout.strip()}", flush=True)
+        keep = [l for l in r.stderr.splitlines() if "[host timing]" in l or ("[gunzip" in l and ("member" in l or "units have" in l or "scratch" in l or "decoded again" not in l))]
+        print("\n".join(keep[:60] if rep else keep[:40]), flush=True)
+    for pg in ("1", "0") if a.quick else ("1", "1:12", "1:16", "1:4", "0"):
         out = d / f"out{pg[0]}.fq"
         out.unlink(missing_ok=True)
-        env = dict(os.environ, FQD_PGZIP=pg[0])
+        env = dict(os.environ, FQD_PGZIP=pg[0], FQD_GUNZIP_ORDINARY_DEVICE="0")
         if ":" in pg:
             env["FQD_PGZIP_THREADS"] = pg.split(":")[1]
         t0 = time.perf_counter()

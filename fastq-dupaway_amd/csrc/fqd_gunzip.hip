@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 #include <unistd.h>
 
@@ -447,6 +448,9 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
         x.cap = ((next - u + 1u) * unit_bytes * ratio + 1024u + 15u) & ~uint64_t(15);
         x.at = 0;
         units.push_back(x);
+        // a long stretch without a dynamic block's start (stored or fixed blocks only: nothing a sequencer or gzip writes for FASTQ)
+        // would be ONE wave's work at some 30 MB/s: beyond 32 MiB the host reader is the faster way, and the caller takes it
+        if ((next - u) * unit_bytes > (uint64_t(32) << 20)) { GZ_TRACE("%llu bytes without a block start that can be guessed: left to the host reader", (unsigned long long)((next - u) * unit_bytes)); return FQD_OK; }
     }
 
     GZ_TRACE("%zu units have a start", units.size());
@@ -475,6 +479,36 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
     std::vector<UnitOut> result;
     std::vector<uint64_t> text_at;
     size_t at = 0;
+    // What follows a member's final block: its trailer (CRC-32, ISIZE) and the end of the file, or the header of another member (RFC 1952).
+    struct Trailer { uint32_t crc = 0, isize = 0; int kind = 0; /* 0 neither, 1 the file ends, 2 another member */ uint64_t next_start = 0; };
+    std::unordered_map<uint64_t, Trailer> trailers;                          // by byte offset: looked at twice (below), fetched once
+    auto trailer_at = [&](uint64_t end_bit, Trailer& t) -> int {
+        const uint64_t trailer = (end_bit + 7u) / 8u;
+        const auto it = trailers.find(trailer);
+        if (it != trailers.end()) { t = it->second; return FQD_OK; }
+        t = Trailer();
+        if (trailer + 8u <= avail_bytes) {
+            uint8_t head[8 + 1024];
+            const size_t got = size_t(std::min<uint64_t>(sizeof head, avail_bytes - trailer));
+            GZ_TRY(e, hipMemcpyAsync(head, deflate + trailer, got, hipMemcpyDeviceToHost, stream));
+            GZ_TRY(e, hipStreamSynchronize(stream));
+            t.crc = head[0] | (uint32_t(head[1]) << 8) | (uint32_t(head[2]) << 16) | (uint32_t(head[3]) << 24);
+            t.isize = head[4] | (uint32_t(head[5]) << 8) | (uint32_t(head[6]) << 16) | (uint32_t(head[7]) << 24);
+            if (trailer + 8u == avail_bytes) t.kind = 1;
+            else {
+                const uint8_t* h = head + 8; const size_t hn = got - 8;
+                size_t at_h = 10;
+                bool fine = hn >= 18 && h[0] == 31 && h[1] == 139 && h[2] == 8 && !(h[3] & 0xE0);
+                if (fine && (h[3] & 4)) { if (at_h + 2 > hn) fine = false; else at_h += 2 + (h[at_h] | (size_t(h[at_h + 1]) << 8)); }
+                if (fine && (h[3] & 8)) { while (at_h < hn && h[at_h]) ++at_h; ++at_h; }
+                if (fine && (h[3] & 16)) { while (at_h < hn && h[at_h]) ++at_h; ++at_h; }
+                if (fine && (h[3] & 2)) at_h += 2;
+                if (fine && at_h + 2 <= hn) { t.kind = 2; t.next_start = (trailer + 8u + at_h) * 8u; }
+            }
+        }
+        trailers[trailer] = t;
+        return FQD_OK;
+    };
     auto decode = [&](uint32_t first, uint32_t count) -> int {              // units [first, first + count) of the batch, both planes
         GZ_TRY(e, hipMemsetAsync(d_counter.p, 0, 64, stream));
         hipLaunchKernelGGL(gz_decode_planes_kernel, dim3(std::min<uint32_t>(2u * count, decoders)), dim3(kWave), 0, stream,
@@ -501,13 +535,56 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
         if (rc) return rc;
         GZ_TRACE("decoded: first unit status %u, %llu bytes, end bit %llu", result[0].status, (unsigned long long)result[0].n, (unsigned long long)result[0].end_bit);
         // ---- 3. the chain
+        // Units that do not start where the unit before them ended — a guess that did not hold (a header-like stretch of bits inside a
+        // block: a few per gigabyte), or the unit behind a member's end, whose next member starts where the trailer and a header
+        // say — are decoded again from there.  One wave decodes some 30 MB/s of packed bytes, so such units are first collected over
+        // the whole batch, on the assumption that where a unit ENDS does not change when it is decoded again (both starts are block
+        // boundaries of one stream), and decoded again in ONE launch; the chain below then checks every link and mends, one unit
+        // at a time, what that assumption missed.  (One launch per unit: 13 ms each, 90 of the 188 ms of a 12-member file.)
+        {
+            std::vector<uint32_t> again;
+            uint64_t expect = expect_start;
+            for (uint32_t k = 0; k < nb; ++k) {
+                UnitIn& x = units[at + k];
+                if (x.start_bit != expect) { x.start_bit = expect; again.push_back(k); }
+                const UnitOut& r = result[2u * k]; const UnitOut& r2 = result[2u * k + 1u];
+                if (r.status != fqd::winf::kOk || r2.status != fqd::winf::kOk || r.end_bit != r2.end_bit || r.how != r2.how) break;   // garbage from a wrong guess: the chain takes over here
+                if (r.how == 2u) {
+                    Trailer t;
+                    if ((rc = trailer_at(r.end_bit, t))) return rc;
+                    if (t.kind != 2) break;
+                    expect = t.next_start;
+                } else expect = r.end_bit;
+            }
+            if (!again.empty()) {
+                repairs += again.size();
+                if (repairs > 64u + units.size() / 16u) { GZ_TRACE("%llu units do not start where the one before them ended: giving up", (unsigned long long)repairs); good = false; break; }
+                std::vector<UnitIn> ru(again.size());
+                for (size_t i = 0; i < again.size(); ++i) ru[i] = units[at + again[i]];
+                std::vector<UnitOut> rr(2u * again.size());
+                DevMem d_ru, d_rr;
+                GZ_TRY(e, d_ru.get(ru.size() * sizeof(UnitIn)));
+                GZ_TRY(e, d_rr.get(rr.size() * sizeof(UnitOut)));
+                GZ_TRY(e, hipMemcpyAsync(d_ru.p, ru.data(), ru.size() * sizeof(UnitIn), hipMemcpyHostToDevice, stream));
+                GZ_TRY(e, hipMemsetAsync(d_counter.p, 0, 64, stream));
+                hipLaunchKernelGGL(gz_decode_planes_kernel, dim3(std::min<uint32_t>(2u * uint32_t(ru.size()), decoders)), dim3(kWave), 0, stream,
+                                   deflate, avail_bytes, d_ru.as<const UnitIn>(), uint32_t(ru.size()), d_p.as<uint8_t>(), d_q.as<uint8_t>(),
+                                   d_tokens.as<fqd::winf::Token>(), d_rr.as<UnitOut>(), d_counter.as<uint32_t>());
+                GZ_TRY(e, hipGetLastError());
+                GZ_TRY(e, hipMemcpyAsync(rr.data(), d_rr.p, rr.size() * sizeof(UnitOut), hipMemcpyDeviceToHost, stream));
+                GZ_TRY(e, hipStreamSynchronize(stream));
+                for (size_t i = 0; i < again.size(); ++i) { result[2u * again[i]] = rr[2u * i]; result[2u * again[i] + 1u] = rr[2u * i + 1u]; }
+                GZ_TRY(e, hipMemcpyAsync(d_units.p, units.data() + at, nb * sizeof(UnitIn), hipMemcpyHostToDevice, stream));
+                GZ_TRY(e, hipMemcpyAsync(d_result.p, result.data(), 2u * nb * sizeof(UnitOut), hipMemcpyHostToDevice, stream));
+                GZ_TRACE("%zu units decoded again in one launch, each from where the unit before it ended", again.size());
+            }
+        }
         text_at.resize(nb);
         uint32_t live = 0;
         for (uint32_t k = 0; k < nb && good && !final_seen; ++k) {
             UnitIn& x = units[at + k];
             if (x.start_bit != expect_start) {
-                // a guess that did not hold (a header-like stretch of bits inside a block: a few per gigabyte): the unit before ended
-                // at the true boundary, so this one is decoded again from there — one small launch — and the chain goes on
+                // what the pass above could not know: the unit before this one ended elsewhere when it was decoded again
                 if (++repairs > 64u + units.size() / 16u) { good = false; break; }       // (damage, not bad luck)
                 x.start_bit = expect_start;
                 GZ_TRY(e, hipMemcpyAsync(d_units.as<UnitIn>() + k, &x, sizeof(UnitIn), hipMemcpyHostToDevice, stream));
@@ -527,30 +604,16 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
             if (r.how == 2u) {
                 // the member's final block ended here: its trailer follows at the next byte, and — `cat a.gz b.gz`, or a writer that
                 // starts a member every so often — perhaps another member, whose first block the next unit is then decoded from
-                // (its own guess lies further on: the repair above takes it back)
-                const uint64_t trailer = (r.end_bit + 7u) / 8u;
-                if (trailer + 8u > avail_bytes) { good = false; break; }
-                uint8_t head[8 + 1024];
-                const size_t got = size_t(std::min<uint64_t>(sizeof head, avail_bytes - trailer));
-                GZ_TRY(e, hipMemcpyAsync(head, deflate + trailer, got, hipMemcpyDeviceToHost, stream));
-                GZ_TRY(e, hipStreamSynchronize(stream));
+                Trailer t;
+                if ((rc = trailer_at(r.end_bit, t))) return rc;
+                if (t.kind == 0) { GZ_TRACE("no trailer, or no member header, behind the final block that ends at bit %llu", (unsigned long long)r.end_bit); good = false; break; }
                 Member m;
-                m.text_from = member_from; m.text_to = total; m.deflate_end = trailer;
-                m.crc = head[0] | (uint32_t(head[1]) << 8) | (uint32_t(head[2]) << 16) | (uint32_t(head[3]) << 24);
-                m.isize = head[4] | (uint32_t(head[5]) << 8) | (uint32_t(head[6]) << 16) | (uint32_t(head[7]) << 24);
+                m.text_from = member_from; m.text_to = total; m.deflate_end = (r.end_bit + 7u) / 8u;
+                m.crc = t.crc; m.isize = t.isize;
                 members.push_back(m);
                 member_from = total;
-                if (trailer + 8u == avail_bytes) { final_seen = true; break; }
-                // the next member's header (RFC 1952)
-                const uint8_t* h = head + 8; const size_t hn = got - 8;
-                size_t at_h = 10;
-                if (hn < 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || (h[3] & 0xE0)) { good = false; break; }
-                if (h[3] & 4) { if (at_h + 2 > hn) { good = false; break; } at_h += 2 + (h[at_h] | (size_t(h[at_h + 1]) << 8)); }
-                if (h[3] & 8) { while (at_h < hn && h[at_h]) ++at_h; ++at_h; }
-                if (h[3] & 16) { while (at_h < hn && h[at_h]) ++at_h; ++at_h; }
-                if (h[3] & 2) at_h += 2;
-                if (at_h + 2 > hn) { good = false; break; }
-                expect_start = (trailer + 8u + at_h) * 8u;
+                if (t.kind == 1) { final_seen = true; break; }
+                expect_start = t.next_start;
             }
         }
         if (!good) break;

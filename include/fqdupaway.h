@@ -431,7 +431,8 @@ int  fqd_bgzf_inflate(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_o
  * its trailer.  *ok = 1: text[0 .. *text_bytes) is the text of all members, *deflate_bytes the offset (from `deflate`) at which
  * the LAST member's deflate stream ends (its 8-byte trailer is the end of the file's data), *crc32 that member's CRC-32.
  * *ok = 0: a guess that could not be repaired, damaged data, a CRC or length that is not the trailer's, bytes behind the last
- * member that are no member, a unit that outgrew its room or a text longer than text_cap — nothing is reported beyond that: the
+ * member that are no member, a unit that outgrew its room, a text longer than text_cap, or more than 32 MiB of packed bytes in
+ * which no dynamic block starts (stored or fixed blocks only: one wave's work) — nothing is reported beyond that: the
  * caller reads the file the host way, which produces the reference-visible diagnostic.  Waits for the stream. */
 int  fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint8_t* text, uint64_t text_cap,
                 uint64_t* text_bytes, uint64_t* deflate_bytes, uint32_t* crc32, int32_t* ok);

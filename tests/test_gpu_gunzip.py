@@ -120,6 +120,17 @@ def test_what_does_not_fit_or_is_damaged_is_reported(eng, monkeypatch):
     assert not ok
 
 
+def test_a_long_stretch_without_a_guessable_start_is_left_to_the_host(eng):
+    """Stored blocks only (level 0): no dynamic block to guess, the whole member would be one wave's work.  Up to 32 MiB that is
+    what happens (and the text is right); beyond, the call says "not ok" at once and the caller's host reader takes the file."""
+    small = fastq_text(20000, 6)
+    ok, got, _, crc, _ = device_gunzip(eng, member(small, 0), len(small))
+    assert ok and got == small and crc == zlib.crc32(small) & 0xFFFFFFFF
+    big = small * (-(-(40 << 20) // len(small)))
+    ok, got, _, _, _ = device_gunzip(eng, member(big, 0), len(big))
+    assert not ok and got == b""
+
+
 def test_large_member_is_fast_enough_to_matter(eng):
     """~200 MB of FASTQ text as one member: times the call (a report, not a bar) and checks CRC and length."""
     import time

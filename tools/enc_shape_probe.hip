@@ -1,6 +1,8 @@
-// enc_shape_probe — which feature of the staged encoder's STRUCTURE costs it the distance to the chip's 2:1 ceiling?
-// tools/mix_probe.hip: a bare grid-stride kernel moves the encoder's bytes (150 B in, 72 B out per read) at 7.3-7.5 TB/s;
-// the encoder reaches 5.3-5.7, and round 4's A/Bs say its arithmetic is not why (no packing at all: no faster).  The
+// enc_shape_probe — does any feature of the staged encoder's STRUCTURE cost it bandwidth?
+// tools/mix_probe.hip (the fixed one, profiles/r04_mix_probe.jsonl): a bare grid-stride kernel moves the encoder's traffic mix
+// (150 B in, 72 B out per read) at 4.9-5.05 TB/s; the encoder itself reaches 5.3-5.7, and round 4's A/Bs say its arithmetic is
+// not what bounds it (no packing at all: 0.15 ms).  (This header first quoted 7.3-7.5 TB/s for the bare kernel: the
+// mix probe's first run, whose compiler had removed half the loads.)  The
 // variants below move exactly the encoder's bytes — a workgroup takes tiles of 256 reads = 38400 contiguous bytes, writes
 // 16 KiB of "keys" and 2 KiB of "hashes" per tile — and add its structure one piece at a time:
 //   0  registers only: 16-byte loads (BATCH in flight per lane), xor, 16-byte key stores, 8-byte hash stores; no LDS

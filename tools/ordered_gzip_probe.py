@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--reads", type=int, default=30_000_000)
     ap.add_argument("--dir", default="/dev/shm/fqd_og")
     ap.add_argument("--quick", action="store_true", help="host reader: the default and zlib only")
+    ap.add_argument("--rocprof", default="", help="directory for a rocprofv3 --kernel-trace --stats run of the device path")
+    ap.add_argument("--out-gz", action="store_true", help="write out.fq.gz (deflated on the GPU in the resident run) instead of a plain file")
     a = ap.parse_args()
     import numpy as np
     from fastq_dupaway_amd import _lib
@@ -47,20 +49,29 @@ def main():
     print(f"{plain.stat().st_size / 1e9:.2f} GB of FASTQ -> {gz.stat().st_size / 1e9:.2f} GB of ordinary gzip", flush=True)
     plain.unlink()
     said = {}
+    sfx = ".gz" if a.out_gz else ""
     # first the default (round 4: the file to HBM as it lies on disk, inflated there by fqd_gunzip), twice, with its stages
     for rep in range(2):
-        out = d / "out_dev.fq"
+        out = d / ("out_dev.fq" + sfx)
         out.unlink(missing_ok=True)
         t0 = time.perf_counter()
         r = subprocess.run([str(_lib.CLI_PATH), "-i", str(gz), "-o", str(out), "--fast", "-v"], capture_output=True, text=True,
-                           env=dict(os.environ, FQD_HOST_TIMING="1", FQD_GUNZIP_TRACE="1" if rep else "0"))
+                           env=dict(os.environ, FQD_HOST_TIMING="1", FQD_GUNZIP_TRACE="1"))
         dt = time.perf_counter() - t0
-        said["device"] = (r.returncode, r.stdout, out.stat().st_size)
+        said["device"] = (r.returncode, r.stdout, 0 if a.out_gz else out.stat().st_size)
         print(f"inflated on the GPU: rc={r.returncode} {dt:.2f} s = {n / dt / 1e6:.2f} M reads/s | {r.stdout.strip()}", flush=True)
-        keep = [l for l in r.stderr.splitlines() if "[host timing]" in l or ("[gunzip" in l and ("member" in l or "units have" in l or "scratch" in l or "decoded again" not in l))]
+        keep = [l for l in r.stderr.splitlines() if "[host timing]" in l or ("[gunzip" in l and "decoded again" not in l)]
         print("\n".join(keep[:60] if rep else keep[:40]), flush=True)
+        print(f"units decoded again from the true boundary: {sum('decoded again' in l for l in r.stderr.splitlines())}", flush=True)
+    if a.rocprof:
+        # one more run under rocprofv3 (the binary itself after `--`): which kernel the time between the stages belongs to
+        out = d / ("out_prof.fq" + sfx)
+        r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", a.rocprof, "-o", "cli", "--output-format", "csv", "--",
+                            str(_lib.CLI_PATH), "-i", str(gz), "-o", str(out), "--fast", "-v"], capture_output=True, text=True)
+        print(f"under rocprofv3: rc={r.returncode} | {r.stdout.strip()[-200:]}", flush=True)
+        out.unlink(missing_ok=True)
     for pg in ("1", "0") if a.quick else ("1", "1:12", "1:16", "1:4", "0"):
-        out = d / f"out{pg[0]}.fq"
+        out = d / (f"out{pg[0]}.fq" + sfx)
         out.unlink(missing_ok=True)
         env = dict(os.environ, FQD_PGZIP=pg[0], FQD_GUNZIP_ORDINARY_DEVICE="0")
         if ":" in pg:
@@ -68,7 +79,7 @@ def main():
         t0 = time.perf_counter()
         r = subprocess.run([str(_lib.CLI_PATH), "-i", str(gz), "-o", str(out), "--fast", "-v"], capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t0
-        said[pg] = (r.returncode, r.stdout, out.stat().st_size)
+        said[pg] = (r.returncode, r.stdout, 0 if a.out_gz else out.stat().st_size)
         print(f"FQD_PGZIP={pg} (reader on/off[:threads]): rc={r.returncode} {dt:.2f} s = {n / dt / 1e6:.2f} M reads/s | {r.stdout.strip()}", flush=True)
     print("same lines and output size:", len(set(said.values())) == 1)
     for f in d.iterdir():

@@ -136,6 +136,7 @@ def load_library():
     L.fqd_bgzf_inflate.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, vp, C.POINTER(u64)]
     L.fqd_bgzf_inflate_async.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, vp, vp]
     L.fqd_gunzip.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), C.POINTER(C.c_int32)]
+    L.fqd_gunzip_arriving.argtypes = [vp, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), C.POINTER(C.c_int32)]
     L.fqd_count_lines.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.fqd_scan_records.argtypes = [vp, vp, u64, u32, u64, vp, vp, vp, vp, vp, C.POINTER(i32)]
     L.fqd_partition_keys.argtypes = [vp, vp, u64, u32, u32, vp, vp, vp]

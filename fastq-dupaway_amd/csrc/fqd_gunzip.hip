@@ -56,14 +56,14 @@ constexpr uint32_t kWave = 64;
 // The first offset of the unit that passes everything is its start.  (First version: every look for every offset as it came,
 // the second one lane at a time — 25 of 168 ms per gigabyte of text; the looks in stages: 5.)
 __global__ __launch_bounds__(kWave)
-void gz_find_starts_kernel(BitIn in, uint64_t unit_bits, uint64_t n_units, uint64_t* __restrict__ start)
+void gz_find_starts_kernel(BitIn in, uint64_t unit_bits, uint64_t first_unit, uint64_t n_units /* one past the last */, uint64_t* __restrict__ start)
 {
     __shared__ uint8_t lens[kWave][320];
     __shared__ uint64_t sifted[2 * kWave], looked[2 * kWave];
     const uint32_t lane = threadIdx.x;
     const uint64_t last_word = ((in.nbits + in.lead) >> 6) + 3u;              // 32 readable bytes lie behind the stream: no word beyond them is asked for
     auto word = [&](uint64_t i) { return in.words[i <= last_word ? i : last_word]; };
-    for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+    for (uint64_t u = first_unit + blockIdx.x; u < n_units; u += gridDim.x) {
         if (u == 0) { if (lane == 0) start[0] = 0; continue; }
         const uint64_t lo = u * unit_bits, hi = lo + unit_bits < in.nbits ? lo + unit_bits : in.nbits;
         uint64_t at = ~0ull;
@@ -396,6 +396,12 @@ extern "C" {
 int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint8_t* text, uint64_t text_cap,
                uint64_t* text_bytes, uint64_t* deflate_bytes, uint32_t* crc32, int32_t* ok)
 {
+    return fqd_gunzip_arriving(e, deflate, avail_bytes, nullptr, text, text_cap, text_bytes, deflate_bytes, crc32, ok);
+}
+
+int fqd_gunzip_arriving(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, const volatile uint64_t* arrived, uint8_t* text, uint64_t text_cap,
+                        uint64_t* text_bytes, uint64_t* deflate_bytes, uint32_t* crc32, int32_t* ok)
+{
     if (!e) return FQD_ERR_ARG;
     if (!deflate || !text || !text_bytes || !deflate_bytes || !crc32 || !ok) return fqd_internal_fail(e, FQD_ERR_ARG, "fqd_gunzip: bad arguments");
     *ok = 0; *text_bytes = 0; *deflate_bytes = 0; *crc32 = 0;
@@ -419,57 +425,74 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
     // not (zlib ends a block every 16 K codes: some 20-50 KB packed).  (Measured and replaced on the way here, DESIGN §3b: one
     // serial decoder per wave writing 16-bit symbols, all lanes running it alike — 4.6 GB/s of text; the same, one decoder per
     // LANE with its tables in HBM — 2.6 GB/s: lanes of a wave that copy matches of different lengths wait for the longest.)
-    uint64_t unit_bytes = std::min<uint64_t>(512u << 10, std::max<uint64_t>(64u << 10, (avail_bytes / 8192u + 4095u) & ~uint64_t(4095)));
+    // Large files: some 16 K units of at most 256 KiB — a unit that has to be decoded again is ONE wave's work (11 MB/s of packed bytes
+    // when it runs alone), the chip's 4096 decoders are filled in whole rounds, and the windows' chain costs 2 us a unit.
+    uint64_t unit_bytes = std::min<uint64_t>(256u << 10, std::max<uint64_t>(64u << 10, (avail_bytes / 16384u + 4095u) & ~uint64_t(4095)));
     if (const char* v = std::getenv("FQD_GUNZIP_UNIT_KB")) { const long kb = std::atol(v); if (kb > 0) unit_bytes = uint64_t(kb) << 10; }
     uint64_t ratio = 8;                                                      // symbols of room per compressed byte (FASTQ packs 3-6 fold)
     if (const char* v = std::getenv("FQD_GUNZIP_RATIO")) { const long r = std::atol(v); if (r > 0) ratio = uint64_t(r); }
     const uint64_t n_nominal = (avail_bytes + unit_bytes - 1) / unit_bytes;
 
-    // ---- 1. starts
+    // ---- 1. starts, and the units they make — of what has ARRIVED (fqd_gunzip_arriving: the file is still being copied to HBM
+    // by another thread of the caller, which raises *arrived as its copies complete; everything below works on what is there
+    // and waits for the rest, so that block starts are found and units decoded under the read)
+    auto have_now = [&]() -> uint64_t { if (!arrived) return avail_bytes; const uint64_t a = *arrived; return a < avail_bytes ? a : (a == ~0ull ? ~0ull : avail_bytes); };
     DevMem d_start;
     GZ_TRY(e, d_start.get(n_nominal * 8));
-    hipLaunchKernelGGL(gz_find_starts_kernel, dim3(uint32_t(std::min<uint64_t>(n_nominal, uint64_t(n_cu) * 16u))), dim3(kWave), 0, stream,
-                       in, unit_bytes * 8u, n_nominal, d_start.as<uint64_t>());
-    GZ_TRY(e, hipGetLastError());
-    GZ_TRACE("%llu bytes, %llu units of %llu bytes: looking for block starts", (unsigned long long)avail_bytes, (unsigned long long)n_nominal, (unsigned long long)unit_bytes);
-    std::vector<uint64_t> start(n_nominal);
-    GZ_TRY(e, hipMemcpyAsync(start.data(), d_start.p, n_nominal * 8, hipMemcpyDeviceToHost, stream));
-    GZ_TRY(e, hipStreamSynchronize(stream));
+    std::vector<uint64_t> start(n_nominal, ~0ull);
     std::vector<UnitIn> units;
-    for (uint64_t u = 0; u < n_nominal; ++u) {
-        if (start[u] == ~0ull) continue;
-        uint64_t next = u + 1;
-        while (next < n_nominal && start[next] == ~0ull) ++next;             // a unit without a start belongs to the one before it
-        UnitIn x;
-        x.start_bit = start[u];
-        x.stop_bit = next < n_nominal ? next * unit_bytes * 8u : ~0ull;
-        // room: `ratio` bytes of text per compressed byte of the unit's stretch — and of one unit more: a unit that is decoded again
-        // from the boundary the unit before it REALLY ended at (a member that ends early in that unit) starts that much earlier
-        x.cap = ((next - u + 1u) * unit_bytes * ratio + 1024u + 15u) & ~uint64_t(15);
-        x.at = 0;
-        units.push_back(x);
-        // a long stretch without a dynamic block's start (stored or fixed blocks only: nothing a sequencer or gzip writes for FASTQ)
-        // would be ONE wave's work at some 30 MB/s: beyond 32 MiB the host reader is the faster way, and the caller takes it
-        if ((next - u) * unit_bytes > (uint64_t(32) << 20)) { GZ_TRACE("%llu bytes without a block start that can be guessed: left to the host reader", (unsigned long long)((next - u) * unit_bytes)); return FQD_OK; }
-    }
+    uint64_t searched = 0, built = 0;                                         // nominal units looked at for a start / turned into units
+    bool hopeless = false;
+    auto take_in = [&](uint64_t have) -> int {
+        // a unit is looked at when it and what the looks read beyond a position (a block header: some hundred bytes) have arrived
+        const uint64_t can = have == avail_bytes ? n_nominal : (have > 4096u ? (have - 4096u) / unit_bytes : 0u);
+        if (can > searched) {
+            hipLaunchKernelGGL(gz_find_starts_kernel, dim3(uint32_t(std::min<uint64_t>(can - searched, uint64_t(n_cu) * 16u))), dim3(kWave), 0, stream,
+                               in, unit_bytes * 8u, searched, can, d_start.as<uint64_t>());
+            GZ_TRY(e, hipGetLastError());
+            GZ_TRY(e, hipMemcpyAsync(start.data() + searched, d_start.as<uint64_t>() + searched, (can - searched) * 8, hipMemcpyDeviceToHost, stream));
+            GZ_TRY(e, hipStreamSynchronize(stream));
+            GZ_TRACE("%llu of %llu bytes there: block starts of units %llu to %llu looked for", (unsigned long long)have, (unsigned long long)avail_bytes,
+                     (unsigned long long)searched, (unsigned long long)can);
+            searched = can;
+        }
+        while (built < searched) {
+            if (start[built] == ~0ull) { ++built; continue; }
+            uint64_t next = built + 1;
+            while (next < searched && start[next] == ~0ull) ++next;          // a unit without a start belongs to the one before it
+            // a long stretch without a dynamic block's start (stored or fixed blocks only: nothing a sequencer or gzip writes for FASTQ)
+            // would be ONE wave's work at some 30 MB/s: beyond 32 MiB the host reader is the faster way, and the caller takes it
+            if ((next - built) * unit_bytes > (uint64_t(32) << 20)) {
+                GZ_TRACE("%llu bytes without a block start that can be guessed: left to the host reader", (unsigned long long)((next - built) * unit_bytes));
+                hopeless = true; return FQD_OK;
+            }
+            if (next == searched && searched < n_nominal) break;             // where this unit stops is not known yet
+            UnitIn x;
+            x.start_bit = start[built];
+            x.stop_bit = next < n_nominal ? next * unit_bytes * 8u : ~0ull;
+            // room: `ratio` bytes of text per compressed byte of the unit's stretch — and of one unit more: a unit that is decoded again
+            // from the boundary the unit before it REALLY ended at (a member that ends early in that unit) starts that much earlier
+            x.cap = ((next - built + 1u) * unit_bytes * ratio + 1024u + 15u) & ~uint64_t(15);
+            x.at = 0;
+            units.push_back(x);
+            built = next;
+        }
+        return FQD_OK;
+    };
 
-    GZ_TRACE("%zu units have a start", units.size());
     // ---- 2-5 in batches of units whose two planes fit the scratch
     uint64_t plane_bytes = uint64_t(8) << 30;                                // per plane
     if (const char* v = std::getenv("FQD_GUNZIP_SCRATCH_MB")) { const long mb = std::atol(v); if (mb > 0) plane_bytes = (uint64_t(mb) << 20) / 2; }
     auto room_of = [](const UnitIn& x) { return uint64_t(kWindow) + x.cap + 64u; };          // made-up window, text, slack (a multiple of 16)
-    {
-        uint64_t largest = 0, all = 0;
-        for (const UnitIn& x : units) { largest = std::max(largest, room_of(x)); all += room_of(x); }
-        plane_bytes = std::min(std::max(plane_bytes, largest), all);
-    }
+    plane_bytes = std::min(plane_bytes, n_nominal * (uint64_t(kWindow) + 2u * unit_bytes * ratio + 1024u + 15u + 64u));     // (never more than all units need)
     DevMem d_p, d_q, d_units, d_result, d_text_at, d_windows, d_counter, d_tokens, d_maps;
     GZ_TRY(e, d_p.get(plane_bytes + 64));
     GZ_TRY(e, d_q.get(plane_bytes + 64));
     GZ_TRY(e, d_counter.get(64));
-    const uint32_t decoders = uint32_t(std::min<uint64_t>(2u * units.size(), uint64_t(n_cu) * 16u));    // 10 KB of LDS, <= 128 VGPRs: sixteen waves a CU
+    const uint32_t decoders = uint32_t(std::min<uint64_t>(2u * n_nominal, uint64_t(n_cu) * 16u));      // 10 KB of LDS, <= 128 VGPRs: sixteen waves a CU
     GZ_TRY(e, d_tokens.get(size_t(decoders) * fqd::winf::kTokenRoom * sizeof(fqd::winf::Token)));
-    GZ_TRACE("scratch allocated: 2 planes of %llu bytes, %u decoders' tokens", (unsigned long long)plane_bytes, decoders);
+    GZ_TRACE("%llu bytes, %llu units of %llu bytes; scratch: 2 planes of %llu bytes, %u decoders' tokens", (unsigned long long)avail_bytes, (unsigned long long)n_nominal,
+             (unsigned long long)unit_bytes, (unsigned long long)plane_bytes, decoders);
     struct Member { uint64_t text_from, text_to, deflate_end; uint32_t crc, isize; };
     std::vector<Member> members;
     uint64_t member_from = 0;
@@ -479,6 +502,9 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
     std::vector<UnitOut> result;
     std::vector<uint64_t> text_at;
     size_t at = 0;
+    uint64_t have = 0;                                                        // bytes of the stream a batch may count on
+    bool member_end_before = false;                                           // the unit the chain took last ended a member
+    bool all_there = false;
     // What follows a member's final block: its trailer (CRC-32, ISIZE) and the end of the file, or the header of another member (RFC 1952).
     struct Trailer { uint32_t crc = 0, isize = 0; int kind = 0; /* 0 neither, 1 the file ends, 2 another member */ uint64_t next_start = 0; };
     std::unordered_map<uint64_t, Trailer> trailers;                          // by byte offset: looked at twice (below), fetched once
@@ -512,26 +538,65 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
     auto decode = [&](uint32_t first, uint32_t count) -> int {              // units [first, first + count) of the batch, both planes
         GZ_TRY(e, hipMemsetAsync(d_counter.p, 0, 64, stream));
         hipLaunchKernelGGL(gz_decode_planes_kernel, dim3(std::min<uint32_t>(2u * count, decoders)), dim3(kWave), 0, stream,
-                           deflate, avail_bytes, d_units.as<const UnitIn>() + first, count, d_p.as<uint8_t>(), d_q.as<uint8_t>(),
+                           deflate, have, d_units.as<const UnitIn>() + first, count, d_p.as<uint8_t>(), d_q.as<uint8_t>(),
                            d_tokens.as<fqd::winf::Token>(), d_result.as<UnitOut>() + 2u * first, d_counter.as<uint32_t>());
         GZ_TRY(e, hipGetLastError());
         GZ_TRY(e, hipMemcpyAsync(result.data() + 2u * first, d_result.as<UnitOut>() + 2u * first, 2u * count * sizeof(UnitOut), hipMemcpyDeviceToHost, stream));
         GZ_TRY(e, hipStreamSynchronize(stream));
         return FQD_OK;
     };
-    while (at < units.size() && good && !final_seen) {
+    // what lies behind a final block (trailer, perhaps a header of up to a kilobyte) can be looked at
+    auto trailer_there = [&](uint64_t end_bit) { return all_there || (end_bit + 7u) / 8u + 8u + 1024u <= have; };
+    uint64_t wait_beyond = 0;                                                // nothing to do until more than this has arrived
+    while (good && !final_seen) {
+        have = have_now();
+        if (have == ~0ull) { GZ_TRACE("the caller says the rest of the file will not come"); good = false; break; }
+        all_there = have == avail_bytes;
+        if (!all_there && have <= wait_beyond) { ::usleep(100); continue; }
+        int rc = take_in(have);
+        if (rc) return rc;
+        if (hopeless) return FQD_OK;
+        // units that can be decoded with what is there: a unit reads on to the first block boundary behind its stop — a unit of slack
+        size_t ready = at;
+        while (ready < units.size() && (all_there || (units[ready].stop_bit != ~0ull && units[ready].stop_bit / 8u + unit_bytes <= have))) ++ready;
+        if (ready == at) {
+            if (!all_there) { wait_beyond = have; continue; }
+            if (expect_start / 8u + 2u >= avail_bytes) break;                // (no final block's end was seen: not ok)
+            // members go on behind the last unit that had a start: the rest of the file as one more unit, from where the chain stands
+            UnitIn x;
+            x.start_bit = expect_start; x.stop_bit = ~0ull; x.at = 0;
+            x.cap = ((avail_bytes - expect_start / 8u) * ratio + 1024u + 15u) & ~uint64_t(15);
+            if ((avail_bytes - expect_start / 8u) > (uint64_t(32) << 20)) return FQD_OK;
+            units.push_back(x);
+            ready = units.size();
+        }
+        // a batch: what the planes hold — less some room for units put in between (below) — and, when there are that many, whole
+        // rounds of the decoders (two items a unit): a round that fills a sixth of the chip takes as long as one that fills it
+        const uint64_t one_more = uint64_t(kWindow) + ((2u * unit_bytes * ratio + 1024u + 15u) & ~uint64_t(15)) + 64u;
+        const uint64_t spare = std::min<uint64_t>(plane_bytes / 8u, 24u * one_more);
         size_t hi = at; uint64_t used = 0;
-        while (hi < units.size() && used + room_of(units[hi]) <= plane_bytes) { units[hi].at = used; used += room_of(units[hi]); ++hi; }
-        const uint32_t nb = uint32_t(hi - at);
-        if (nb == 0) { good = false; break; }
-        GZ_TRY(e, d_units.get(nb * sizeof(UnitIn)));
-        GZ_TRY(e, d_result.get(2u * nb * sizeof(UnitOut)));
-        GZ_TRY(e, d_text_at.get(nb * 8));
-        GZ_TRY(e, d_windows.get(uint64_t(nb + 1u) * kWindow));
+        while (hi < ready && used + room_of(units[hi]) <= plane_bytes - spare) { units[hi].at = used; used += room_of(units[hi]); ++hi; }
+        if (const size_t round = decoders / 2u; hi - at > round && (hi < ready || !all_there)) {
+            hi = at + (hi - at) / round * round;
+            used = units[hi - 1].at + room_of(units[hi - 1]);
+        }
+        if (hi == at) {
+            // one unit that needs more than a plane holds (FQD_GUNZIP_SCRATCH_MB set small, a long stretch): the planes grow
+            plane_bytes = room_of(units[at]) + room_of(units[at]) / 4u;
+            GZ_TRY(e, hipStreamSynchronize(stream));
+            GZ_TRY(e, d_p.get(plane_bytes + 64));
+            GZ_TRY(e, d_q.get(plane_bytes + 64));
+            continue;
+        }
+        uint32_t nb = uint32_t(hi - at);                                      // (up to 24 units may be put in between, below)
+        GZ_TRY(e, d_units.get((nb + 24u) * sizeof(UnitIn)));
+        GZ_TRY(e, d_result.get(2u * (nb + 24u) * sizeof(UnitOut)));
+        GZ_TRY(e, d_text_at.get((nb + 24u) * 8));
+        GZ_TRY(e, d_windows.get(uint64_t(nb + 25u) * kWindow));
         GZ_TRY(e, hipMemcpyAsync(d_units.p, units.data() + at, nb * sizeof(UnitIn), hipMemcpyHostToDevice, stream));
         result.resize(2u * nb);
         GZ_TRACE("batch of %u units queued for decoding (%llu bytes a plane)", nb, (unsigned long long)used);
-        int rc = decode(0, nb);
+        rc = decode(0, nb);
         if (rc) return rc;
         GZ_TRACE("decoded: first unit status %u, %llu bytes, end bit %llu", result[0].status, (unsigned long long)result[0].n, (unsigned long long)result[0].end_bit);
         // ---- 3. the chain
@@ -542,25 +607,40 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
         // boundaries of one stream), and decoded again in ONE launch; the chain below then checks every link and mends, one unit
         // at a time, what that assumption missed.  (One launch per unit: 13 ms each, 90 of the 188 ms of a 12-member file.)
         {
-            std::vector<uint32_t> again;
-            uint64_t expect = expect_start;
+            // A unit behind a member's end is not decoded again as a whole: the stretch from the new member's first block to the unit's
+            // nominal start becomes a unit of its own, PUT IN before it (room for it at the planes' end), and the unit keeps what it
+            // decoded from its own guess — on average a quarter of the work, and it grows with the unit no more.
+            std::vector<uint32_t> again;                                     // positions in the batch
+            std::vector<UnitIn> put_in;                                      // .cap == 0: decoded again where it is
+            uint64_t expect = expect_start, spare_at = used;
+            bool behind_member_end = member_end_before;
             for (uint32_t k = 0; k < nb; ++k) {
                 UnitIn& x = units[at + k];
-                if (x.start_bit != expect) { x.start_bit = expect; again.push_back(k); }
+                if (x.start_bit != expect) {
+                    const uint64_t nominal = at + k > 0 ? units[at + k - 1].stop_bit : ~0ull;      // where this unit's share of the stream begins
+                    UnitIn y{0, 0, 0, 0};
+                    if (behind_member_end && nominal != ~0ull && expect < nominal && x.start_bit >= nominal && put_in.size() < 24u &&
+                        spare_at + one_more <= plane_bytes && std::count_if(put_in.begin(), put_in.end(), [](const UnitIn& u) { return u.cap != 0; }) < 24) {
+                        y.start_bit = expect; y.stop_bit = nominal; y.at = spare_at; y.cap = one_more - kWindow - 64u;
+                        spare_at += one_more;
+                    } else x.start_bit = expect;
+                    again.push_back(k); put_in.push_back(y);
+                }
                 const UnitOut& r = result[2u * k]; const UnitOut& r2 = result[2u * k + 1u];
                 if (r.status != fqd::winf::kOk || r2.status != fqd::winf::kOk || r.end_bit != r2.end_bit || r.how != r2.how) break;   // garbage from a wrong guess: the chain takes over here
                 if (r.how == 2u) {
+                    if (!trailer_there(r.end_bit)) break;
                     Trailer t;
                     if ((rc = trailer_at(r.end_bit, t))) return rc;
                     if (t.kind != 2) break;
-                    expect = t.next_start;
-                } else expect = r.end_bit;
+                    expect = t.next_start; behind_member_end = true;
+                } else { expect = r.end_bit; behind_member_end = false; }
             }
             if (!again.empty()) {
                 repairs += again.size();
                 if (repairs > 64u + units.size() / 16u) { GZ_TRACE("%llu units do not start where the one before them ended: giving up", (unsigned long long)repairs); good = false; break; }
                 std::vector<UnitIn> ru(again.size());
-                for (size_t i = 0; i < again.size(); ++i) ru[i] = units[at + again[i]];
+                for (size_t i = 0; i < again.size(); ++i) ru[i] = put_in[i].cap ? put_in[i] : units[at + again[i]];
                 std::vector<UnitOut> rr(2u * again.size());
                 DevMem d_ru, d_rr;
                 GZ_TRY(e, d_ru.get(ru.size() * sizeof(UnitIn)));
@@ -568,19 +648,30 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
                 GZ_TRY(e, hipMemcpyAsync(d_ru.p, ru.data(), ru.size() * sizeof(UnitIn), hipMemcpyHostToDevice, stream));
                 GZ_TRY(e, hipMemsetAsync(d_counter.p, 0, 64, stream));
                 hipLaunchKernelGGL(gz_decode_planes_kernel, dim3(std::min<uint32_t>(2u * uint32_t(ru.size()), decoders)), dim3(kWave), 0, stream,
-                                   deflate, avail_bytes, d_ru.as<const UnitIn>(), uint32_t(ru.size()), d_p.as<uint8_t>(), d_q.as<uint8_t>(),
+                                   deflate, have, d_ru.as<const UnitIn>(), uint32_t(ru.size()), d_p.as<uint8_t>(), d_q.as<uint8_t>(),
                                    d_tokens.as<fqd::winf::Token>(), d_rr.as<UnitOut>(), d_counter.as<uint32_t>());
                 GZ_TRY(e, hipGetLastError());
                 GZ_TRY(e, hipMemcpyAsync(rr.data(), d_rr.p, rr.size() * sizeof(UnitOut), hipMemcpyDeviceToHost, stream));
                 GZ_TRY(e, hipStreamSynchronize(stream));
-                for (size_t i = 0; i < again.size(); ++i) { result[2u * again[i]] = rr[2u * i]; result[2u * again[i] + 1u] = rr[2u * i + 1u]; }
+                uint32_t more = 0;
+                for (size_t i = again.size(); i-- > 0;) {                     // from the back: positions before it stay what they are
+                    const uint32_t k = again[i];
+                    if (put_in[i].cap) {
+                        units.insert(units.begin() + std::ptrdiff_t(at + k), put_in[i]);
+                        result.insert(result.begin() + std::ptrdiff_t(2u * k), {rr[2u * i], rr[2u * i + 1u]});
+                        ++more;
+                    } else { result[2u * k] = rr[2u * i]; result[2u * k + 1u] = rr[2u * i + 1u]; }
+                }
+                nb += more; hi += more;
                 GZ_TRY(e, hipMemcpyAsync(d_units.p, units.data() + at, nb * sizeof(UnitIn), hipMemcpyHostToDevice, stream));
                 GZ_TRY(e, hipMemcpyAsync(d_result.p, result.data(), 2u * nb * sizeof(UnitOut), hipMemcpyHostToDevice, stream));
-                GZ_TRACE("%zu units decoded again in one launch, each from where the unit before it ended", again.size());
+                GZ_TRACE("%zu units decoded again in one launch, each from where the unit before it ended (%u of them the short stretch behind a member's end, put in as a unit)",
+                         again.size(), more);
             }
         }
         text_at.resize(nb);
         uint32_t live = 0;
+        bool put_off = false;                                                 // a unit that needs bytes that have not arrived: it and what follows wait
         for (uint32_t k = 0; k < nb && good && !final_seen; ++k) {
             UnitIn& x = units[at + k];
             if (x.start_bit != expect_start) {
@@ -593,14 +684,17 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
             }
             const UnitOut& r = result[2u * k]; const UnitOut& r2 = result[2u * k + 1u];
             if (r.status != fqd::winf::kOk || r2.status != fqd::winf::kOk || r.end_bit != r2.end_bit || r.n != r2.n || r.how != r2.how) {
+                if (!all_there) { put_off = true; break; }                    // (it may have run into what has not arrived: once more when there is more)
                 GZ_TRACE("unit %zu (from bit %llu, room %llu): status %u / %u, %llu / %llu bytes: giving up", at + k, (unsigned long long)x.start_bit, (unsigned long long)x.cap,
                          r.status, r2.status, (unsigned long long)r.n, (unsigned long long)r2.n);
                 good = false; break;
             }
+            if (r.how == 2u && !trailer_there(r.end_bit)) { put_off = true; break; }
             if (total + r.n > text_cap) { GZ_TRACE("the text outgrows the room given (%llu bytes)", (unsigned long long)text_cap); good = false; break; }
             text_at[k] = total; total += r.n;
             expect_start = r.end_bit;
             live = k + 1;
+            member_end_before = r.how == 2u;
             if (r.how == 2u) {
                 // the member's final block ended here: its trailer follows at the next byte, and — `cat a.gz b.gz`, or a writer that
                 // starts a member every so often — perhaps another member, whose first block the next unit is then decoded from
@@ -617,6 +711,8 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
             }
         }
         if (!good) break;
+        if (put_off) { GZ_TRACE("unit %zu waits for bytes that have not arrived (%llu there)", at + live, (unsigned long long)have); wait_beyond = have; }
+        if (live == 0) continue;
         // ---- 4, 5
         GZ_TRY(e, hipMemcpyAsync(d_text_at.p, text_at.data(), live * 8, hipMemcpyHostToDevice, stream));
         GZ_TRY(e, hipMemcpyAsync(d_windows.p, carry.data(), kWindow, hipMemcpyHostToDevice, stream));
@@ -635,14 +731,6 @@ int fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint
         GZ_TRY(e, hipStreamSynchronize(stream));
         GZ_TRACE("windows and bytes of %u units done, %llu bytes of text so far", live, (unsigned long long)total);
         at = at + live < hi && final_seen ? hi : at + live;                  // (units of the batch behind a repair that were not reached are decoded with the next batch)
-        if (at == units.size() && !final_seen && expect_start / 8u + 2u < avail_bytes) {
-            // members go on behind the last unit that had a start: the rest of the file as one more unit, from where the chain stands
-            UnitIn x;
-            x.start_bit = expect_start; x.stop_bit = ~0ull; x.at = 0;
-            x.cap = ((avail_bytes - expect_start / 8u) * ratio + 1024u + 15u) & ~uint64_t(15);
-            if (room_of(x) > plane_bytes) { good = false; break; }
-            units.push_back(x);
-        }
     }
     if (!good || !final_seen) return FQD_OK;                                  // *ok stays 0: the caller reads the file the host way
 

@@ -273,11 +273,16 @@ class Engine:
                                              self._p(crc), n_members, self._p(text), C.byref(bad)))
         return int(bad.value)
 
-    def gunzip(self, deflate, avail: int, text):
+    def gunzip(self, deflate, avail: int, text, arrived=None):
         """An ordinary gzip member's deflate stream (device bytes from its first byte on) inflated into text (device); returns
-        (ok, text_bytes, deflate_bytes, crc32)."""
+        (ok, text_bytes, deflate_bytes, crc32).  arrived: a ctypes.c_uint64 another thread raises while it copies the file into
+        `deflate` (fqd_gunzip_arriving: the call works on what is there and waits for the rest)."""
         tb, db, crc, ok = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0), C.c_int32(0)
-        self._check(self._L.fqd_gunzip(self._h, self._p(deflate), avail, self._p(text), text.numel(), C.byref(tb), C.byref(db), C.byref(crc), C.byref(ok)))
+        if arrived is None:
+            self._check(self._L.fqd_gunzip(self._h, self._p(deflate), avail, self._p(text), text.numel(), C.byref(tb), C.byref(db), C.byref(crc), C.byref(ok)))
+        else:
+            self._check(self._L.fqd_gunzip_arriving(self._h, self._p(deflate), avail, C.byref(arrived), self._p(text), text.numel(),
+                                                    C.byref(tb), C.byref(db), C.byref(crc), C.byref(ok)))
         return bool(ok.value), int(tb.value), int(db.value), int(crc.value)
 
     def count_lines(self, text, n: int) -> int:

@@ -293,7 +293,7 @@ size_t InputFile::read(char* dst, size_t n, unsigned threads)
         return got;
     }
     if (bgzf_) return read_bgzf(dst, n, threads);
-    constexpr size_t kMinPart = 16u << 20;
+    static const size_t kMinPart = [] { const char* v = std::getenv("FQD_READ_PART_MB"); const long mb = v ? std::atol(v) : 0; return size_t(mb > 0 ? mb : 16) << 20; }();   // bytes per reading thread
     if (!gz_ && regular_ && threads > 1 && n >= 2 * kMinPart && !eof_) {
         const size_t want = static_cast<size_t>(std::min<uint64_t>(n, size_ > offset_ ? size_ - offset_ : 0));
         const unsigned parts = static_cast<unsigned>(std::min<size_t>(threads, std::max<size_t>(1, want / kMinPart)));

@@ -275,61 +275,75 @@ bool fetch_gzip_ordinary(const std::string& name, size_t block_bytes, int device
     static const bool wanted = [] { const char* v = std::getenv("FQD_GUNZIP_ORDINARY_DEVICE"); return !v || std::atoi(v) != 0; }();
     uint64_t size = 0;
     if (!wanted || !has_gz_extension(name) || !is_regular_file(name, size) || size < 28) return false;
+    // the member's header (RFC 1952): magic, method 8, the optional fields; a BGZF file never comes here (fetch_bgzf took it)
+    size_t header = 0;
+    {
+        unsigned char p[1024];
+        std::FILE* peek = std::fopen(name.c_str(), "rb");
+        const size_t got = peek ? std::fread(p, 1, sizeof p, peek) : 0;
+        if (peek) std::fclose(peek);
+        if (got < 18 || p[0] != 31 || p[1] != 139 || p[2] != 8 || (p[3] & 0xE0)) return false;
+        size_t h = 10;
+        if (p[3] & 4) { if (h + 2 > got) return false; h += 2 + (p[h] | (size_t(p[h + 1]) << 8)); }
+        if (p[3] & 8) { while (h < got && p[h]) ++h; ++h; }
+        if (p[3] & 16) { while (h < got && p[h]) ++h; ++h; }
+        if (p[3] & 2) h += 2;
+        if (h + 10 > got || h + 10 > size) return false;
+        header = h;
+    }
     InputFile file(name, true);
     HIP_OK(hipSetDevice(device));
-    hipStream_t up = nullptr;
+    hipStream_t up = nullptr, work = nullptr;
     HIP_OK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
-    struct Guard { hipStream_t s; ~Guard() { (void)hipStreamDestroy(s); } } g{up};
-    Pinned<char> block[2];
-    block[0].reserve(block_bytes); block[1].reserve(block_bytes);
+    struct Guard { hipStream_t& s; ~Guard() { if (s) (void)hipStreamDestroy(s); } } g{up}, gw{work};
+    HIP_OK(hipStreamCreateWithFlags(&work, hipStreamNonBlocking));
     Device<char> comp;
     comp.reserve(size + 64);
     HIP_OK(hipMemsetAsync(comp.p + size, 0, 64, up));
-    uint64_t at = 0;
-    size_t header = 0;
-    unsigned char tail[8] = {0};
-    std::unique_ptr<StageClock::Scope> reading(new StageClock::Scope("  ordinary gzip: the file read and copied to HBM"));
-    for (int k = 0;; k ^= 1) {                                   // the copy of one block overlaps the read of the next
-        const size_t got = file.read(block[k].p, block_bytes, host_threads());
-        HIP_OK(hipStreamSynchronize(up));                          // the other block's copy
-        if (got == 0) break;
-        if (at + got > size) return false;                         // the file grew under us
-        if (at == 0) {
-            // the member's header (RFC 1952): magic, method 8, the optional fields; a BGZF file never comes here (fetch_bgzf took it)
-            const unsigned char* p = reinterpret_cast<const unsigned char*>(block[k].p);
-            if (got < 18 || p[0] != 31 || p[1] != 139 || p[2] != 8 || (p[3] & 0xE0)) return false;
-            size_t h = 10;
-            if (p[3] & 4) { if (h + 2 > got) return false; h += 2 + (p[h] | (size_t(p[h + 1]) << 8)); }
-            if (p[3] & 8) { while (h < got && p[h]) ++h; ++h; }
-            if (p[3] & 16) { while (h < got && p[h]) ++h; ++h; }
-            if (p[3] & 2) h += 2;
-            if (h + 10 > got) return false;
-            header = h;
+    HIP_OK(hipStreamSynchronize(up));
+    // The inflating runs on a thread of its own WHILE the file is read (fqd_gunzip_arriving): block starts are looked for and units
+    // decoded as their bytes reach HBM; `arrived` is raised here after every block's copy.  Room for the text: ISIZE is its length
+    // modulo 2^32 only and stands at the file's end, so room is what FASTQ at its most packable needs (binned qualities: sevenfold);
+    // a text that outgrows it sends the file to the host reader.
+    const uint64_t room = size * 8u + (64u << 10);
+    alignas(8) volatile uint64_t arrived = 0;
+    struct Outcome { int rc = FQD_OK; uint64_t tb = 0, db = 0; uint32_t crc = 0; int32_t ok = 0; std::string error; std::exception_ptr thrown; } out;
+    std::thread worker([&] {
+        try {
+            HIP_OK(hipSetDevice(device));
+            { StageClock::Scope t("  ordinary gzip: room for the text (under the read)"); f.text.room_for(room + 64, work); }
+            EngineHandle eng(1, device, work);                    // a small engine of this thread's own: the stream and the error slot of the call
+            StageClock::Scope t("  ordinary gzip: inflated on the GPU (fqd_gunzip_arriving, under the read and after it)");
+            out.rc = fqd_gunzip_arriving(eng.e, reinterpret_cast<const uint8_t*>(comp.p) + header, size - header, &arrived,
+                                         reinterpret_cast<uint8_t*>(f.text.p), room, &out.tb, &out.db, &out.crc, &out.ok);
+            if (out.rc != FQD_OK) out.error = fqd_last_error(eng.e);
+        } catch (...) { out.thrown = std::current_exception(); }
+    });
+    struct Join { std::thread& t; volatile uint64_t& arrived; ~Join() { if (t.joinable()) { arrived = ~0ull; t.join(); } } } join{worker, arrived};   // (an early way out: "the rest will not come")
+    Pinned<char> block[2];
+    block[0].reserve(block_bytes); block[1].reserve(block_bytes);
+    uint64_t at = 0, sent[2] = {0, 0};
+    {
+        StageClock::Scope reading("  ordinary gzip: the file read and copied to HBM");
+        for (int k = 0;; k ^= 1) {                                   // the copy of one block overlaps the read of the next
+            const size_t got = file.read(block[k].p, block_bytes, host_threads());
+            HIP_OK(hipStreamSynchronize(up));                          // the other block's copy: those bytes are in HBM now
+            if (sent[k ^ 1] > header) arrived = sent[k ^ 1] - header;
+            if (got == 0) break;
+            if (at + got > size) return false;                         // the file grew under us
+            HIP_OK(hipMemcpyAsync(comp.p + at, block[k].p, got, hipMemcpyHostToDevice, up));
+            at += got;
+            sent[k] = at;
         }
-        // the last eight bytes of the file, wherever the blocks cut it
-        if (at + got + 8 > size)
-            for (size_t i = at + 8 >= size ? 0 : static_cast<size_t>(size - 8 - at); i < got; ++i) tail[at + i + 8 - size] = static_cast<unsigned char>(block[k].p[i]);
-        HIP_OK(hipMemcpyAsync(comp.p + at, block[k].p, got, hipMemcpyHostToDevice, up));
-        at += got;
     }
-    reading.reset();
-    if (at != size || header == 0) return false;
-    const uint32_t want_crc = tail[0] | (uint32_t(tail[1]) << 8) | (uint32_t(tail[2]) << 16) | (uint32_t(tail[3]) << 24);
-    const uint32_t isize = tail[4] | (uint32_t(tail[5]) << 8) | (uint32_t(tail[6]) << 16) | (uint32_t(tail[7]) << 24);
-    // room for the text: ISIZE is its length modulo 2^32 only, so room is what FASTQ at its most packable needs (binned
-    // qualities: sevenfold) and at least what ISIZE says; a text that outgrows it sends the file to the host reader
-    const uint64_t room = std::max<uint64_t>(uint64_t(isize), size * 8u) + (64u << 10);
-    { StageClock::Scope t("  ordinary gzip: room for the text"); f.text.room_for(room + 64, up); }
-    std::unique_ptr<EngineHandle> engine;
-    { StageClock::Scope t("  ordinary gzip: an engine for the call"); engine = std::make_unique<EngineHandle>(1, device, up); }   // a small engine of this thread's own: the stream and the error slot of the call
-    EngineHandle& eng = *engine;
-    uint64_t tb = 0, db = 0; uint32_t crc = 0; int32_t ok = 0;
-    StageClock::Scope t_inflate("  ordinary gzip: inflated on the GPU (fqd_gunzip)");
-    const int rc = fqd_gunzip(eng.e, reinterpret_cast<const uint8_t*>(comp.p) + header, size - header, reinterpret_cast<uint8_t*>(f.text.p), room, &tb, &db, &crc, &ok);
-    if (rc != FQD_OK) throw DeviceError(std::string("GPU engine: ") + fqd_last_error(eng.e));
-    (void)want_crc; (void)isize; (void)crc;                          // (every member's CRC-32 and ISIZE were held against its trailer by the call)
-    if (!ok || header + db + 8 != size) return false;
-    text_bytes = tb;
+    if (at != size) return false;
+    arrived = size - header;
+    { StageClock::Scope t("  ordinary gzip: the rest of the inflating, after the read"); worker.join(); }
+    if (out.thrown) std::rethrow_exception(out.thrown);
+    if (out.rc != FQD_OK) throw DeviceError(std::string("GPU engine: ") + out.error);
+    // (every member's CRC-32 and ISIZE were held against its trailer by the call)
+    if (!out.ok || header + out.db + 8 != size) { f.text.used = 0; return false; }
+    text_bytes = out.tb;
     return true;
 }
 

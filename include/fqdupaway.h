@@ -436,6 +436,13 @@ int  fqd_bgzf_inflate(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_o
  * caller reads the file the host way, which produces the reference-visible diagnostic.  Waits for the stream. */
 int  fqd_gunzip(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, uint8_t* text, uint64_t text_cap,
                 uint64_t* text_bytes, uint64_t* deflate_bytes, uint32_t* crc32, int32_t* ok);
+/* The same for a file that is STILL BEING COPIED to HBM by another thread of the caller: *arrived (host memory) says how many of
+ * the avail_bytes bytes from `deflate` on are in HBM and complete — the caller raises it as its copies finish (after the copy
+ * stream has been waited for), never lowers it, and ends at avail_bytes; ~0 means "the rest will not come" and ends the call
+ * with *ok = 0.  Block starts are looked for and units decoded as their bytes arrive, so that most of the call runs under the
+ * read of the file; the call returns when everything has arrived and been dealt with.  arrived = NULL: everything is there. */
+int  fqd_gunzip_arriving(fqd_engine* e, const uint8_t* deflate, uint64_t avail_bytes, const volatile uint64_t* arrived,
+                         uint8_t* text, uint64_t text_cap, uint64_t* text_bytes, uint64_t* deflate_bytes, uint32_t* crc32, int32_t* ok);
 
 /* The same for one BATCH of members of a file that is still being read: queued on the engine's stream, nothing waited
  * for; bad members are ADDED to the two uint64 at bad_counters (device; zeroed by the caller, read when it likes), so

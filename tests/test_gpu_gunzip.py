@@ -120,6 +120,57 @@ def test_what_does_not_fit_or_is_damaged_is_reported(eng, monkeypatch):
     assert not ok
 
 
+@pytest.mark.parametrize("step,unit_kb", [(50_000, "8"), (333_333, None), (3_000_000, "64")])
+def test_a_file_that_is_still_arriving(eng, monkeypatch, step, unit_kb):
+    """fqd_gunzip_arriving: the packed bytes reach HBM piece by piece from another thread (what lies beyond the mark is garbage
+    until then) while the call runs; the text, the CRC and the end must be those of the plain call — several members, a member
+    end inside a piece, units that wait for bytes that are not there yet.  ~0 in the counter ends the call with ok = 0."""
+    import ctypes
+    import threading
+    import time
+    import torch
+    if unit_kb:
+        monkeypatch.setenv("FQD_GUNZIP_UNIT_KB", unit_kb)
+    parts = [fastq_text(9000, 21), fastq_text(50, 22), fastq_text(14000, 23)]
+    data = b"".join(parts)
+    raw = b"".join(member(p, 6 if k != 1 else 1) for k, p in enumerate(parts))
+    h = header_len(raw)
+    dev = torch.device("cuda", 0)
+    real = torch.frombuffer(bytearray(raw[h:] + b"\0" * 32), dtype=torch.uint8).to(dev)
+    n = len(raw) - h
+    for give_up in (False, True):
+        buf = torch.randint(0, 256, (n + 32,), dtype=torch.uint8, device=dev)          # garbage where nothing has arrived
+        text = torch.full((len(data) + 64,), 0xEE, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        arrived = ctypes.c_uint64(0)
+        side = torch.cuda.Stream(device=dev)
+
+        def feed():
+            at = 0
+            while at < n:
+                hi = min(n, at + step)
+                if give_up and hi > n // 2:
+                    arrived.value = 0xFFFFFFFFFFFFFFFF
+                    return
+                with torch.cuda.stream(side):
+                    buf[at:hi + (32 if hi == n else 0)].copy_(real[at:hi + (32 if hi == n else 0)])
+                side.synchronize()
+                arrived.value = hi
+                at = hi
+                time.sleep(0.002)
+        t = threading.Thread(target=feed)
+        t.start()
+        ok, nb, deflate_bytes, crc = eng.gunzip(buf, n, text[: len(data)], arrived=arrived)
+        t.join()
+        eng.sync()
+        if give_up:
+            assert not ok
+            continue
+        assert ok and nb == len(data) and text[:nb].cpu().numpy().tobytes() == data
+        assert h + deflate_bytes + 8 == len(raw) and crc == zlib.crc32(parts[-1]) & 0xFFFFFFFF
+        assert bool((text[len(data):] == 0xEE).all())
+
+
 def test_a_long_stretch_without_a_guessable_start_is_left_to_the_host(eng):
     """Stored blocks only (level 0): no dynamic block to guess, the whole member would be one wave's work.  Up to 32 MiB that is
     what happens (and the text is right); beyond, the call says "not ok" at once and the caller's host reader takes the file."""

@@ -37,6 +37,7 @@
 FQD_HIDDEN hipStream_t fqd_internal_stream(fqd_engine* e);
 FQD_HIDDEN int fqd_internal_device(fqd_engine* e);
 FQD_HIDDEN int fqd_internal_fail(fqd_engine* e, int code, const char* msg);
+FQD_HIDDEN int fqd_internal_scratch(fqd_engine* e, int which, size_t bytes, void** out);
 
 namespace {
 
@@ -382,10 +383,8 @@ uint32_t advance_zero_bytes(uint32_t reg, uint64_t n)
     return reg;
 }
 
-struct DevMem {
+struct View {                                                                // a piece of the engine's scratch (below)
     void* p = nullptr;
-    ~DevMem() { if (p) (void)hipFree(p); }
-    hipError_t get(size_t bytes) { if (p) { (void)hipFree(p); p = nullptr; } return hipMalloc(&p, bytes ? bytes : 16); }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -433,12 +432,42 @@ int fqd_gunzip_arriving(fqd_engine* e, const uint8_t* deflate, uint64_t avail_by
     if (const char* v = std::getenv("FQD_GUNZIP_RATIO")) { const long r = std::atol(v); if (r > 0) ratio = uint64_t(r); }
     const uint64_t n_nominal = (avail_bytes + unit_bytes - 1) / unit_bytes;
 
+    // ---- 2-5 in batches of units whose two planes fit the scratch: by default TWO rounds of the chip's decoders (two items a unit)
+    const uint64_t one_more = uint64_t(kWindow) + ((2u * unit_bytes * ratio + 1024u + 15u) & ~uint64_t(15)) + 64u;     // the room of a unit of one nominal unit
+    const uint32_t decoders = uint32_t(std::min<uint64_t>(2u * n_nominal, uint64_t(n_cu) * 16u));      // 10 KB of LDS, <= 128 VGPRs: sixteen waves a CU
+    uint64_t plane_bytes = std::min<uint64_t>(uint64_t(8) << 30, (decoders + 64u) * one_more);        // per plane: two rounds (two back to back take 48 ms where one takes 30)
+    if (const char* v = std::getenv("FQD_GUNZIP_SCRATCH_MB")) { const long mb = std::atol(v); if (mb > 0) plane_bytes = (uint64_t(mb) << 20) / 2; }
+    auto room_of = [](const UnitIn& x) { return uint64_t(kWindow) + x.cap + 64u; };          // made-up window, text, slack (a multiple of 16)
+    plane_bytes = std::min(plane_bytes, n_nominal * one_more + 64u * one_more);                       // (never more than all units need)
+    // ONE piece of the engine's scratch holds everything the call needs on the device, and stays with the engine: a call that
+    // frees gigabytes hands them to the driver for clearing, and the process's next hipMalloc — the dedup engine's key store, the
+    // other file's planes — waits for that (configs[4] shape, two files at once: a second lost in whatever stage came next).
+    View d_start, d_p, d_q, d_units, d_result, d_text_at, d_windows, d_counter, d_tokens, d_maps, d_ru, d_rr, d_shift, d_raw;
+    uint64_t nb_cap = 0;                                                      // units a batch can hold
+    auto place = [&]() -> int {
+        nb_cap = plane_bytes / one_more + 32u;
+        size_t o = 0;
+        auto take = [&](size_t bytes) { const size_t at_o = o; o = (o + bytes + 255u) & ~size_t(255); return at_o; };
+        const size_t o_p = take(plane_bytes + 64), o_q = take(plane_bytes + 64);
+        const size_t o_tok = take(size_t(decoders) * fqd::winf::kTokenRoom * sizeof(fqd::winf::Token));
+        const size_t o_maps = take(nb_cap * kWindow * 2u), o_win = take((nb_cap + 1u) * kWindow);
+        const size_t o_units = take(nb_cap * sizeof(UnitIn)), o_res = take(2u * nb_cap * sizeof(UnitOut)), o_at = take(nb_cap * 8u);
+        const size_t o_ru = take(nb_cap * sizeof(UnitIn)), o_rr = take(2u * nb_cap * sizeof(UnitOut));
+        const size_t o_cnt = take(64), o_start = take(n_nominal * 8u), o_shift = take(8 * 32 * 4), o_raw = take((text_cap / kSlice + 2u) * 4u);
+        void* base = nullptr;
+        const int rc_s = fqd_internal_scratch(e, 1, o, &base);
+        if (rc_s != FQD_OK) return rc_s;
+        uint8_t* b8 = static_cast<uint8_t*>(base);
+        d_p.p = b8 + o_p; d_q.p = b8 + o_q; d_tokens.p = b8 + o_tok; d_maps.p = b8 + o_maps; d_windows.p = b8 + o_win;
+        d_units.p = b8 + o_units; d_result.p = b8 + o_res; d_text_at.p = b8 + o_at; d_ru.p = b8 + o_ru; d_rr.p = b8 + o_rr;
+        d_counter.p = b8 + o_cnt; d_start.p = b8 + o_start; d_shift.p = b8 + o_shift; d_raw.p = b8 + o_raw;
+        return FQD_OK;
+    };
+    { const int rc_p = place(); if (rc_p != FQD_OK) return rc_p; }
     // ---- 1. starts, and the units they make — of what has ARRIVED (fqd_gunzip_arriving: the file is still being copied to HBM
     // by another thread of the caller, which raises *arrived as its copies complete; everything below works on what is there
     // and waits for the rest, so that block starts are found and units decoded under the read)
     auto have_now = [&]() -> uint64_t { if (!arrived) return avail_bytes; const uint64_t a = *arrived; return a < avail_bytes ? a : (a == ~0ull ? ~0ull : avail_bytes); };
-    DevMem d_start;
-    GZ_TRY(e, d_start.get(n_nominal * 8));
     std::vector<uint64_t> start(n_nominal, ~0ull);
     std::vector<UnitIn> units;
     uint64_t searched = 0, built = 0;                                         // nominal units looked at for a start / turned into units
@@ -480,17 +509,6 @@ int fqd_gunzip_arriving(fqd_engine* e, const uint8_t* deflate, uint64_t avail_by
         return FQD_OK;
     };
 
-    // ---- 2-5 in batches of units whose two planes fit the scratch
-    uint64_t plane_bytes = uint64_t(8) << 30;                                // per plane
-    if (const char* v = std::getenv("FQD_GUNZIP_SCRATCH_MB")) { const long mb = std::atol(v); if (mb > 0) plane_bytes = (uint64_t(mb) << 20) / 2; }
-    auto room_of = [](const UnitIn& x) { return uint64_t(kWindow) + x.cap + 64u; };          // made-up window, text, slack (a multiple of 16)
-    plane_bytes = std::min(plane_bytes, n_nominal * (uint64_t(kWindow) + 2u * unit_bytes * ratio + 1024u + 15u + 64u));     // (never more than all units need)
-    DevMem d_p, d_q, d_units, d_result, d_text_at, d_windows, d_counter, d_tokens, d_maps;
-    GZ_TRY(e, d_p.get(plane_bytes + 64));
-    GZ_TRY(e, d_q.get(plane_bytes + 64));
-    GZ_TRY(e, d_counter.get(64));
-    const uint32_t decoders = uint32_t(std::min<uint64_t>(2u * n_nominal, uint64_t(n_cu) * 16u));      // 10 KB of LDS, <= 128 VGPRs: sixteen waves a CU
-    GZ_TRY(e, d_tokens.get(size_t(decoders) * fqd::winf::kTokenRoom * sizeof(fqd::winf::Token)));
     GZ_TRACE("%llu bytes, %llu units of %llu bytes; scratch: 2 planes of %llu bytes, %u decoders' tokens", (unsigned long long)avail_bytes, (unsigned long long)n_nominal,
              (unsigned long long)unit_bytes, (unsigned long long)plane_bytes, decoders);
     struct Member { uint64_t text_from, text_to, deflate_end; uint32_t crc, isize; };
@@ -572,7 +590,6 @@ int fqd_gunzip_arriving(fqd_engine* e, const uint8_t* deflate, uint64_t avail_by
         }
         // a batch: what the planes hold — less some room for units put in between (below) — and, when there are that many, whole
         // rounds of the decoders (two items a unit): a round that fills a sixth of the chip takes as long as one that fills it
-        const uint64_t one_more = uint64_t(kWindow) + ((2u * unit_bytes * ratio + 1024u + 15u) & ~uint64_t(15)) + 64u;
         const uint64_t spare = std::min<uint64_t>(plane_bytes / 8u, 24u * one_more);
         size_t hi = at; uint64_t used = 0;
         while (hi < ready && used + room_of(units[hi]) <= plane_bytes - spare) { units[hi].at = used; used += room_of(units[hi]); ++hi; }
@@ -584,15 +601,11 @@ int fqd_gunzip_arriving(fqd_engine* e, const uint8_t* deflate, uint64_t avail_by
             // one unit that needs more than a plane holds (FQD_GUNZIP_SCRATCH_MB set small, a long stretch): the planes grow
             plane_bytes = room_of(units[at]) + room_of(units[at]) / 4u;
             GZ_TRY(e, hipStreamSynchronize(stream));
-            GZ_TRY(e, d_p.get(plane_bytes + 64));
-            GZ_TRY(e, d_q.get(plane_bytes + 64));
+            if ((rc = place())) return rc;
             continue;
         }
         uint32_t nb = uint32_t(hi - at);                                      // (up to 24 units may be put in between, below)
-        GZ_TRY(e, d_units.get((nb + 24u) * sizeof(UnitIn)));
-        GZ_TRY(e, d_result.get(2u * (nb + 24u) * sizeof(UnitOut)));
-        GZ_TRY(e, d_text_at.get((nb + 24u) * 8));
-        GZ_TRY(e, d_windows.get(uint64_t(nb + 25u) * kWindow));
+        if (nb + 24u > nb_cap) { hi = at + size_t(nb_cap - 24u); nb = uint32_t(hi - at); used = units[hi - 1].at + room_of(units[hi - 1]); }   // (cannot be: a unit's room is at least one_more)
         GZ_TRY(e, hipMemcpyAsync(d_units.p, units.data() + at, nb * sizeof(UnitIn), hipMemcpyHostToDevice, stream));
         result.resize(2u * nb);
         GZ_TRACE("batch of %u units queued for decoding (%llu bytes a plane)", nb, (unsigned long long)used);
@@ -642,9 +655,6 @@ int fqd_gunzip_arriving(fqd_engine* e, const uint8_t* deflate, uint64_t avail_by
                 std::vector<UnitIn> ru(again.size());
                 for (size_t i = 0; i < again.size(); ++i) ru[i] = put_in[i].cap ? put_in[i] : units[at + again[i]];
                 std::vector<UnitOut> rr(2u * again.size());
-                DevMem d_ru, d_rr;
-                GZ_TRY(e, d_ru.get(ru.size() * sizeof(UnitIn)));
-                GZ_TRY(e, d_rr.get(rr.size() * sizeof(UnitOut)));
                 GZ_TRY(e, hipMemcpyAsync(d_ru.p, ru.data(), ru.size() * sizeof(UnitIn), hipMemcpyHostToDevice, stream));
                 GZ_TRY(e, hipMemsetAsync(d_counter.p, 0, 64, stream));
                 hipLaunchKernelGGL(gz_decode_planes_kernel, dim3(std::min<uint32_t>(2u * uint32_t(ru.size()), decoders)), dim3(kWave), 0, stream,
@@ -716,7 +726,6 @@ int fqd_gunzip_arriving(fqd_engine* e, const uint8_t* deflate, uint64_t avail_by
         // ---- 4, 5
         GZ_TRY(e, hipMemcpyAsync(d_text_at.p, text_at.data(), live * 8, hipMemcpyHostToDevice, stream));
         GZ_TRY(e, hipMemcpyAsync(d_windows.p, carry.data(), kWindow, hipMemcpyHostToDevice, stream));
-        GZ_TRY(e, d_maps.get(size_t(live) * kWindow * 2));
         hipLaunchKernelGGL(gz_window_maps_kernel, dim3(std::min<uint32_t>(live, uint32_t(n_cu) * 8u)), dim3(256), 0, stream, d_units.as<const UnitIn>(),
                            d_result.as<const UnitOut>(), live, d_p.as<const uint8_t>(), d_q.as<const uint8_t>(), d_maps.as<uint16_t>());
         GZ_TRY(e, hipFuncSetAttribute(reinterpret_cast<const void*>(gz_windows_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(2u * kWindow)));
@@ -738,9 +747,6 @@ int fqd_gunzip_arriving(fqd_engine* e, const uint8_t* deflate, uint64_t avail_by
     if (members.empty()) return FQD_OK;
     uint32_t crc = 0;
     {
-        DevMem d_shift, d_raw;
-        GZ_TRY(e, d_shift.get(8 * 32 * 4));
-        GZ_TRY(e, d_raw.get(((total + kSlice - 1) / kSlice + members.size()) * 4));
         uint32_t shift[8][32];
         Mat m = mat_one_zero_byte();
         for (int k = 0; k < 8; ++k) m = mat_square(m);                        // 256 zero bytes

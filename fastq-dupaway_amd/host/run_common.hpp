@@ -316,9 +316,12 @@ struct FileOnDevice {
     GrowDevice<char> text;
     GrowDevice<uint64_t> start, seq_off; GrowDevice<uint32_t> id_len, seq_len, size;
     Device<uint64_t> tag_off; Device<uint32_t> tag_len;
+    // what inflated an ordinary gzip file here (fetch_gzip_ordinary): the packed bytes and the engine whose scratch the inflating
+    // used stay until the run ends — gigabytes freed in mid-run are cleared by the driver while the process's next hipMalloc waits
+    Device<char> packed; std::shared_ptr<EngineHandle> codec;
     uint64_t n = 0;
     void forget() { text.used = start.used = seq_off.used = id_len.used = seq_len.used = size.used = 0; n = 0; }
-    void release() { text.release(); start.release(); seq_off.release(); id_len.release(); seq_len.release(); size.release(); tag_off.release(); tag_len.release(); n = 0; }
+    void release() { packed.release(); codec.reset(); text.release(); start.release(); seq_off.release(); id_len.release(); seq_len.release(); size.release(); tag_off.release(); tag_len.release(); n = 0; }
 };
 
 // A BGZF input of the resident run goes to HBM as it lies on disk — a fifth of its text — and is inflated and cut

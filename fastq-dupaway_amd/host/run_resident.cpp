@@ -297,7 +297,7 @@ bool fetch_gzip_ordinary(const std::string& name, size_t block_bytes, int device
     HIP_OK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
     struct Guard { hipStream_t& s; ~Guard() { if (s) (void)hipStreamDestroy(s); } } g{up}, gw{work};
     HIP_OK(hipStreamCreateWithFlags(&work, hipStreamNonBlocking));
-    Device<char> comp;
+    Device<char>& comp = f.packed;                                 // (stays with the file: see FileOnDevice)
     comp.reserve(size + 64);
     HIP_OK(hipMemsetAsync(comp.p + size, 0, 64, up));
     HIP_OK(hipStreamSynchronize(up));
@@ -312,7 +312,8 @@ bool fetch_gzip_ordinary(const std::string& name, size_t block_bytes, int device
         try {
             HIP_OK(hipSetDevice(device));
             { StageClock::Scope t("  ordinary gzip: room for the text (under the read)"); f.text.room_for(room + 64, work); }
-            EngineHandle eng(1, device, work);                    // a small engine of this thread's own: the stream and the error slot of the call
+            f.codec = std::make_shared<EngineHandle>(1, device, nullptr);   // a small engine of this file's own: stream, scratch and error slot of the call
+            EngineHandle& eng = *f.codec;
             StageClock::Scope t("  ordinary gzip: inflated on the GPU (fqd_gunzip_arriving, under the read and after it)");
             out.rc = fqd_gunzip_arriving(eng.e, reinterpret_cast<const uint8_t*>(comp.p) + header, size - header, &arrived,
                                          reinterpret_cast<uint8_t*>(f.text.p), room, &out.tb, &out.db, &out.crc, &out.ok);
@@ -342,6 +343,8 @@ bool fetch_gzip_ordinary(const std::string& name, size_t block_bytes, int device
     if (out.thrown) std::rethrow_exception(out.thrown);
     if (out.rc != FQD_OK) throw DeviceError(std::string("GPU engine: ") + out.error);
     // (every member's CRC-32 and ISIZE were held against its trailer by the call)
+    static const bool park = [] { const char* v = std::getenv("FQD_GUNZIP_PARK"); return !v || std::atoi(v) != 0; }();   // 0: give the scratch and the packed bytes back at once (A/B)
+    if (!park) { f.codec.reset(); f.packed.release(); }
     if (!out.ok || header + out.db + 8 != size) { f.text.used = 0; return false; }
     text_bytes = out.tb;
     return true;

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--reads", type=int, default=30_000_000)
     ap.add_argument("--dir", default="/dev/shm/fqd_og")
     ap.add_argument("--quick", action="store_true", help="host reader: the default and zlib only")
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--settle", type=float, default=0.0, help="seconds to wait before every timed run (the driver clears what the process before gave back)")
     ap.add_argument("--rocprof", default="", help="directory for a rocprofv3 --kernel-trace --stats run of the device path")
     ap.add_argument("--out-gz", action="store_true", help="write out.fq.gz (deflated on the GPU in the resident run) instead of a plain file")
     a = ap.parse_args()
@@ -51,9 +53,10 @@ def main():
     said = {}
     sfx = ".gz" if a.out_gz else ""
     # first the default (round 4: the file to HBM as it lies on disk, inflated there by fqd_gunzip), twice, with its stages
-    for rep in range(2):
+    for rep in range(a.reps):
         out = d / ("out_dev.fq" + sfx)
         out.unlink(missing_ok=True)
+        time.sleep(a.settle)
         t0 = time.perf_counter()
         r = subprocess.run([str(_lib.CLI_PATH), "-i", str(gz), "-o", str(out), "--fast", "-v"], capture_output=True, text=True,
                            env=dict(os.environ, FQD_HOST_TIMING="1", FQD_GUNZIP_TRACE="1"))

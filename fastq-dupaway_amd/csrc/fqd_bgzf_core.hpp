@@ -3,7 +3,7 @@
 //
 // The reference writes `.gz` outputs through Boost's zlib filter (file_utils.hpp:71-82), one
 // thread, level 6.  Here the surviving records are already in HBM when they are to be written
-// (hash_dup_remover.cpp, resident `--unordered` run), so the deflate happens there too and only
+// (host/run_resident.cpp + survivor_writer.cpp, the resident runs), so the deflate happens there too and only
 // the compressed bytes cross PCIe.  What a member holds is text of FASTQ/FASTA records, and the
 // coder is built for that and nothing else:
 //   * a member (65280 input bytes) belongs to one workgroup of 512 threads; thread t owns the 128

@@ -308,7 +308,7 @@ constexpr uint32_t kBurst = 32;                        // literal turns in a row
 template <bool kWrite, class S>
 FQD_HD void decode_range(const S& sh, Bits& in, uint32_t from, uint32_t stop, uint32_t total_bits,
                          uint32_t& end, uint32_t& nbytes, uint32_t& ntok, uint32_t& flags,
-                         uint8_t* out, uint32_t out_len, uint32_t pos, Token* tok, uint32_t tk)
+                         uint8_t* out, uint32_t out_len, uint32_t pos, Token* tok, uint32_t tk, uint8_t* out2 = nullptr)
 {
     in.seek(from);
     uint32_t bytes = 0, matches = 0, fl = 0, burst = 0;
@@ -320,13 +320,13 @@ FQD_HD void decode_range(const S& sh, Bits& in, uint32_t from, uint32_t stop, ui
         acc |= uint64_t(lits) << (8u * waiting);
         waiting += n; pos += n;
         if (waiting >= 8u) {
-            if (pos - waiting + 8u <= out_len) store8(out + (pos - waiting), acc);
+            if (pos - waiting + 8u <= out_len) { store8(out + (pos - waiting), acc); if (out2) store8(out2 + (pos - waiting), acc); }
             waiting -= 8u;
             acc = waiting ? uint64_t(lits) >> (8u * (n - waiting)) : 0ull;
         }
     };
     auto flush = [&]() {
-        if (waiting && pos <= out_len) store_low(out + (pos - waiting), acc, waiting);
+        if (waiting && pos <= out_len) { store_low(out + (pos - waiting), acc, waiting); if (out2) store_low(out2 + (pos - waiting), acc, waiting); }
         waiting = 0; acc = 0;
     };
     // A turn of this loop costs every lane of the wave every branch some lane takes, and literals are most of what
@@ -469,8 +469,9 @@ FQD_HD void copy_chunk(uint8_t* d, uint32_t len, uint32_t dist, uint32_t per, ui
 // Matches of one window, in stream order, 64 at a time.  A match may be copied once no unresolved match of its group
 // writes into the bytes it reads (everything before the group is final: literals are, and earlier groups are done).
 template <class Ctx, class S>
-FQD_HD bool resolve_matches(Ctx& ctx, S& sh, uint8_t* out, const Token* tok, uint32_t ntok)
-{
+FQD_HD bool resolve_matches(Ctx& ctx, S& sh, uint8_t* out, const Token* tok, uint32_t ntok, uint8_t* out2 = nullptr)
+{   // out2: a SECOND text the same tokens are applied to (csrc/fqd_gunzip.hip: the two planes of a unit, which differ only in the
+    // 32 KiB before the stretch): every copy is made in both, in the same round — the trips to memory that wait for each other are shared
     constexpr uint32_t L = Ctx::kLanes;
     bool fine = true;
     for (uint32_t g0 = 0; g0 < ntok; g0 += L) {
@@ -539,6 +540,7 @@ FQD_HD bool resolve_matches(Ctx& ctx, S& sh, uint8_t* out, const Token* tok, uin
             ctx.lanes_open([&](uint32_t j) {
                 if (!(((go & ~big) >> j) & 1ull)) return;
                 copy_short(out + sh.pl.tok_dst[j], sh.pl.tok_len[j], sh.pl.tok_dist[j], sh.pl.pre_bytes[j]);
+                if (out2) copy_short(out2 + sh.pl.tok_dst[j], sh.pl.tok_len[j], sh.pl.tok_dist[j], sh.pl.pre_bytes[j]);
             });
             // (matches that go in the same round neither read nor write each other's bytes: no need to wait in between)
             constexpr uint32_t kAtOnce = L >= 63u ? 3u : 1u, kPerMatch = L / kAtOnce;     // 17 chunks hold 258 bytes
@@ -552,8 +554,10 @@ FQD_HD bool resolve_matches(Ctx& ctx, S& sh, uint8_t* out, const Token* tok, uin
                     if (q >= kAtOnce) return;
                     const uint32_t j = q == 0u ? t0 : q == 1u ? t1 : t2;
                     if (j >= 64u) return;
-                    for (uint32_t i = k % kPerMatch; i < 17u; i += kPerMatch)
+                    for (uint32_t i = k % kPerMatch; i < 17u; i += kPerMatch) {
                         copy_chunk(out + sh.pl.tok_dst[j], sh.pl.tok_len[j], sh.pl.tok_dist[j], sh.pl.pre_bytes[j], i);
+                        if (out2) copy_chunk(out2 + sh.pl.tok_dst[j], sh.pl.tok_len[j], sh.pl.tok_dist[j], sh.pl.pre_bytes[j], i);
+                    }
                 });
             }
             ctx.sync();
@@ -575,7 +579,7 @@ FQD_HD bool resolve_matches(Ctx& ctx, S& sh, uint8_t* out, const Token* tok, uin
 constexpr uint32_t kStopHere = 100;
 template <bool kUnit, class Ctx, class S>
 FQD_HD uint32_t inflate_impl(Ctx& ctx, S& sh, const uint8_t* comp, uint32_t comp_len, uint32_t first_bit, uint32_t stop_bit,
-                             uint8_t* out, uint32_t out_start, uint32_t out_len, Token* tok, uint32_t* info)
+                             uint8_t* out, uint32_t out_start, uint32_t out_len, Token* tok, uint32_t* info, uint8_t* out2 = nullptr)
 {
     constexpr uint32_t L = Ctx::kLanes;
     const uint32_t total_bits = comp_len * 8u;
@@ -614,7 +618,7 @@ FQD_HD uint32_t inflate_impl(Ctx& ctx, S& sh, const uint8_t* comp, uint32_t comp
             const uint32_t n = ctx.same(sh.same[4]), first = bitpos / 8u;
             if (outpos + n > out_len) return kOutputOverrun;
             if (first + n > comp_len) return kInputOverrun;
-            ctx.lanes([&](uint32_t lane) { for (uint32_t k = lane; k < n; k += L) out[outpos + k] = comp[first + k]; });
+            ctx.lanes([&](uint32_t lane) { for (uint32_t k = lane; k < n; k += L) { out[outpos + k] = comp[first + k]; if (out2) out2[outpos + k] = comp[first + k]; } });
             outpos += n; bitpos += 8u * n;
             ctx.mark(6);
             if (last) break;
@@ -724,10 +728,10 @@ FQD_HD uint32_t inflate_impl(Ctx& ctx, S& sh, const uint8_t* comp, uint32_t comp
                 Bits in; in.open(comp, comp_len);
                 uint32_t end, nb, nt, fl;
                 decode_range<true>(sh, in, sh.pl.start[lane], bitpos + (lane + 1u) * sub, total_bits, end, nb, nt, fl,
-                                   out, out_len, outpos + sh.pl.pre_bytes[lane], tok, sh.pl.pre_tok[lane]);
+                                   out, out_len, outpos + sh.pl.pre_bytes[lane], tok, sh.pl.pre_tok[lane], out2);
             });
             ctx.mark(4);
-            if (!resolve_matches(ctx, sh, out, tok, toks)) return kBadDistance;
+            if (!resolve_matches(ctx, sh, out, tok, toks, out2)) return kBadDistance;
             ctx.mark(5);
             outpos += bytes;
             bitpos = ctx.same(sh.pl.end[valid - 1u]);
@@ -746,9 +750,9 @@ FQD_HD uint32_t inflate_member(Ctx& ctx, S& sh, const uint8_t* comp, uint32_t co
 }
 template <class Ctx, class S>
 FQD_HD uint32_t inflate_stretch(Ctx& ctx, S& sh, const uint8_t* comp, uint32_t comp_len, uint32_t first_bit, uint32_t stop_bit,
-                                uint8_t* out, uint32_t out_start, uint32_t out_len, Token* tok, uint32_t* info)
-{
-    return inflate_impl<true>(ctx, sh, comp, comp_len, first_bit, stop_bit, out, out_start, out_len, tok, info);
+                                uint8_t* out, uint32_t out_start, uint32_t out_len, Token* tok, uint32_t* info, uint8_t* out2 = nullptr)
+{   // out2: a second room of the same size whose text differs from out's only through what the caller put before out_start in each
+    return inflate_impl<true>(ctx, sh, comp, comp_len, first_bit, stop_bit, out, out_start, out_len, tok, info, out2);
 }
 
 } // namespace winf

@@ -622,7 +622,7 @@ void gather_seq_kernel(const uint32_t* __restrict__ idx, uint64_t n, const uint6
 }
 
 // ---------------------------------------------------------------------------------------------
-// Support kernels of the bounded-memory `--unordered` run (host/hash_dup_remover.cpp,
+// Support kernels of the bounded-memory `--unordered` run (host/run_unordered.cpp,
 // run_unordered_streaming): the host streams both files through small pinned blocks; what the join
 // and the dedup need of every record — its tag and its sequence — is copied out of the uploaded block
 // into stores that stay in HBM, and where every surviving record goes in the output is computed here.

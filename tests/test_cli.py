@@ -586,18 +586,20 @@ def test_ordered_runs_on_bgzf_inputs_stay_on_the_device(exe, oracle, tmp_path, c
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["single", "paired", "unordered"])
-@pytest.mark.parametrize("case", ["good", "header_fields", "flipped_bit", "truncated", "two_members", "bad_base"])
+@pytest.mark.parametrize("case", ["good", "header_fields", "flipped_bit", "truncated", "two_members", "bad_base", "very_packable"])
 def test_ordinary_gzip_inputs_inflated_on_the_device(exe, oracle, tmp_path, case, mode):
     """FQD_GUNZIP_ORDINARY_DEVICE=1: an ordinary `.gz` (one long deflate stream, what gzip / pigz / sequencers write; reference
     file_utils.cpp:59-66 reads it through the same decompressor) goes to HBM as it lies on disk and is inflated THERE
     (fqd_gunzip).  Good files: the oracle's bytes and lines, and the device really did it (its stage shows in the timing).
     Several members (`cat a.gz b.gz`) are walked on the device too.  Anything irregular — damage, a cut file, an unknown base —
     is left to the host reader: exactly what the run with FQD_GUNZIP_ORDINARY_DEVICE=0 gives, message, exit code and partial
-    output alike."""
+    output alike; so is a text that packs more than the eightfold the device reader keeps room for (one read repeated: 200-fold)."""
     from gunzip_cases import header_with_fields, member
     rnd = random.Random(23)
     n = 30000
     seqs = random_reads(rnd, n, 4000, 60, 100)
+    if case == "very_packable":
+        seqs = [b"ACGTTGCA" * 12] * n
     r1 = [(b"M01:7:FC:1:%d:%d 1:N:0" % (1100 + k % 7, 1000 + k), seqs[k]) for k in range(n)]
     r2 = [(b"M01:7:FC:1:%d:%d 2:N:0" % (1100 + k % 7, 1000 + k), seqs[(k * 13) % n]) for k in range(n)]
     if case == "bad_base":
@@ -629,7 +631,7 @@ def test_ordinary_gzip_inputs_inflated_on_the_device(exe, oracle, tmp_path, case
             assert "ordered/resident: survivors out of HBM" in r.stderr, r.stderr       # the resident run took the files: nothing was left to the host reader
     assert runs["1"] == runs["0"]
     rc, out, said, got = runs["1"]
-    if case in ("good", "header_fields", "two_members"):
+    if case in ("good", "header_fields", "two_members", "very_packable"):
         ps = [tmp_path / f"p{s + 1}.fq" for s in range(S)]
         es = [tmp_path / f"e{s + 1}.fq" for s in range(S)]
         for s in range(S):

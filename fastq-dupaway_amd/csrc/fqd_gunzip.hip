@@ -8,8 +8,8 @@
 //   gz_find_starts_kernel   one wave per unit of the compressed bytes: 64 bit offsets at a time are given a first look
 //                           (three header bits, counts, a complete code-length code: registers only); the few that pass
 //                           get the second look (all code lengths, both codes complete) one after the other;
-//   gz_decode_planes_kernel one wave per unit and plane: the wave decoder of the BGZF reader (fqd_inflate_wave.hpp), run twice per
-//                           unit over two made-up windows — what comes out the same in both planes is a byte of the stream,
+//   gz_decode_planes_kernel one wave per unit: the wave decoder of the BGZF reader (fqd_inflate_wave.hpp) writing TWO texts of the
+//                           unit behind two made-up windows — what comes out the same in both planes is a byte of the stream,
 //                           what differs says which byte of the unknown window it is;
 //   gz_window_maps_kernel,  the 32 KiB of text that end with a unit: which place of the window before every place copies (all units at
 //   gz_windows_chain_kernel once), then the windows themselves unit after unit, the running window in LDS;
@@ -122,16 +122,16 @@ void gz_find_starts_kernel(BitIn in, uint64_t unit_bits, uint64_t first_unit, ui
     }
 }
 
-// ---- 2. a unit decoded — twice, as BYTES -------------------------------------------------------------------------------------
+// ---- 2. a unit decoded — into two texts, as BYTES -------------------------------------------------------------------------------------
 // The wave decoder of the BGZF reader (fqd_inflate_wave.hpp: the lanes decode a block's bits side by side from guessed code
 // boundaries, matches are resolved 64 at a time) writes bytes and copies bytes; what a unit needs are SYMBOLS — "a byte", or
-// "the byte at place w of the 32 KiB before me", which nobody knows yet.  It gets them without a line of that decoder
-// changed: the unit is decoded twice, each time with a MADE-UP window in front of its room,
+// "the byte at place w of the 32 KiB before me", which nobody knows yet.  It gets them from that decoder as it is, given a
+// second output: the unit's text is written twice — every literal stored, every match copied in both — each behind a MADE-UP window,
 //     plane P: window[w] = w & 255          plane Q: window[w] = (w & 255) ^ (1 + (w >> 8))
 // Copies are the identity on bytes, so a byte that was copied (however often) from place w of the window comes out as P[w] in
 // one plane and Q[w] in the other — two values that differ for every w and give w back — and a literal of the stream comes
-// out the same in both.  P == Q: the byte; otherwise w = P | ((P ^ Q) - 1) << 8.  Twice the decoding at 50 times the speed of
-// the one-lane decoder this kernel replaced (csrc/fqd_gunzip_core.hpp, kept as the CPU reference form: 4.6 GB/s of text).
+// out the same in both.  P == Q: the byte; otherwise w = P | ((P ^ Q) - 1) << 8.  Twice the stores and copies at 50 times the speed
+// of the one-lane decoder this kernel replaced (csrc/fqd_gunzip_core.hpp, kept as the CPU reference form: 4.6 GB/s of text).
 struct UnitIn  { uint64_t start_bit, stop_bit, at, cap; };                   // where to start, the next unit's nominal start, the unit's place in a plane, room behind the window
 struct UnitOut { uint64_t end_bit, n; uint32_t status, how; };               // how: 1 a boundary, 2 the final block's end
 
@@ -162,29 +162,34 @@ void gz_decode_planes_kernel(const uint8_t* __restrict__ deflate, uint64_t avail
     for (;;) {
         if (threadIdx.x == 0) my_item = atomicAdd(next_item, 1u);
         __syncthreads();
-        const uint32_t item = my_item;
+        const uint32_t u = my_item;
         __syncthreads();
-        if (item >= 2u * n_units) break;
-        const uint32_t u = item >> 1, plane = item & 1u;
+        if (u >= n_units) break;
         const UnitIn ui = units[u];
-        uint8_t* out = (plane ? plane_q : plane_p) + ui.at;
-        // the made-up window: 32 KiB, sixteen bytes a lane and store
+        uint8_t* out_p = plane_p + ui.at;
+        uint8_t* out_q = plane_q + ui.at;
+        // the two made-up windows: 32 KiB each, sixteen bytes a lane and store
         for (uint32_t w0 = threadIdx.x * 16u; w0 < kWindow; w0 += kWave * 16u) {
-            uint32_t v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t w = w0 + 4u * k;
-                v[k] = made_up(plane, w) | (made_up(plane, w + 1u) << 8) | (made_up(plane, w + 2u) << 16) | (made_up(plane, w + 3u) << 24);
+            for (uint32_t plane = 0; plane < 2u; ++plane) {
+                uint32_t v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t w = w0 + 4u * k;
+                    v[k] = made_up(plane, w) | (made_up(plane, w + 1u) << 8) | (made_up(plane, w + 2u) << 16) | (made_up(plane, w + 3u) << 24);
+                }
+                reinterpret_cast<uint4*>((plane ? out_q : out_p) + w0)[0] = uint4{v[0], v[1], v[2], v[3]};
             }
-            reinterpret_cast<uint4*>(out + w0)[0] = uint4{v[0], v[1], v[2], v[3]};
         }
         __syncthreads();
         const uint64_t byte0 = ui.start_bit >> 3;
         const uint64_t left = avail_bytes - byte0;
         const uint32_t comp_len = uint32_t(left < (1ull << 28) ? left : (1ull << 28));
         const uint64_t rel = ui.stop_bit == ~0ull ? 0xFFFFFFFFull : ui.stop_bit - byte0 * 8u;
+        // ONE decode, two texts: the codes are read once, every literal is stored and every match copied in both planes (round 4's
+        // first version decoded the unit once per plane: 210 of the 360 ms of a 9.5 GB file)
         const uint32_t st = fqd::winf::inflate_stretch(ctx, sh, deflate + byte0, comp_len, uint32_t(ui.start_bit & 7u), uint32_t(rel < 0xFFFFFFFFull ? rel : 0xFFFFFFFFull),
-                                                       out, kWindow, uint32_t(kWindow + ui.cap), tok, info);
+                                                       out_p, kWindow, uint32_t(kWindow + ui.cap), tok, info, out_q);
         __syncthreads();
         if (threadIdx.x == 0) {
             UnitOut r;
@@ -192,7 +197,7 @@ void gz_decode_planes_kernel(const uint8_t* __restrict__ deflate, uint64_t avail
             r.end_bit = st == fqd::winf::kOk ? byte0 * 8u + info[0] : 0;
             r.n = st == fqd::winf::kOk ? info[1] - kWindow : 0;
             r.how = st == fqd::winf::kOk ? info[2] : 0;
-            result[item] = r;
+            result[2u * u] = r; result[2u * u + 1u] = r;                      // (one entry per plane, as the host has known them)
         }
         __syncthreads();
     }
@@ -432,10 +437,10 @@ int fqd_gunzip_arriving(fqd_engine* e, const uint8_t* deflate, uint64_t avail_by
     if (const char* v = std::getenv("FQD_GUNZIP_RATIO")) { const long r = std::atol(v); if (r > 0) ratio = uint64_t(r); }
     const uint64_t n_nominal = (avail_bytes + unit_bytes - 1) / unit_bytes;
 
-    // ---- 2-5 in batches of units whose two planes fit the scratch: by default TWO rounds of the chip's decoders (two items a unit)
+    // ---- 2-5 in batches of units whose two planes fit the scratch: by default up to two rounds of the chip's decoders (a wave a unit)
     const uint64_t one_more = uint64_t(kWindow) + ((2u * unit_bytes * ratio + 1024u + 15u) & ~uint64_t(15)) + 64u;     // the room of a unit of one nominal unit
-    const uint32_t decoders = uint32_t(std::min<uint64_t>(2u * n_nominal, uint64_t(n_cu) * 16u));      // 10 KB of LDS, <= 128 VGPRs: sixteen waves a CU
-    uint64_t plane_bytes = std::min<uint64_t>(uint64_t(8) << 30, (decoders + 64u) * one_more);        // per plane: two rounds (two back to back take 48 ms where one takes 30)
+    const uint32_t decoders = uint32_t(std::min<uint64_t>(n_nominal, uint64_t(n_cu) * 16u));           // a wave a unit; 10 KB of LDS, <= 128 VGPRs: sixteen waves a CU
+    uint64_t plane_bytes = std::min<uint64_t>(uint64_t(8) << 30, (2u * decoders + 64u) * one_more);   // per plane: two rounds if 8 GiB hold them (two back to back take less than twice one)
     if (const char* v = std::getenv("FQD_GUNZIP_SCRATCH_MB")) { const long mb = std::atol(v); if (mb > 0) plane_bytes = (uint64_t(mb) << 20) / 2; }
     auto room_of = [](const UnitIn& x) { return uint64_t(kWindow) + x.cap + 64u; };          // made-up window, text, slack (a multiple of 16)
     plane_bytes = std::min(plane_bytes, n_nominal * one_more + 64u * one_more);                       // (never more than all units need)
@@ -555,7 +560,7 @@ int fqd_gunzip_arriving(fqd_engine* e, const uint8_t* deflate, uint64_t avail_by
     };
     auto decode = [&](uint32_t first, uint32_t count) -> int {              // units [first, first + count) of the batch, both planes
         GZ_TRY(e, hipMemsetAsync(d_counter.p, 0, 64, stream));
-        hipLaunchKernelGGL(gz_decode_planes_kernel, dim3(std::min<uint32_t>(2u * count, decoders)), dim3(kWave), 0, stream,
+        hipLaunchKernelGGL(gz_decode_planes_kernel, dim3(std::min<uint32_t>(count, decoders)), dim3(kWave), 0, stream,
                            deflate, have, d_units.as<const UnitIn>() + first, count, d_p.as<uint8_t>(), d_q.as<uint8_t>(),
                            d_tokens.as<fqd::winf::Token>(), d_result.as<UnitOut>() + 2u * first, d_counter.as<uint32_t>());
         GZ_TRY(e, hipGetLastError());
@@ -589,11 +594,11 @@ int fqd_gunzip_arriving(fqd_engine* e, const uint8_t* deflate, uint64_t avail_by
             ready = units.size();
         }
         // a batch: what the planes hold — less some room for units put in between (below) — and, when there are that many, whole
-        // rounds of the decoders (two items a unit): a round that fills a sixth of the chip takes as long as one that fills it
+        // rounds of the decoders (a wave a unit): a round that fills a sixth of the chip takes as long as one that fills it
         const uint64_t spare = std::min<uint64_t>(plane_bytes / 8u, 24u * one_more);
         size_t hi = at; uint64_t used = 0;
         while (hi < ready && used + room_of(units[hi]) <= plane_bytes - spare) { units[hi].at = used; used += room_of(units[hi]); ++hi; }
-        if (const size_t round = decoders / 2u; hi - at > round && (hi < ready || !all_there)) {
+        if (const size_t round = decoders; hi - at > round && (hi < ready || !all_there)) {
             hi = at + (hi - at) / round * round;
             used = units[hi - 1].at + room_of(units[hi - 1]);
         }
@@ -657,7 +662,7 @@ int fqd_gunzip_arriving(fqd_engine* e, const uint8_t* deflate, uint64_t avail_by
                 std::vector<UnitOut> rr(2u * again.size());
                 GZ_TRY(e, hipMemcpyAsync(d_ru.p, ru.data(), ru.size() * sizeof(UnitIn), hipMemcpyHostToDevice, stream));
                 GZ_TRY(e, hipMemsetAsync(d_counter.p, 0, 64, stream));
-                hipLaunchKernelGGL(gz_decode_planes_kernel, dim3(std::min<uint32_t>(2u * uint32_t(ru.size()), decoders)), dim3(kWave), 0, stream,
+                hipLaunchKernelGGL(gz_decode_planes_kernel, dim3(std::min<uint32_t>(uint32_t(ru.size()), decoders)), dim3(kWave), 0, stream,
                                    deflate, have, d_ru.as<const UnitIn>(), uint32_t(ru.size()), d_p.as<uint8_t>(), d_q.as<uint8_t>(),
                                    d_tokens.as<fqd::winf::Token>(), d_rr.as<UnitOut>(), d_counter.as<uint32_t>());
                 GZ_TRY(e, hipGetLastError());

@@ -423,8 +423,8 @@ int  fqd_bgzf_inflate(fqd_engine* e, const uint8_t* comp, const uint64_t* comp_o
  * write; the reference reads it through the same gzip decompressor, file_utils.cpp:59-66) inflated in HBM.  `deflate` (device;
  * any alignment; 32 readable bytes behind the last one) points at the FIRST member's raw deflate stream — the caller has walked
  * its 10-byte-plus header — and avail_bytes says how many bytes of the file lie from there on (trailers and further members
- * included).  The stream is cut into units whose block starts are GUESSED; every unit is decoded on its own — twice, by the wave
- * decoder of the BGZF reader, over two made-up 32 KiB windows, so that what comes out says for every byte whether it is a byte of
+ * included).  The stream is cut into units whose block starts are GUESSED; every unit is decoded on its own — by the wave
+ * decoder of the BGZF reader, into two texts behind two made-up 32 KiB windows, so that what comes out says for every byte whether it is a byte of
  * the stream or a copy of a place of the window before the unit — the chain of unit ends and starts is checked (a wrong guess:
  * the unit is decoded again from the true boundary), the windows are made unit after unit, and the places become text
  * (csrc/fqd_gunzip.hip).  Further members are walked where a final block ends; every member's CRC-32 and ISIZE are held against

@@ -4,7 +4,7 @@
 // written for tests/test_gunzip_core.py to compare with what zlib makes of the same file.  Test infrastructure only.
 //   gunzip_core_check <in.gz> <out> <unit_bytes> [max_ratio] [serial|planes]     prints: status units bytes_out deflate_bytes
 //   serial: fqd_gunzip_core.hpp's one decoder per unit writing symbols; planes (what the kernels do): the wave decoder of
-//   fqd_inflate_wave.hpp (its lanes a loop here) run TWICE per unit over two made-up windows, whose outputs together ARE the symbols
+//   fqd_inflate_wave.hpp (its lanes a loop here) run per unit over TWO made-up windows at once, whose two texts together ARE the symbols
 //   status: ok | chain (a unit does not start where the one before it ended) | bad (damaged data) | full (a unit's room) | header
 #include <cstdio>
 #include <cstdlib>
@@ -94,7 +94,7 @@ int main(int argc, char** argv)
     std::vector<fqd::winf::Token> wtok(fqd::winf::kTokenRoom);
     auto decode = [&](Unit& x) {
         if (planes) {
-            // the unit twice through the byte decoder, the 32 KiB before it made up: plane_P[w] = w & 255, plane_Q[w] = (w & 255) ^ (1 + (w >> 8)).
+            // the unit through the byte decoder into two texts, the 32 KiB before each made up: plane_P[w] = w & 255, plane_Q[w] = (w & 255) ^ (1 + (w >> 8)).
             // A byte that comes out the same in both is a literal of the stream; one that differs was copied from place w of the window.
             const uint64_t cap = x.span * ratio + 1024;
             std::vector<uint8_t> pl[2];
@@ -110,9 +110,11 @@ int main(int argc, char** argv)
             for (int p = 0; p < 2; ++p) {
                 pl[p].assign(kWindow + cap + 16, 0xEE);
                 for (uint32_t w = 0; w < kWindow; ++w) pl[p][w] = p ? uint8_t((w & 255u) ^ (1u + (w >> 8))) : uint8_t(w & 255u);
-                st[p] = fqd::winf::inflate_stretch(ctx, *wsh, cp, comp_len, first_bit, uint32_t(std::min<uint64_t>(rel_stop, 0xFFFFFFFFull)),
-                                                   pl[p].data(), kWindow, uint32_t(kWindow + cap), wtok.data(), info[p]);
             }
+            // ONE decode writes both planes (as gz_decode_planes_kernel does): literals stored twice, matches copied in each
+            st[0] = st[1] = fqd::winf::inflate_stretch(ctx, *wsh, cp, comp_len, first_bit, uint32_t(std::min<uint64_t>(rel_stop, 0xFFFFFFFFull)),
+                                                       pl[0].data(), kWindow, uint32_t(kWindow + cap), wtok.data(), info[0], pl[1].data());
+            info[1][0] = info[0][0]; info[1][1] = info[0][1]; info[1][2] = info[0][2];
             if (st[0] != fqd::winf::kOk || st[1] != fqd::winf::kOk || info[0][0] != info[1][0] || info[0][1] != info[1][1]) {
                 x.status = st[0] == fqd::winf::kOutputOverrun || st[1] == fqd::winf::kOutputOverrun ? uint32_t(kOutputFull) : uint32_t(kBadData);
                 x.end = 0; x.sym.clear();
